@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- NW-head hot path on MI355X.  Contract: see the task statement / DESIGN.md.
+
+One "step" = one query batch (B=256, d=512) predicted against the whole support bank
+('full' inference, nwhead/nw.py:127-160 with mode='full'): scores -> softmax -> label aggregation ->
+log.  Workload "K3": bank N=50000, d=512, C=200 (BASELINE.json configs[2]); with --gpus G the bank is
+sharded G ways (strong scaling), partials are exchanged with one RCCL all-gather per bucket of steps.
+The north-star shape T (B=256, N=10000, d=512) is measured in the same run on rank 0 and reported in
+the same JSON line under "north_star_T".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA peak (= vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def alg_bytes(B, N, d, C):
+    return 4 * B * d + 4 * N * d + 8 * N + 4 * B * C
+
+
+def alg_flops(B, N, d):
+    return 2 * B * N * d + 10 * B * N
+
+
+def make_inputs(B, N, d, C, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, d, generator=g)
+    s = torch.randn(N, d, generator=g)
+    sy = (torch.arange(N) % C).sort().values            # class-sorted, balanced like the 'full' bank
+    return q.to(dev), s.to(dev), sy.to(dev)
+
+
+def time_kernel_events(fn, iters, warmup=3):
+    """Average device time of fn() over `iters` launches on the current stream (HIP events)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3      # seconds
+
+
+def measure_shape(B, N, d, C, dev, iters):
+    """Single-GPU forward at one shape: whole-op time and the dominant (scores) kernel's time."""
+    from nwhead_amd import ops
+    q, s, sy = make_inputs(B, N, d, C, dev)
+    t_fwd = time_kernel_events(lambda: ops.nw_head(q, s, sy, C), iters)
+    t_sc = time_kernel_events(lambda: ops.nw_scores(q, s), iters)
+    fl = alg_flops(B, N, d)
+    return {"B": B, "N": N, "d": d, "C": C, "ms_per_call": t_fwd * 1e3, "query_pred_per_s": B / t_fwd,
+            "alg_GBps": alg_bytes(B, N, d, C) / t_fwd / 1e9, "frac_hbm": alg_bytes(B, N, d, C) / t_fwd / 1e9 / PEAK_HBM_GBS,
+            "scores_kernel_us": t_sc * 1e6, "scores_kernel_TFLOPs": 2 * B * N * d / t_sc / 1e12,
+            "frac_mfma_f32": 2 * B * N * d / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "whole_op_frac_of_roofline": max(alg_bytes(B, N, d, C) / (PEAK_HBM_GBS * 1e9), fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) / t_fwd}
+
+
+def cpu_baseline(B_sample, N, d, C, budget_s=20.0):
+    """The reference's op sequence (oracle port) on this host's cores, bounded sample."""
+    from oracle import nw_oracle as O
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B_sample, d, generator=g)
+    s = torch.randn(N, d, generator=g)
+    sy = (torch.arange(N) % C).sort().values
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        O.nw_head_f32(q, s, sy, C)                          # warm-up
+        times, t_all = [], time.perf_counter()
+        while len(times) < 5 and (time.perf_counter() - t_all) < budget_s:
+            t0 = time.perf_counter()
+            O.nw_head_f32(q, s, sy, C)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B_sample / med, "unit": "query-predictions/s", "cores": cores, "kind": "port",
+            "sample": f"B={B_sample} queries x full bank N={N}, d={d}, C={C}; median of {len(times)} calls, "
+                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--bank", type=int, default=50000)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--classes", type=int, default=200)
+    ap.add_argument("--bucket", type=int, default=8, help="query batches per RCCL all-gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from nwhead_amd import ops
+    from nwhead_amd.sharded import ShardedBank, shard_bounds
+
+    B, N, d, C = args.batch, args.bank, args.dim, args.classes
+    q, s, sy = make_inputs(B, N, d, C, dev)
+    lo, hi = shard_bounds(N, world, rank)
+    bank = ShardedBank(s[lo:hi].clone(), sy[lo:hi].clone(), C)
+    del s
+    # a few distinct query batches so that nothing is cached across steps
+    gq = torch.Generator().manual_seed(123)
+    qs = [torch.randn(B, d, generator=gq).to(dev) for _ in range(4)]
+
+    def run(nsteps):
+        if world == 1:
+            outs = None
+            for i in range(nsteps):
+                outs = ops.nw_head(qs[i % 4], bank.feat, bank.y, C)
+            return outs
+        return bank.predict_stream([qs[i % 4] for i in range(nsteps)], bucket=args.bucket)[-1]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    line = None
+    if rank == 0:
+        n_shard = hi - lo
+        t_sc = time_kernel_events(lambda: ops.nw_scores(qs[0], bank.feat), 50)
+        flops = 2.0 * B * n_shard * d
+        roof = {"bound": "mfma", "kernel": "nw_scores_mfma_kernel", "achieved": flops / t_sc / 1e12,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "launch_us": t_sc * 1e6, "alg_flops_per_launch": flops,
+                "alg_bytes_per_launch": alg_bytes(B, n_shard, d, C),
+                "alg_GBps": alg_bytes(B, n_shard, d, C) / t_sc / 1e9}
+        line = {"metric": "query-predictions/sec", "value": args.steps * B / dt, "unit": "query-predictions/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"K3 predict('full'): B={B} queries/step vs bank N={N} d={d} C={C}, "
+                                       f"bank sharded {world}-way" + (f", all-gather bucket {args.bucket}" if world > 1 else ""),
+                           "B": B, "N_support": N, "d": d, "C": C, "parallelism": f"support-shard x{world}"},
+                "roofline": roof}
+        if world == 1:
+            line["north_star_T"] = measure_shape(256, 10000, 512, 200, dev, 100)
+            line["config_K2_head"] = measure_shape(64, 1000, 512, 200, dev, 100)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(32, N, d, C)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * nwhead_hip.h -- C ABI of libnwhead_hip.so: the MI355X (gfx950) implementation of the
+ * Nadaraya-Watson head hot path of alanqrwang/nwhead @ 2024_08_07.
+ *
+ * The reference has no FFI; its seam is the Python operator
+ *     NWHead.forward(x, sx, sy)            nwhead/nw.py:266-289
+ * built from                               nwhead/kernel.py:13-44   (score functions)
+ * plus util/metric.py:23-50 (support_influence) and the implicit autograd of the above
+ * (loss.backward(), train.py:414).  Each entry point below names the reference lines it
+ * replaces.  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer into HIP memory owned by the caller, row-major, dense;
+ *     float = IEEE fp32, labels = int64 (torch.long), sizes = int64;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue
+ *     work on it: they never synchronise, never allocate, never free;
+ *   - return value: NW_OK (0) or a negative nw_status; nothing is thrown;
+ *   - stateless and thread-safe: safe from any host thread with its own stream;
+ *   - scratch memory is supplied by the caller; ask nw_*_workspace_bytes() for the size.
+ */
+#ifndef NWHEAD_HIP_H
+#define NWHEAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NW_ABI_VERSION 1
+
+/* score functions = the reference's kernel modules, nwhead/kernel.py:80-97 (get_kernel) */
+typedef enum {
+    NW_SCORE_EUCLIDEAN = 0,   /* -cdist(x, y)                           kernel.py:13-15 */
+    NW_SCORE_HYPERSPHERE = 1, /* -cdist(normalize(x), normalize(y))     kernel.py:17-21 */
+    NW_SCORE_COSINE = 2,      /* normalize(x) . normalize(y)            kernel.py:23-28 */
+    NW_SCORE_DOT = 3,         /* x . y                                  kernel.py:30-33 */
+    NW_SCORE_CLIP = 4         /* exp(logit_scale) * cosine              kernel.py:35-44 */
+} nw_score_kind;
+
+typedef enum {
+    NW_OK = 0,
+    NW_ERR_INVALID_ARG = -1,  /* null pointer, negative size, label array missing ...          */
+    NW_ERR_UNSUPPORTED = -2,  /* unknown score kind                                             */
+    NW_ERR_WORKSPACE = -3,    /* workspace smaller than nw_*_workspace_bytes()                  */
+    NW_ERR_LAUNCH = -4,       /* hipLaunchKernel / hipMemsetAsync reported an error             */
+    NW_ERR_NO_DEVICE = -5     /* no gfx950 device visible to this process                       */
+} nw_status;
+
+int nw_abi_version(void);
+const char *nw_status_string(int status);
+/* 0 when a HIP device is visible and its arch is gfx950, else NW_ERR_NO_DEVICE. */
+int nw_device_check(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scores only.  Replaces kernel(x, y): nwhead/kernel.py:13-44 as called from nwhead/nw.py:283
+ * (x unsqueezed to (B,1,d), y = support) and from NWNet.get_neighbors nwhead/nw.py:248 and
+ * KNN.__call__ nwhead/utils.py:187 (2-D queries x bank).
+ *   q        (B,d)
+ *   s        (N,d) when sup_batched == 0, (B,N,d) when sup_batched != 0
+ *   scores   (B,N) out
+ *   logit_scale_dev  device pointer to the CLIP log-scale scalar (kernel.py:38); only read for
+ *                    NW_SCORE_CLIP; may be NULL otherwise
+ * cdist regime (torch picks the matmul form when N > 25, else the direct difference form): the
+ * same switch is made here so that exact-zero distances behave as in the reference.
+ * ------------------------------------------------------------------------------------------- */
+int nw_scores_f32(const float *q, const float *s, float *scores,
+                  int64_t B, int64_t N, int64_t d,
+                  int kind, const float *logit_scale_dev, int sup_batched, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Forward.  Replaces NWHead.forward nwhead/nw.py:266-289:
+ *     one_hot(sy) -> kernel scores -> softmax over supports -> bmm with one-hot -> log(. + 1e-12)
+ *   sy          (N,) or, when labels_batched != 0, (B,N); values outside [0,C) contribute nothing
+ *   out         (B,C) log-probabilities
+ *   scores_out  optional (B,N): raw scores (saved for backward / neighbour search)
+ *   lse_out     optional (B,):  log sum_j exp(score_bj)  (saved for backward)
+ *   weights_out optional (B,N): softmax weights  (the `sweights` of util/metric.py:23)
+ *   workspace   nw_fwd_workspace_bytes(B,N,d,C) bytes of scratch (may be NULL if that is 0)
+ * ------------------------------------------------------------------------------------------- */
+size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C);
+int nw_fwd_f32(const float *q, const float *s, const int64_t *sy,
+               float *out, float *scores_out, float *lse_out, float *weights_out,
+               void *workspace, size_t workspace_bytes,
+               int64_t B, int64_t N, int64_t d, int64_t C,
+               int kind, const float *logit_scale_dev,
+               int sup_batched, int labels_batched, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sharded 'full' inference (new capability): per-shard partials of the same
+ * forward over this rank's slice of the support bank, and the merge.
+ *   m    (B,)   max_j score            (-inf for an empty shard)
+ *   den  (B,)   sum_j exp(score - m)
+ *   num  (B,C)  sum_{j: sy_j = c} exp(score - m)
+ * nw_merge_finalize_f32 takes the partials of G shards and writes
+ *   out = log(num / den + 1e-12) after rescaling every shard to the common max.
+ *   Shard g's arrays start at m + g*stride_m, den + g*stride_den, num + g*stride_num (strides in
+ *   floats; pass B, B, B*C for dense (G,B) (G,B) (G,B,C) stacks, or the common row length when the
+ *   three sections of each shard are packed in one all-gathered buffer).
+ * ------------------------------------------------------------------------------------------- */
+int nw_fwd_partial_f32(const float *q, const float *s, const int64_t *sy,
+                       float *m, float *den, float *num,
+                       void *workspace, size_t workspace_bytes,
+                       int64_t B, int64_t N, int64_t d, int64_t C,
+                       int kind, const float *logit_scale_dev, void *stream);
+int nw_merge_finalize_f32(const float *m, const float *den, const float *num, float *out,
+                          int64_t G, int64_t B, int64_t C,
+                          int64_t stride_m, int64_t stride_den, int64_t stride_num, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward.  Replaces the autograd graph the reference builds through nwhead/nw.py:276-289 and
+ * nwhead/kernel.py:13-44 (loss.backward(), train.py:414), including torch's zero sub-gradient at
+ * distance 0 (_euclidean_dist_backward / cdist_backward mask).
+ *   scores, lse   as saved by nw_fwd_f32
+ *   out, gout     (B,C) forward output and its incoming gradient
+ *   gq            (B,d) out;  gs (N,d) or (B,N,d) out;  glogit_scale optional scalar out (CLIP)
+ *   workspace     nw_bwd_workspace_bytes(...) bytes
+ * ------------------------------------------------------------------------------------------- */
+size_t nw_bwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C, int kind, int sup_batched);
+int nw_bwd_f32(const float *q, const float *s, const int64_t *sy,
+               const float *scores, const float *lse, const float *out, const float *gout,
+               float *gq, float *gs, float *glogit_scale,
+               void *workspace, size_t workspace_bytes,
+               int64_t B, int64_t N, int64_t d, int64_t C,
+               int kind, const float *logit_scale_dev,
+               int sup_batched, int labels_batched, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * support_influence.  Replaces util/metric.py:23-50, vectorised over the query batch:
+ *   infl[b,j] = log((p - p*w_bj) / (p - w_bj*[sy_j == qy_b])),  p = probs[b, qy_b]
+ *   probs (B,C) = exp(out);  qy (B,) int64;  w (B,N) softmax weights;  sy (N,) int64
+ * Every product/difference/quotient is rounded separately (no FMA contraction) so the +inf / NaN
+ * pattern of the reference's one-shot classes is reproduced.
+ * ------------------------------------------------------------------------------------------- */
+int nw_support_influence_f32(const float *probs, const int64_t *qy, const float *w,
+                             const int64_t *sy, float *infl,
+                             int64_t B, int64_t N, int64_t C, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NWHEAD_HIP_H */

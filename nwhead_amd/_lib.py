@@ -1,0 +1,67 @@
+"""ctypes binding of libnwhead_hip.so (the C ABI in include/nwhead_hip.h).
+
+There is NO fallback: if the shared library is missing, or a tensor is not on a HIP device, the
+ops raise.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C nwhead_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnwhead_hip.so")
+
+SCORE_KINDS = {"euclidean": 0, "hypersphere_euclidean": 1, "cosine": 2, "dotproduct": 3, "clip": 4}
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/nwhead_hip.h one to one
+SIGNATURES = {
+    "nw_abi_version": (_int, []),
+    "nw_status_string": (C.c_char_p, [_int]),
+    "nw_device_check": (_int, []),
+    "nw_scores_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p, _int, _p]),
+    "nw_fwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "nw_fwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
+    "nw_fwd_partial_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _p]),
+    "nw_merge_finalize_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "nw_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int]),
+    "nw_bwd_f32": (_int, [_p] * 10 + [_p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
+    "nw_support_influence_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+}
+
+_lib = None
+
+
+class NWHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NWHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run __graft_entry__.build() "
+            "(or `make -C nwhead_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nw_abi_version() != 1:
+        raise NWHipError("libnwhead_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().nw_status_string(status).decode()
+        raise NWHipError(f"{what}: {msg} (status {status})")

@@ -1,0 +1,103 @@
+// capi.hip -- the extern "C" surface declared in include/nwhead_hip.h (gfx950 / MI355X only).
+#include <string.h>
+#include "nw_internal.h"
+
+namespace {
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline bool bad_kind(int kind) { return kind < NW_SCORE_EUCLIDEAN || kind > NW_SCORE_CLIP; }
+}  // namespace
+
+extern "C" int nw_abi_version(void) { return NW_ABI_VERSION; }
+
+extern "C" const char* nw_status_string(int status) {
+    switch (status) {
+        case NW_OK: return "ok";
+        case NW_ERR_INVALID_ARG: return "invalid argument";
+        case NW_ERR_UNSUPPORTED: return "unsupported score kind or size";
+        case NW_ERR_WORKSPACE: return "workspace too small";
+        case NW_ERR_LAUNCH: return "HIP launch failed";
+        case NW_ERR_NO_DEVICE: return "no gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int nw_device_check(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NW_ERR_NO_DEVICE;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NW_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NW_ERR_NO_DEVICE;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? NW_OK : NW_ERR_NO_DEVICE;
+}
+
+extern "C" int nw_scores_f32(const float* q, const float* s, float* scores, int64_t B, int64_t N,
+                             int64_t d, int kind, const float* logit_scale_dev, int sup_batched,
+                             void* stream) {
+    if (B < 0 || N < 0 || d < 0) return NW_ERR_INVALID_ARG;
+    if (bad_kind(kind)) return NW_ERR_UNSUPPORTED;
+    if (B == 0 || N == 0) return NW_OK;
+    if (!q || !s || !scores) return NW_ERR_INVALID_ARG;
+    if (kind == NW_SCORE_CLIP && !logit_scale_dev) return NW_ERR_INVALID_ARG;
+    return nw::launch_scores(q, s, scores, B, N, d, kind, logit_scale_dev, sup_batched,
+                             static_cast<hipStream_t>(stream));
+}
+
+// The forward keeps one (B,N) fp32 score matrix as scratch when the caller does not ask for it.
+extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C) {
+    (void)d; (void)C;
+    if (B <= 0 || N <= 0) return 0;
+    return align256((size_t)B * (size_t)N * sizeof(float));
+}
+
+extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, float* out,
+                          float* scores_out, float* lse_out, float* weights_out, void* workspace,
+                          size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C,
+                          int kind, const float* logit_scale_dev, int sup_batched,
+                          int labels_batched, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
+    if (bad_kind(kind)) return NW_ERR_UNSUPPORTED;
+    if (B == 0) return NW_OK;
+    if (!out && C > 0) return NW_ERR_INVALID_ARG;
+    if (N > 0 && (!q || !s || !sy)) return NW_ERR_INVALID_ARG;
+    if (kind == NW_SCORE_CLIP && !logit_scale_dev) return NW_ERR_INVALID_ARG;
+    if (labels_batched && !sup_batched) return NW_ERR_INVALID_ARG;
+    float* scores = scores_out;
+    if (!scores && N > 0) {
+        if (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C)) return NW_ERR_WORKSPACE;
+        scores = static_cast<float*>(workspace);
+    }
+    int rc = nw::launch_scores(q, s, scores, B, N, d, kind, logit_scale_dev, sup_batched, st);
+    if (rc != NW_OK) return rc;
+    return nw::launch_aggregate(scores, sy, labels_batched, out, lse_out, weights_out, nullptr,
+                                nullptr, nullptr, B, N, C, st);
+}
+
+extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t* sy, float* m,
+                                  float* den, float* num, void* workspace, size_t workspace_bytes,
+                                  int64_t B, int64_t N, int64_t d, int64_t C, int kind,
+                                  const float* logit_scale_dev, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
+    if (bad_kind(kind)) return NW_ERR_UNSUPPORTED;
+    if (B == 0) return NW_OK;
+    if (!m || !den || (!num && C > 0)) return NW_ERR_INVALID_ARG;
+    if (N > 0 && (!q || !s || !sy)) return NW_ERR_INVALID_ARG;
+    if (kind == NW_SCORE_CLIP && !logit_scale_dev) return NW_ERR_INVALID_ARG;
+    float* scores = static_cast<float*>(workspace);
+    if (N > 0 && (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C))) return NW_ERR_WORKSPACE;
+    int rc = nw::launch_scores(q, s, scores, B, N, d, kind, logit_scale_dev, 0, st);
+    if (rc != NW_OK) return rc;
+    return nw::launch_aggregate(scores, sy, 0, nullptr, nullptr, nullptr, m, den, num, B, N, C, st);
+}
+
+extern "C" int nw_merge_finalize_f32(const float* m, const float* den, const float* num, float* out,
+                                     int64_t G, int64_t B, int64_t C, int64_t stride_m,
+                                     int64_t stride_den, int64_t stride_num, void* stream) {
+    if (G < 0 || B < 0 || C < 0) return NW_ERR_INVALID_ARG;
+    if (B == 0 || C == 0) return NW_OK;
+    if (!m || !den || !num || !out) return NW_ERR_INVALID_ARG;
+    return nw::launch_merge(m, den, num, out, G, B, C, stride_m, stride_den, stride_num,
+                            static_cast<hipStream_t>(stream));
+}

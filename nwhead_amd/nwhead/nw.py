@@ -1,0 +1,126 @@
+"""NWNet / NWHead with the reference's constructor and method surface (nwhead/nw.py:11-289), the
+head computed by the HIP kernels in nwhead_amd/csrc/ through ops.nw_head.
+
+Differences that are deliberate (and documented in DESIGN.md):
+  * the precomputed bank (full_feat/full_y) stays on the device instead of round-tripping through
+    host memory every predict() (reference: nw.py:156,226);
+  * 'hnsw' mode is an exact search (hnswlib is not available);
+  * there is no CPU execution path: tensors must live on the MI355X.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .kernel import _ScoreModule, get_kernel
+from .support import SupportSetEval, SupportSetTrain
+
+
+class NWHead(nn.Module):
+    """forward(x:(B,d), sx:(N,d)|(B,N,d), sy:(N,)|(B,N)) -> (B, n_classes) log-probabilities."""
+
+    def __init__(self, kernel, n_classes):
+        super().__init__()
+        if not isinstance(kernel, _ScoreModule):
+            raise NotImplementedError("NWHead runs the score functions built into the HIP kernels "
+                                      "(see get_kernel); custom kernel modules are not supported")
+        self.kernel = kernel
+        self.n_classes = n_classes
+
+    def forward(self, x, sx, sy, return_weights=False):
+        return ops.nw_head(x, sx, sy, self.n_classes, self.kernel.kind, self.kernel._logit_scale(),
+                           return_weights=return_weights)
+
+
+class NWNet(nn.Module):
+    def __init__(self, featurizer, n_classes, support_dataset=None, feat_dim=None, proj_dim=0,
+                 kernel_type='euclidean', train_type='random', n_way=None, n_shot=1,
+                 n_shot_random=1, n_shot_full=100, n_shot_cluster=1, n_neighbors=10,
+                 env_array=None, debug_mode=False, device='cuda:0', return_mask=False):
+        super().__init__()
+        if support_dataset is not None:
+            assert hasattr(support_dataset, 'targets'), 'Support set must have .targets attribute'
+        if proj_dim > 0:
+            assert feat_dim is not None, 'Feature dimension must be specified'
+            featurizer = nn.Sequential(featurizer, nn.Linear(feat_dim, proj_dim))
+        self.featurizer = featurizer
+        self.n_classes, self.train_type, self.n_way = n_classes, train_type, n_way
+        self.n_shot, self.n_shot_random, self.n_shot_full = n_shot, n_shot_random, n_shot_full
+        self.n_shot_cluster, self.n_neighbors = n_shot_cluster, n_neighbors
+        self.env_array, self.debug_mode = env_array, debug_mode
+        self.device, self.return_mask = device, return_mask
+        # registered twice on purpose: reference state_dicts carry both kernel.* and nwhead.kernel.*
+        self.kernel = get_kernel(kernel_type)
+        self.nwhead = NWHead(self.kernel, n_classes)
+        if support_dataset is not None:
+            self.support_train = SupportSetTrain(support_dataset, n_classes, train_type, n_shot,
+                                                 n_way=n_way, env_array=env_array)
+            self.process_support_eval(support_dataset)
+
+    # ------------------------------------------------------------------ evaluation bank
+    def process_support_eval(self, support_dataset):
+        self.support_eval = SupportSetEval(support_dataset, self.n_classes, self.n_shot_random,
+                                           self.n_shot_full, n_shot_cluster=self.n_shot_cluster,
+                                           n_neighbors=self.n_neighbors, env_array=self.env_array)
+
+    @torch.no_grad()
+    def _compute_all_support_feats(self):
+        """Featurise every environment's balanced bank in loader order; rows stay on self.device."""
+        per_env = []
+        for loader in self.support_eval.support_loaders:
+            f, y, m = [], [], []
+            for img, label, meta in loader:
+                f.append(self.featurizer(img.to(self.device)).detach())
+                y.append(label.to(self.device))
+                m.append(meta.to(self.device))
+            per_env.append((torch.cat(f), torch.cat(y), torch.cat(m)))
+        feats, labels, meta = (torch.cat([e[k] for e in per_env]) for k in range(3))
+        return (feats, labels, meta, [e[0] for e in per_env], [e[1] for e in per_env],
+                [e[2] for e in per_env])
+
+    def precompute(self):
+        assert not self.featurizer.training
+        info = self._compute_all_support_feats()
+        self.full_feat, self.full_y = info[0], info[1]
+        self.support_eval.build_infer_iters(*info)
+
+    def predict(self, x, mode='random'):
+        qfeat = self.featurizer(x)
+        sfeat, sy = self.support_eval.get_support(mode, x=qfeat)
+        if self.debug_mode:
+            print('qx shape:', x.shape)
+            print('sfeat shape:', [f.shape for f in sfeat] if mode == 'ensemble' else sfeat.shape)
+            print('sy:', sy)
+        if mode == 'ensemble':
+            probs = sum(self.nwhead(qfeat, f.to(x.device), y.to(x.device)).exp() for f, y in zip(sfeat, sy))
+            out = torch.log(probs / len(sfeat))
+        else:
+            out = self.nwhead(qfeat, sfeat.to(x.device), sy.to(x.device))
+        if self.return_mask:
+            return out, torch.full((len(x),), True)
+        return out
+
+    def get_neighbors(self, x):
+        """Support indices ordered from nearest to farthest under the configured kernel."""
+        qfeat = self.featurizer(x).detach()
+        scores = self.kernel(qfeat, self.full_feat.to(qfeat.device))
+        return torch.argsort(scores, dim=-1, descending=True)
+
+    # ------------------------------------------------------------------ training step
+    def forward(self, x, y, metadata=None, support_data=None):
+        sx, sy, sm = support_data if support_data is not None else self.support_train.get_support(y)
+        if sm is None:
+            sm = torch.zeros_like(sy)
+        sx, sy, sm = sx.to(x.device), sy.to(x.device), sm.to(x.device)
+        nq = len(x)
+        feats = self.featurizer(torch.cat((x, sx), dim=0))   # joint pass: BN statistics are shared
+        qfeat, sfeat = feats[:nq], feats[nq:]
+        isin = torch.isin(y, sy)
+        if self.debug_mode:
+            print('qx shape:', x.shape, 'sx shape:', sx.shape)
+            print('qfeat shape:', qfeat.shape, 'sfeat shape:', sfeat.shape)
+            print('qy:', y, 'sy:', sy, 'qy in sy:', isin)
+            print(f'Percent query dropped: {(1.0 - isin.float().mean().item())*100}%')
+            if metadata is not None:
+                print('qmeta:', metadata, 'smeta:', sm)
+        out = self.nwhead(qfeat, sfeat, sy)
+        return (out, isin) if self.return_mask else out

@@ -1,0 +1,146 @@
+"""Host-side index/sampler logic around the head (API of the reference's nwhead/utils.py).
+
+No arithmetic lives here except KNN, which ranks with the HIP score kernel.  The samplers draw from
+the GLOBAL ``np.random`` state with the same call sequence as the reference
+(utils.py:93,129,136) so a seeded run picks the same supports.
+"""
+import numpy as np
+import torch
+from torch.utils.data import Dataset, default_collate
+
+from .. import ops
+
+
+def get_separated_indices(vals):
+    """[0,1,1,2,3] -> [[0],[1,2],[3],[4]]; labels are ranked by sorted value (utils.py:142-159)."""
+    if torch.is_tensor(vals):
+        vals = vals.detach().cpu().numpy()
+    vals = np.asarray(vals)
+    uniq, inv = np.unique(vals, return_inverse=True)
+    buckets = [[] for _ in range(len(uniq))]
+    for pos, k in enumerate(inv.tolist()):
+        buckets[k].append(pos)
+    return buckets
+
+
+class DatasetMetadata(Dataset):
+    """(x, y) dataset -> (x, y, metadata[idx]) (utils.py:7-19)."""
+
+    def __init__(self, dataset, metadata):
+        self.dataset, self.metadata = dataset, metadata
+        self.targets = dataset.targets
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, idx):
+        item = self.dataset[idx]
+        return item[0], item[1], self.metadata[idx]
+
+
+class FeatureDataset(Dataset):
+    """Precomputed (feature, label, metadata) rows (utils.py:21-32)."""
+
+    def __init__(self, features, targets, metadata):
+        self.features, self.targets, self.metadata = features, targets, metadata
+
+    def __len__(self):
+        return len(self.features)
+
+    def __getitem__(self, idx):
+        return self.features[idx], self.targets[idx], self.metadata[idx]
+
+
+class FullDataset(Dataset):
+    """Class-balanced prefix of a dataset: the first min(n_shot_full, smallest class) items of every
+    class, classes in ascending order -> the bank is class-sorted (utils.py:34-54)."""
+
+    def __init__(self, underlying_dataset, n_shot_full):
+        self.underlying_dataset = underlying_dataset
+        self.indices = get_separated_indices(underlying_dataset.targets)
+        keep = min(n_shot_full, min(len(ix) for ix in self.indices))
+        self.keys = [i for ix in self.indices for i in ix[:keep]]
+
+    def __len__(self):
+        return len(self.keys)
+
+    def __getitem__(self, key):
+        return self.underlying_dataset[self.keys[key]]
+
+
+class InfiniteUniformClassLoader:
+    """n_shot random items from every class (or from n_way classes that include the query classes).
+
+    Same draws as utils.py:99-140 for a given ``np.random`` state: one ``choice`` for the extra
+    classes (probability 0 on the query classes), then one ``choice(row, n_shot, replace=False)``
+    per selected class, query classes last and duplicates kept.
+    """
+
+    def __init__(self, dataset, n_shot, n_way=None):
+        self.dataset = dataset
+        self.indices = get_separated_indices(dataset.targets)
+        self.n_classes = len(self.indices)
+        self.n_shot, self.n_way = n_shot, n_way
+        self.collate_fn = default_collate
+        if n_way:
+            assert n_way <= self.n_classes
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        raise NotImplementedError
+
+    def next(self, qy=None):
+        rows = self.indices
+        if self.n_way:
+            assert len(qy) <= self.n_way, "qy must be smaller than n_way"
+            qy = qy.detach().cpu().numpy()
+            p = np.ones(self.n_classes)
+            p[qy] = 0
+            p /= p.sum()
+            extra = np.random.choice(self.n_classes, size=self.n_way - len(qy), replace=False, p=p)
+            rows = [self.indices[c] for c in np.concatenate([extra, qy])]
+        picks = np.array([np.random.choice(r, size=self.n_shot, replace=False) for r in rows]).flatten()
+        return self.collate_fn([self.dataset[i] for i in picks])
+
+
+class KNN:
+    """Exact nearest supports by Euclidean distance (utils.py:178-193).  As in the reference, the k
+    rows of ALL queries are concatenated into one shared (B*k, d) support."""
+
+    def __init__(self, data, labels, n_neighbors=20):
+        self.data, self.labels, self.n_neighbors = data, labels, n_neighbors
+
+    def indices(self, x):
+        scores = ops.nw_scores(x, self.data.to(x.device), "euclidean")
+        k = min(self.n_neighbors, scores.shape[1])
+        # descending score == ascending distance; stable so ties resolve like argsort would
+        return torch.argsort(scores, dim=-1, descending=True, stable=True)[:, :k]
+
+    def __call__(self, x):
+        idx = self.indices(x).reshape(-1)
+        return self.data[idx.to(self.data.device)], self.labels[idx.to(self.labels.device)]
+
+
+class HNSW(KNN):
+    """The reference uses hnswlib's approximate index (utils.py:195-216); hnswlib is not part of
+    this image, so 'hnsw' mode is served by the exact search above (a superset in recall)."""
+
+
+def compute_clusters(embeddings, labels, n_clusters, closest=False):
+    """Per-class k-means centroids (utils.py:218-246).  k-means itself is third-party CPU code in
+    the reference (sklearn KMeans, random_state=0) and stays so here: out of the HIP scope."""
+    from sklearn.cluster import KMeans
+    emb = embeddings.detach().cpu()
+    lab = labels.detach().cpu()
+    feats, ys = [], []
+    for c in np.unique(lab.numpy()):
+        rows = emb[lab == c]
+        km = KMeans(n_clusters=n_clusters, random_state=0).fit(rows.numpy())
+        cent = torch.tensor(km.cluster_centers_).float()
+        if closest:
+            cent = rows[torch.cdist(cent, rows).argmin(dim=-1)]
+        feats.append(cent)
+        ys += [c] * n_clusters
+    return torch.cat(feats, dim=0), torch.tensor(ys)

@@ -1,0 +1,191 @@
+"""Tensor-level entry points over the C ABI: forward/backward of the NW head, scores, sharded
+partials + merge, support influence.  PyTorch is plumbing only (device memory, current stream,
+autograd bookkeeping); every arithmetic step runs in libnwhead_hip.so.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import SCORE_KINDS, NWHipError
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_hip(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise NWHipError(
+                "nwhead_amd ops run on MI355X only: got a CPU tensor. Move the module and its "
+                "inputs to the HIP device (there is no CPU fallback in the product path).")
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _kind_id(kind):
+    if isinstance(kind, int):
+        return kind
+    try:
+        return SCORE_KINDS[kind]
+    except KeyError:
+        raise NotImplementedError(kind)
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+def nw_scores(q, s, kind="euclidean", logit_scale=None):
+    """q:(B,d), s:(N,d)|(B,N,d) -> (B,N) fp32 scores.  Replaces nwhead/kernel.py:13-44."""
+    _need_hip(q, s, logit_scale)
+    lib = _lib.load()
+    q, s = _f32c(q), _f32c(s)
+    B, d = q.shape
+    batched = s.dim() == 3
+    N = s.shape[-2]
+    out = torch.empty(B, N, dtype=torch.float32, device=q.device)
+    ls = None if logit_scale is None else _f32c(logit_scale)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.nw_scores_f32(_ptr(q), _ptr(s), _ptr(out), B, N, d, _kind_id(kind), _ptr(ls),
+                                     int(batched), _stream(q)), "nw_scores_f32")
+    return out
+
+
+class _NWHeadFn(torch.autograd.Function):
+    """autograd node for NWHead.forward (nwhead/nw.py:266-289)."""
+
+    @staticmethod
+    def forward(ctx, q, s, sy, logit_scale, n_classes, kind_id, want_weights):
+        _need_hip(q, s, sy, logit_scale)
+        lib = _lib.load()
+        qc, sc = _f32c(q), _f32c(s)
+        syc = sy.detach().to(torch.int64).contiguous()
+        B, d = qc.shape
+        sup_b = sc.dim() == 3
+        lab_b = syc.dim() == 2
+        N = sc.shape[-2]
+        dev = qc.device
+        need_bwd = any(ctx.needs_input_grad[:2]) or (logit_scale is not None and ctx.needs_input_grad[3])
+        out = torch.empty(B, n_classes, dtype=torch.float32, device=dev)
+        scores = torch.empty(B, N, dtype=torch.float32, device=dev) if need_bwd else None
+        lse = torch.empty(B, dtype=torch.float32, device=dev) if need_bwd else None
+        weights = torch.empty(B, N, dtype=torch.float32, device=dev) if want_weights else None
+        ls = None if logit_scale is None else _f32c(logit_scale)
+        ws_bytes = 0 if need_bwd else lib.nw_fwd_workspace_bytes(B, N, d, n_classes)
+        ws = _workspace(ws_bytes, dev) if ws_bytes else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(out), _ptr(scores), _ptr(lse),
+                                      _ptr(weights), _ptr(ws), ws_bytes, B, N, d, n_classes, kind_id,
+                                      _ptr(ls), int(sup_b), int(lab_b), _stream(qc)), "nw_fwd_f32")
+        if need_bwd:
+            ctx.save_for_backward(qc, sc, syc, scores, lse, out, ls if ls is not None else torch.empty(0, device=dev))
+            ctx.meta = (B, N, d, n_classes, kind_id, sup_b, lab_b, ls is not None)
+        if want_weights:
+            ctx.mark_non_differentiable(weights)
+            return out, weights
+        return out
+
+    @staticmethod
+    def backward(ctx, gout, *unused):
+        lib = _lib.load()
+        qc, sc, syc, scores, lse, out, ls = ctx.saved_tensors
+        B, N, d, C, kind_id, sup_b, lab_b, has_ls = ctx.meta
+        dev = qc.device
+        g = _f32c(gout)
+        gq = torch.empty_like(qc)
+        gs = torch.empty_like(sc)
+        gls = torch.empty((), dtype=torch.float32, device=dev) if has_ls else None
+        ws_bytes = lib.nw_bwd_workspace_bytes(B, N, d, C, kind_id, int(sup_b))
+        ws = _workspace(ws_bytes, dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nw_bwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(scores), _ptr(lse), _ptr(out),
+                                      _ptr(g), _ptr(gq), _ptr(gs), _ptr(gls), _ptr(ws), ws_bytes,
+                                      B, N, d, C, kind_id, _ptr(ls) if has_ls else None,
+                                      int(sup_b), int(lab_b), _stream(qc)), "nw_bwd_f32")
+        return gq, gs, None, gls, None, None, None
+
+
+def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weights=False):
+    """NWHead.forward(x, sx, sy) -> (B,C) log-probs (and the (B,N) softmax weights on request)."""
+    kid = _kind_id(kind)
+    if kid == SCORE_KINDS["clip"] and logit_scale is None:
+        raise ValueError("clip kernel needs logit_scale")
+    if s.dim() == 2 and sy.dim() != 1 or s.dim() == 3 and sy.dim() != 2:
+        raise ValueError("support labels must be (N,) for (N,d) supports and (B,N) for (B,N,d)")
+    return _NWHeadFn.apply(q, s, sy, logit_scale, int(n_classes), kid, bool(return_weights))
+
+
+def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None):
+    """This rank's (m, den, num) over its shard of the bank; no grad."""
+    _need_hip(q, s, sy, logit_scale)
+    lib = _lib.load()
+    qc, sc = _f32c(q), _f32c(s)
+    syc = sy.detach().to(torch.int64).contiguous()
+    B, d = qc.shape
+    N = sc.shape[0]
+    dev = qc.device
+    packed = torch.empty(B, n_classes + 2, dtype=torch.float32, device=dev)
+    return nw_partials_into(packed, qc, sc, syc, n_classes, kind, logit_scale)
+
+
+def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_scale=None, ws=None):
+    """Write partials into ``packed`` laid out as [m (B) | den (B) | num (B*C)] (flat, contiguous):
+    one buffer = one collective.  Inputs must already be fp32/int64 contiguous HIP tensors."""
+    lib = _lib.load()
+    B, d = qc.shape
+    N = sc.shape[0]
+    C = int(n_classes)
+    flat = packed.view(-1)
+    m, den, num = flat[:B], flat[B:2 * B], flat[2 * B:2 * B + B * C]
+    ws_bytes = lib.nw_fwd_workspace_bytes(B, N, d, C)
+    if ws is None:
+        ws = _workspace(ws_bytes, qc.device)
+    ls = None if logit_scale is None else _f32c(logit_scale)
+    with torch.cuda.device(qc.device):
+        _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(m), _ptr(den), _ptr(num),
+                                          _ptr(ws), ws.numel(), B, N, d, C, _kind_id(kind), _ptr(ls),
+                                          _stream(qc)), "nw_fwd_partial_f32")
+    return packed
+
+
+def nw_merge(packed_all, B, n_classes, out=None):
+    """packed_all: (G, L>=2B+B*C) all-gathered partial buffers, each row [m | den | num] -> (B,C)
+    log-probs.  The merge kernel reads the three sections in place through shard strides."""
+    _need_hip(packed_all)
+    lib = _lib.load()
+    assert packed_all.dim() == 2 and packed_all.is_contiguous() and packed_all.dtype == torch.float32
+    G, L = packed_all.shape
+    C = int(n_classes)
+    assert L >= 2 * B + B * C
+    dev = packed_all.device
+    if out is None:
+        out = torch.empty(B, C, dtype=torch.float32, device=dev)
+    base = packed_all.data_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(lib.nw_merge_finalize_f32(base, base + 4 * B, base + 8 * B, _ptr(out), G, B, C, L, L, L,
+                                             _stream(packed_all)), "nw_merge_finalize_f32")
+    return out
+
+
+def support_influence_idx(probs, qy, w, sy):
+    """Index-label form of util/metric.py:23-50: probs (B,C), qy (B,), w (B,N), sy (N,) -> (B,N)."""
+    _need_hip(probs, qy, w, sy)
+    lib = _lib.load()
+    probs, w = _f32c(probs), _f32c(w)
+    qy = qy.detach().to(torch.int64).contiguous()
+    sy = sy.detach().to(torch.int64).contiguous()
+    B, Cc = probs.shape
+    N = w.shape[1]
+    out = torch.empty(B, N, dtype=torch.float32, device=probs.device)
+    with torch.cuda.device(probs.device):
+        _lib.check(lib.nw_support_influence_f32(_ptr(probs), _ptr(qy), _ptr(w), _ptr(sy), _ptr(out), B, N, Cc,
+                                                _stream(probs)), "nw_support_influence_f32")
+    return out

@@ -1,0 +1,97 @@
+"""'full' inference against a support bank sharded over the ranks of one node.
+
+Rank g owns a contiguous slice of the (class-sorted) bank.  Queries are replicated; each rank runs
+the partial forward over its slice (HIP), the ranks exchange ONE packed buffer per bucket of query
+batches -- [m | den | num] per batch -- with a single RCCL all-gather over xGMI (payloads are a few
+hundred KB: latency-bound, so batches are bucketed and the collective of bucket i overlaps the
+kernels of bucket i+1), and every rank merges to the same (B,C) log-probabilities.
+
+    one process per GPU, torch.distributed backend "nccl" (= RCCL on ROCm); "gloo" in CPU tests,
+    where the compute hooks are replaced by the oracle (tests/test_sharded_gloo.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def shard_bounds(n_rows: int, world: int, rank: int):
+    """Contiguous, near-equal split: rows [lo, hi) of the bank belong to `rank`."""
+    base, extra = divmod(n_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardedBank:
+    def __init__(self, feat_shard, y_shard, n_classes, kind="euclidean", logit_scale=None, group=None,
+                 partial_fn=None, merge_fn=None):
+        self.feat = feat_shard.detach().to(torch.float32).contiguous()
+        self.y = y_shard.detach().to(torch.int64).contiguous()
+        self.C = int(n_classes)
+        self.kind, self.logit_scale, self.group = kind, logit_scale, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._partial = partial_fn or self._hip_partial
+        self._merge = merge_fn or self._hip_merge
+        self._ws = None
+
+    # ---- HIP compute hooks (the product path)
+    def _hip_partial(self, packed_row, q):
+        N, d = self.feat.shape
+        B = q.shape[0]
+        need = ops._lib.load().nw_fwd_workspace_bytes(B, N, d, self.C)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=q.device)
+        ops.nw_partials_into(packed_row, q, self.feat, self.y, self.C, self.kind, self.logit_scale, ws=self._ws)
+
+    def _hip_merge(self, gathered_rows, B):
+        return ops.nw_merge(gathered_rows, B, self.C)
+
+    def row_len(self, B):
+        return 2 * B + B * self.C
+
+    def predict(self, q):
+        """One query batch: (B,d) -> (B,C) log-probabilities, identical on every rank."""
+        return self.predict_stream([q], bucket=1)[0]
+
+    def predict_stream(self, batches, bucket=4):
+        """Pipelined prediction of a list of equally-shaped query batches.
+
+        Per bucket of `bucket` batches: partial kernels write their rows of one packed buffer, one
+        async all-gather ships it, and the merge of the previous bucket runs while it flies."""
+        if not batches:
+            return []
+        B = batches[0].shape[0]
+        L = self.row_len(B)
+        dev, G = self.feat.device, self.world
+        outs, pending = [], None
+        ring = [None, None, None]
+
+        def finish(p):
+            work, gathered, nb = p
+            if work is not None:
+                work.wait()
+            for k in range(nb):
+                rows = gathered[:, k, :]                 # (G, L): shard g's partials of batch k
+                outs.append(self._merge(rows if rows.is_contiguous() else rows.contiguous(), B))
+
+        for i0 in range(0, len(batches), bucket):
+            chunk = batches[i0:i0 + bucket]
+            nb = len(chunk)
+            slot = (i0 // bucket) % 3
+            if ring[slot] is None or ring[slot][0].shape[0] != nb:
+                ring[slot] = (torch.empty(nb, L, dtype=torch.float32, device=dev),
+                              torch.empty(G, nb, L, dtype=torch.float32, device=dev))
+            packed, gathered = ring[slot]
+            for k, q in enumerate(chunk):
+                self._partial(packed[k], q.detach().to(torch.float32).contiguous())
+            if G > 1:
+                work = dist.all_gather_into_tensor(gathered.view(G * nb, L), packed, group=self.group, async_op=True)
+            else:
+                gathered, work = packed.view(1, nb, L), None
+            if pending is not None:
+                finish(pending)
+            pending = (work, gathered, nb)
+        finish(pending)
+        return outs

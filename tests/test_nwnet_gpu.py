@@ -1,0 +1,90 @@
+"""NWNet API parity on the MI355X against fixture G5 (reference NWNet with a tiny featurizer)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import T, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, data, targets, C):
+        self.data, self.targets, self.num_classes = data, list(targets), C
+
+    def __len__(self):
+        return len(self.targets)
+
+    def __getitem__(self, i):
+        return self.data[i], self.targets[i]
+
+
+@pytest.fixture(scope="module")
+def net_and_g():
+    from nwhead_amd.nwhead.nw import NWNet
+    g = load_golden("g5_nwnet_plumbing.npz")
+    C = int(g["C"])
+    ds = _DS(T(g["ds_data"]), g["ds_targets"].tolist(), C)
+    feat = nn.Sequential(nn.Flatten(), nn.Linear(48, 16))
+    with torch.no_grad():
+        feat[1].weight.copy_(T(g["w"]))
+        feat[1].bias.copy_(T(g["b"]))
+    net = NWNet(feat, C, support_dataset=ds, feat_dim=16, n_shot=2, n_way=6, n_shot_full=7,
+                n_shot_cluster=2, n_neighbors=3, device="cuda:0").to("cuda:0")
+    net.eval()
+    np.random.seed(1234)
+    net.precompute()
+    return net, g
+
+
+def close(a, b, rtol=1e-5, atol=3e-5):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b, rtol=rtol, atol=atol)
+
+
+def test_bank_order_and_state_dict(net_and_g):
+    net, g = net_and_g
+    assert net.full_feat.is_cuda                      # bank stays device-resident
+    np.testing.assert_array_equal(net.full_y.cpu().numpy(), g["full_y"])   # class-sorted, balanced
+    close(net.full_feat, g["full_feat"], rtol=1e-5, atol=1e-5)
+    assert set(net.state_dict().keys()) == {"featurizer.1.weight", "featurizer.1.bias"}
+    np.testing.assert_array_equal(net.support_eval.cluster_y.cpu().numpy(), g["cluster_y"])
+
+
+@pytest.mark.parametrize("mode", ["full", "cluster", "knn", "hnsw", "ensemble"])
+def test_predict_modes(net_and_g, mode):
+    net, g = net_and_g
+    xq = T(g["xq"]).cuda()
+    with torch.no_grad():
+        out = net.predict(xq, mode)
+    close(out, g[f"pred_{mode}"], rtol=1e-4, atol=1e-4 if mode == "cluster" else 3e-5)
+
+
+def test_random_mode_and_sampler_draws(net_and_g):
+    net, g = net_and_g
+    xq, yq = T(g["xq"]).cuda(), T(g["yq"]).cuda()
+    with torch.no_grad():
+        np.random.seed(77)
+        close(net.predict(xq, "random"), g["pred_random"])
+        np.random.seed(77)
+        _, ry, _ = net.support_eval.random_iter.next()
+        np.testing.assert_array_equal(ry.cpu().numpy(), g["random_sy"])
+        np.random.seed(99)
+        sx, sy, sm = net.support_train.get_support(yq)
+        np.testing.assert_array_equal(sy.numpy(), g["train_sy"])        # incl. duplicate-class n_way case
+        np.testing.assert_array_equal(sx.numpy(), g["train_sx"])
+        close(net(xq, yq, support_data=(sx, sy, None)), g["fwd_support_data"])
+        np.random.seed(99)
+        close(net(xq, yq), g["fwd_sampled"])
+    nb = net.get_neighbors(xq).cpu().numpy()
+    # same nearest neighbours (ties aside): compare the top-5 columns
+    np.testing.assert_array_equal(nb[:, :5], g["neighbors"][:, :5])
+
+
+def test_errors(net_and_g):
+    net, _ = net_and_g
+    from nwhead_amd.nwhead.kernel import get_kernel
+    with pytest.raises(NotImplementedError):
+        get_kernel("relationnet")
+    with pytest.raises(NotImplementedError):
+        net.support_eval.get_support("nope")
