@@ -58,12 +58,15 @@ def measure_shape(B, N, d, C, dev, iters):
     """Single-GPU forward at one shape: whole-op time and the dominant (scores) kernel's time."""
     from nwhead_amd import ops
     q, s, sy = make_inputs(B, N, d, C, dev)
-    t_fwd = time_kernel_events(lambda: ops.nw_head(q, s, sy, C), iters)
-    t_sc = time_kernel_events(lambda: ops.nw_scores(q, s), iters)
+    sn2 = ops.row_norm2(s)
+    t_fwd = time_kernel_events(lambda: ops.nw_head(q, s, sy, C, support_norm2=sn2), iters)
+    t_gen = time_kernel_events(lambda: ops.nw_head(q, s, sy, C), iters)
+    t_sc = t_fwd
     fl = alg_flops(B, N, d)
     return {"B": B, "N": N, "d": d, "C": C, "ms_per_call": t_fwd * 1e3, "query_pred_per_s": B / t_fwd,
+            "ms_per_call_without_cached_bank_norms": t_gen * 1e3,
             "alg_GBps": alg_bytes(B, N, d, C) / t_fwd / 1e9, "frac_hbm": alg_bytes(B, N, d, C) / t_fwd / 1e9 / PEAK_HBM_GBS,
-            "scores_kernel_us": t_sc * 1e6, "scores_kernel_TFLOPs": 2 * B * N * d / t_sc / 1e12,
+            "fwd_TFLOPs": 2 * B * N * d / t_sc / 1e12,
             "frac_mfma_f32": 2 * B * N * d / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "whole_op_frac_of_roofline": max(alg_bytes(B, N, d, C) / (PEAK_HBM_GBS * 1e9), fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) / t_fwd}
 
@@ -130,7 +133,7 @@ def main():
         if world == 1:
             outs = None
             for i in range(nsteps):
-                outs = ops.nw_head(qs[i % 4], bank.feat, bank.y, C)
+                outs = ops.nw_head(qs[i % 4], bank.feat, bank.y, C, support_norm2=bank.norm2)
             return outs
         return bank.predict_stream([qs[i % 4] for i in range(nsteps)], bucket=args.bucket)[-1]
 
@@ -153,9 +156,11 @@ def main():
     line = None
     if rank == 0:
         n_shard = hi - lo
-        t_sc = time_kernel_events(lambda: ops.nw_scores(qs[0], bank.feat), 50)
+        # one launch = one forward over this rank's shard = nw_fused_kernel (+ the small merge kernel)
+        t_sc = time_kernel_events(lambda: ops.nw_partials(qs[0], bank.feat, bank.y, C) if world > 1 else
+                                  ops.nw_head(qs[0], bank.feat, bank.y, C, support_norm2=bank.norm2), 50)
         flops = 2.0 * B * n_shard * d
-        roof = {"bound": "mfma", "kernel": "nw_scores_mfma_kernel", "achieved": flops / t_sc / 1e12,
+        roof = {"bound": "mfma", "kernel": "nw_fused_kernel (+nw_merge_runs_kernel)", "achieved": flops / t_sc / 1e12,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                 "launch_us": t_sc * 1e6, "alg_flops_per_launch": flops,

@@ -69,10 +69,19 @@ int nw_scores_f32(const float *q, const float *s, float *scores,
                   int64_t B, int64_t N, int64_t d,
                   int kind, const float *logit_scale_dev, int sup_batched, void *stream);
 
+/* Squared L2 norm of every row of a dense (rows,d) matrix: n2[r] = sum_k x[r,k]^2.  The pow(2).sum(-1)
+ * half of torch.cdist's matmul form (and of F.normalize, nwhead/kernel.py:19-20), hoisted out of the
+ * hot loop for operands that do not change between calls (the precomputed support bank). */
+int nw_row_norm2_f32(const float *x, float *n2, int64_t rows, int64_t d, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Forward.  Replaces NWHead.forward nwhead/nw.py:266-289:
  *     one_hot(sy) -> kernel scores -> softmax over supports -> bmm with one-hot -> log(. + 1e-12)
  *   sy          (N,) or, when labels_batched != 0, (B,N); values outside [0,C) contribute nothing
+ *   s_norm2     optional (N,): squared row norms of s as written by nw_row_norm2_f32.  The resident
+ *               bank of 'full' inference (NWNet.precompute, nwhead/nw.py:118-125) caches them so
+ *               that the hot loop is matrix-core work only; NULL = computed inside the kernel.
+ *               Only read for a shared 2-D support.
  *   out         (B,C) log-probabilities
  *   scores_out  optional (B,N): raw scores (saved for backward / neighbour search)
  *   lse_out     optional (B,):  log sum_j exp(score_bj)  (saved for backward)
@@ -80,7 +89,7 @@ int nw_scores_f32(const float *q, const float *s, float *scores,
  *   workspace   nw_fwd_workspace_bytes(B,N,d,C) bytes of scratch (may be NULL if that is 0)
  * ------------------------------------------------------------------------------------------- */
 size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C);
-int nw_fwd_f32(const float *q, const float *s, const int64_t *sy,
+int nw_fwd_f32(const float *q, const float *s, const int64_t *sy, const float *s_norm2,
                float *out, float *scores_out, float *lse_out, float *weights_out,
                void *workspace, size_t workspace_bytes,
                int64_t B, int64_t N, int64_t d, int64_t C,
@@ -99,7 +108,7 @@ int nw_fwd_f32(const float *q, const float *s, const int64_t *sy,
  *   floats; pass B, B, B*C for dense (G,B) (G,B) (G,B,C) stacks, or the common row length when the
  *   three sections of each shard are packed in one all-gathered buffer).
  * ------------------------------------------------------------------------------------------- */
-int nw_fwd_partial_f32(const float *q, const float *s, const int64_t *sy,
+int nw_fwd_partial_f32(const float *q, const float *s, const int64_t *sy, const float *s_norm2,
                        float *m, float *den, float *num,
                        void *workspace, size_t workspace_bytes,
                        int64_t B, int64_t N, int64_t d, int64_t C,

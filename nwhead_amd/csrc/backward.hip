@@ -190,6 +190,15 @@ size_t bwd_layout(int64_t B, int64_t N, int sup_batched, char* base, BwdWs* ws) 
 }
 
 }  // namespace
+
+int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStream_t st) {
+    if (rows <= 0) return NW_OK;
+    if ((rows + 3) / 4 > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(nw_rownorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, n2, rows, d);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
 }  // namespace nw
 
 extern "C" size_t nw_bwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C, int kind,

@@ -43,15 +43,25 @@ extern "C" int nw_scores_f32(const float* q, const float* s, float* scores, int6
                              static_cast<hipStream_t>(stream));
 }
 
-// The forward keeps one (B,N) fp32 score matrix as scratch when the caller does not ask for it.
+// Scratch: the fused path keeps per-tile softmax statistics and label-run sums (fused.hip); the
+// two-kernel path (per-query supports, N <= 25, weights requested) one (B,N) score matrix.
 extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C) {
     (void)d; (void)C;
     if (B <= 0 || N <= 0) return 0;
-    return align256((size_t)B * (size_t)N * sizeof(float));
+    const size_t plain = align256((size_t)B * (size_t)N * sizeof(float));
+    const size_t fused = nw::fused_workspace_bytes(B, N);
+    return plain > fused ? plain : fused;
 }
 
-extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, float* out,
-                          float* scores_out, float* lse_out, float* weights_out, void* workspace,
+extern "C" int nw_row_norm2_f32(const float* x, float* n2, int64_t rows, int64_t d, void* stream) {
+    if (rows < 0 || d < 0) return NW_ERR_INVALID_ARG;
+    if (rows == 0) return NW_OK;
+    if (!x || !n2) return NW_ERR_INVALID_ARG;
+    return nw::launch_rownorm2(x, n2, rows, d, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
+                          float* out, float* scores_out, float* lse_out, float* weights_out, void* workspace,
                           size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C,
                           int kind, const float* logit_scale_dev, int sup_batched,
                           int labels_batched, void* stream) {
@@ -63,6 +73,12 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, flo
     if (N > 0 && (!q || !s || !sy)) return NW_ERR_INVALID_ARG;
     if (kind == NW_SCORE_CLIP && !logit_scale_dev) return NW_ERR_INVALID_ARG;
     if (labels_batched && !sup_batched) return NW_ERR_INVALID_ARG;
+    if (N > 0 && C > 0 && !sup_batched && !weights_out && nw::fused_eligible(q, s, B, N, d, C) &&
+        (!scores_out || (reinterpret_cast<uintptr_t>(scores_out) & 15) == 0)) {
+        if (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C)) return NW_ERR_WORKSPACE;
+        return nw::launch_fused(q, s, sy, s_norm2, logit_scale_dev, out, scores_out, lse_out, nullptr,
+                                nullptr, nullptr, workspace, workspace_bytes, B, N, d, C, kind, st);
+    }
     float* scores = scores_out;
     if (!scores && N > 0) {
         if (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C)) return NW_ERR_WORKSPACE;
@@ -74,8 +90,8 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, flo
                                 nullptr, nullptr, B, N, C, st);
 }
 
-extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t* sy, float* m,
-                                  float* den, float* num, void* workspace, size_t workspace_bytes,
+extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t* sy,
+                                  const float* s_norm2, float* m, float* den, float* num, void* workspace, size_t workspace_bytes,
                                   int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                                   const float* logit_scale_dev, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -87,6 +103,9 @@ extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t*
     if (kind == NW_SCORE_CLIP && !logit_scale_dev) return NW_ERR_INVALID_ARG;
     float* scores = static_cast<float*>(workspace);
     if (N > 0 && (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C))) return NW_ERR_WORKSPACE;
+    if (N > 0 && C > 0 && nw::fused_eligible(q, s, B, N, d, C))
+        return nw::launch_fused(q, s, sy, s_norm2, logit_scale_dev, nullptr, nullptr, nullptr, m, den,
+                                num, workspace, workspace_bytes, B, N, d, C, kind, st);
     int rc = nw::launch_scores(q, s, scores, B, N, d, kind, logit_scale_dev, 0, st);
     if (rc != NW_OK) return rc;
     return nw::launch_aggregate(scores, sy, 0, nullptr, nullptr, nullptr, m, den, num, B, N, C, st);

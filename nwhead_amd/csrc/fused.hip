@@ -1,0 +1,172 @@
+// fused.hip -- the fused NW-head forward for a shared (N,d) support (gfx950 / MI355X only).
+//
+// Replaces, in ONE pass over the support rows and without materialising the (B,N) score matrix,
+// the reference sequence  one_hot -> kernel scores -> softmax -> bmm -> log  (nwhead/nw.py:276-289,
+// scores from nwhead/kernel.py:13-44):
+//
+//   nw_fused_kernel   per workgroup tile (64 queries x 16*RS supports): fp32-MFMA dot products
+//                     (tile_core.h), score epilogue, tile-local softmax statistics
+//                     m = max_j s, den = sum_j e^(s-m), and the e^(s-m) sums of every RUN of equal
+//                     consecutive labels inside the tile (a class-sorted bank has 1-2 runs per tile;
+//                     an unsorted one degrades gracefully to one run per support).
+//   nw_merge_runs_kernel  per query: rescale every tile to the global max, add run sums into the
+//                     per-class accumulator, write log(num/den + 1e-12) (or the (m, den, num)
+//                     partials of a shard).
+#include "fused_impl.h"
+
+namespace nw {
+
+// instantiated in fused_k0.hip .. fused_k4.hip
+#define NW_EXTERN_FUSED_KIND(K)                                                                          \
+    extern template int launch_fused_kind<K>(const float*, const float*, const int64_t*, const float*,   \
+                                             const float*, float*, float*, float*, float*, float*,       \
+                                             float*, void*, size_t, int, int, int, int, hipStream_t);
+NW_EXTERN_FUSED_KIND(NW_SCORE_EUCLIDEAN)
+NW_EXTERN_FUSED_KIND(NW_SCORE_HYPERSPHERE)
+NW_EXTERN_FUSED_KIND(NW_SCORE_COSINE)
+NW_EXTERN_FUSED_KIND(NW_SCORE_DOT)
+NW_EXTERN_FUSED_KIND(NW_SCORE_CLIP)
+#undef NW_EXTERN_FUSED_KIND
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += al256(bytes);
+        return p;
+    };
+    FusedWs w;
+    w.m = reinterpret_cast<float*>(take((size_t)n_stiles * B * 4));
+    w.den = reinterpret_cast<float*>(take((size_t)n_stiles * B * 4));
+    w.nrun = reinterpret_cast<int*>(take((size_t)n_stiles * 4));
+    w.lab = reinterpret_cast<int*>(take((size_t)n_stiles * BS * 4));
+    w.num = reinterpret_cast<float*>(take((size_t)n_stiles * BS * B * 4));
+    if (ws) *ws = w;
+    return off;
+}
+
+namespace {
+
+// One workgroup per query.  Tiles are rescaled to the global max M; run sums go to their class.
+template <bool PARTIAL>
+__global__ __launch_bounds__(256) void nw_merge_runs_kernel(
+    const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
+    const int* __restrict__ ws_lab, const float* __restrict__ ws_num, float* __restrict__ out,
+    float* __restrict__ lse, float* __restrict__ m_out, float* __restrict__ den_out,
+    float* __restrict__ num_out, int B, int C, int n_stiles, int BS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    float* num = red + 8;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) num[c] = 0.f;
+
+    float M = -INFINITY;
+    for (int t = tid; t < n_stiles; t += 256) M = fmaxf(M, ws_m[(size_t)t * B + b]);
+    M = block_max(M, red);
+
+    float den = 0.f;
+    for (int t = tid; t < n_stiles; t += 256) {
+        const float f = expf(ws_m[(size_t)t * B + b] - M);
+        den += ws_den[(size_t)t * B + b] * f;
+        const int nr = ws_nrun[t];
+        for (int r = 0; r < nr; ++r) {
+            const int y = ws_lab[(size_t)t * BS + r];
+            if (y >= 0) atomicAdd(&num[y], ws_num[((size_t)t * BS + r) * B + b] * f);
+        }
+    }
+    den = block_sum(den, red);  // its barriers also order the LDS adds before the reads below
+    __syncthreads();
+    if (PARTIAL) {
+        if (tid == 0) {
+            m_out[b] = M;
+            den_out[b] = den;
+        }
+        for (int c = tid; c < C; c += 256) num_out[(size_t)b * C + c] = num[c];
+    } else {
+        const float inv = 1.f / den;
+        if (tid == 0 && lse) lse[b] = M + logf(den);
+        for (int c = tid; c < C; c += 256) out[(size_t)b * C + c] = logf(num[c] * inv + NW_LOG_EPS);
+    }
+}
+
+int env_rs() {
+    static int v = [] {
+        const char* e = getenv("NW_TILE_RS");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
+}  // namespace
+
+int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
+                      int B, int C, int n_stiles, int BS, hipStream_t st) {
+    const size_t mlds = (8 + (size_t)C) * sizeof(float);
+    if (out)
+        hipLaunchKernelGGL(nw_merge_runs_kernel<false>, dim3(B), dim3(256), mlds, st, ws.m, ws.den, ws.nrun,
+                           ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS);
+    else
+        hipLaunchKernelGGL(nw_merge_runs_kernel<true>, dim3(B), dim3(256), mlds, st, ws.m, ws.den, ws.nrun,
+                           ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+// Support-tile height (in 16-row blocks).  Model: workgroups run in rounds of 256 (one per CU at
+// full MFMA rate; two co-resident ones share the pipe but fill each other's barrier bubbles, worth
+// ~15 %), each costs RS blocks of MFMA work plus a fixed prologue/epilogue.
+int pick_rs(int64_t B, int64_t N) {
+    const int forced = env_rs();
+    if (forced == 2 || forced == 4 || forced == 6 || forced == 8 || forced == 10 || forced == 12)
+        return forced;
+    const int cand[] = {2, 4, 6, 8, 10, 12};  // even: the four loader waves split a tile evenly
+    const int64_t nq = (B + BQ - 1) / BQ;
+    double best = 1e30;
+    int best_rs = 8;
+    for (int rs : cand) {
+        const int64_t ns = (N + 16 * rs - 1) / (16 * rs);
+        const int64_t nwg = nq * ns;
+        const int64_t rounds = (nwg + 255) / 256;
+        double cost = (double)rounds * (rs + 1.5);
+        if (nwg >= 384) cost *= 0.85;
+        if (cost < best - 1e-9) {
+            best = cost;
+            best_rs = rs;
+        }
+    }
+    return best_rs;
+}
+
+size_t fused_workspace_bytes(int64_t B, int64_t N) {
+    const int rs = pick_rs(B, N);
+    const int64_t n_stiles = (N + 16 * rs - 1) / (16 * rs);
+    return fused_layout(B, n_stiles, 16 * rs, nullptr, nullptr);
+}
+
+bool fused_eligible(const float* q, const float* s, int64_t B, int64_t N, int64_t d, int64_t C) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(s)) & 15) == 0;
+    return N > 25 && d >= 4 && (d % 4) == 0 && aligned && B < (1 << 30) && N < (1 << 30) &&
+           d < (1 << 30) && C < (1 << 30) && (8 + C) * 4 <= 160 * 1024;
+}
+
+// out != nullptr: final log-probabilities (+ optional scores / lse); out == nullptr: (m, den, num).
+int launch_fused(const float* q, const float* s, const int64_t* sy, const float* s_norm2, const float* ls, float* out,
+                 float* scores, float* lse, float* m, float* den, float* num, void* workspace,
+                 size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C, int kind,
+                 hipStream_t st) {
+#define NW_KIND_CASE(K) \
+    case K: return launch_fused_kind<K>(q, s, sy, s_norm2, ls, out, scores, lse, m, den, num, workspace, workspace_bytes, (int)B, (int)N, (int)d, (int)C, st)
+    switch (kind) {
+        NW_KIND_CASE(NW_SCORE_EUCLIDEAN);
+        NW_KIND_CASE(NW_SCORE_HYPERSPHERE);
+        NW_KIND_CASE(NW_SCORE_COSINE);
+        NW_KIND_CASE(NW_SCORE_DOT);
+        NW_KIND_CASE(NW_SCORE_CLIP);
+        default: return NW_ERR_UNSUPPORTED;
+    }
+#undef NW_KIND_CASE
+}
+
+}  // namespace nw

@@ -1,0 +1,277 @@
+// fused_impl.h -- nw_fused_kernel and its per-score-kind launcher (gfx950 / MI355X only).
+// Included by fused_k*.hip, one translation unit per score kind so that the build parallelises.
+#pragma once
+#include <type_traits>
+#include "tile_core.h"
+#include "tile_dma.h"
+
+namespace nw {
+
+constexpr int RUN_CAP = 192;  // >= 16*RS for the largest RS
+
+struct FusedWs {  // views into the caller's workspace
+    float* m;     // [n_stiles][B]
+    float* den;   // [n_stiles][B]
+    int* nrun;    // [n_stiles]
+    int* lab;     // [n_stiles][BS]      label of run r (-1: padding / out-of-range label)
+    float* num;   // [n_stiles][BS][B]   run sums, rows >= nrun[st] never touched
+};
+size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws);
+int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
+                      int B, int C, int n_stiles, int BS, hipStream_t st);
+
+namespace {
+
+// MODE_REG : register-staged loaders (tile_core.h), any d % 4 == 0; loaders compute both norms
+// MODE_DMA : LDS-DMA loaders (tile_dma.h), d % 32 == 0; consumers compute both norms
+// MODE_DMA_SN : LDS-DMA loaders, support norms supplied by the caller (cached bank)
+enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2 };
+
+template <int RS, int KIND, bool WRITE_SCORES, int MODE>
+__global__ __launch_bounds__(TILE_THREADS) void nw_fused_kernel(
+    const float* __restrict__ q, const float* __restrict__ s, const int64_t* __restrict__ sy,
+    const float* __restrict__ s_norm2, const float* __restrict__ logit_scale,
+    float* __restrict__ scores, float* __restrict__ ws_m,
+    float* __restrict__ ws_den, int* __restrict__ ws_nrun, int* __restrict__ ws_lab,
+    float* __restrict__ ws_num, int B, int N, int d, int C, int n_stiles, int n_qtiles) {
+    using Cfg = TileCfg<RS>;
+    constexpr int BS = Cfg::BS;
+    constexpr bool NEED_NORM = (KIND != NW_SCORE_DOT);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // header: qn2[64] | sn2[RUN_CAP] | runid[RUN_CAP] | runlab[RUN_CAP] | nrun ; then the stage buffers
+    float* qn2 = reinterpret_cast<float*>(smem);
+    float* sn2 = qn2 + 64;
+    int* runid = reinterpret_cast<int*>(sn2 + RUN_CAP);
+    int* runlab = runid + RUN_CAP;
+    int* nrun_s = runlab + RUN_CAP;
+    constexpr int HDR = (64 + 3 * RUN_CAP + 4) * 4;
+    static_assert(HDR % 16 == 0, "stage buffers must stay 16-byte aligned");
+    float4* stage = reinterpret_cast<float4*>(smem + HDR);
+
+    int qt, st;
+    if (!decode_block(n_stiles, n_qtiles, qt, st)) return;
+    const int q0 = qt * BQ, s0 = st * BS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, g = lane >> 4;
+#ifdef NW_DIAG_FUSED   // diagnostic build only (tools/bench_fused.hip): phase stamps go to `scores`
+#define NW_FSTAMP(k) if (tid == 0) reinterpret_cast<unsigned long long*>(scores)[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime()
+#else
+#define NW_FSTAMP(k)
+#endif
+    NW_FSTAMP(0);
+
+    // cached support norms: fetched now, long before the epilogue needs them (the DMA loop never
+    // touches sn2 in this mode)
+    if (MODE == MODE_DMA_SN && NEED_NORM) {
+        for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
+    }
+    // ---- runs of equal consecutive labels inside this support tile (one wave, 3 rows per lane)
+    if (wave == 0) {
+        int lab[3], flag[3];
+        int prev_last = 0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = 3 * lane + u, j = s0 + t;
+            int64_t y = -1;
+            if (t < BS && j < N) y = sy[j];
+            lab[u] = ((uint64_t)y < (uint64_t)C) ? (int)y : -1;
+        }
+        prev_last = __shfl_up(lab[2], 1);
+        flag[0] = (lane == 0) || (lab[0] != prev_last);
+        flag[1] = lab[1] != lab[0];
+        flag[2] = lab[2] != lab[1];
+        int incl = flag[0] + flag[1] + flag[2];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        int id = incl - (flag[0] + flag[1] + flag[2]) - 1;  // run id before this lane's rows
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = 3 * lane + u;
+            id += flag[u];
+            if (t < BS) {
+                runid[t] = id;
+                if (flag[u]) runlab[id] = lab[u];
+                if (t == BS - 1) *nrun_s = id + 1;
+            }
+        }
+    }
+
+    NW_FSTAMP(1);
+    // the K walk of every support tile starts at a different chunk (see tile_core.h: spreads the
+    // simultaneous requests of all workgroups over the memory channels); the workgroups that share
+    // a support tile keep the same order so that they still hit each other's lines in L2
+    const int nk = (d + BK - 1) / BK;
+    const int rot = st % nk;
+    f32x4 acc[RS];
+    if (MODE == MODE_REG) {
+        tile_dots<RS, NEED_NORM>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
+    } else {
+        tile_dots_dma<RS, NEED_NORM, NEED_NORM && MODE == MODE_DMA>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
+    }
+    // (both end behind a barrier: the run tables above and the norms are visible, and the stage
+    //  buffers are dead from here on)
+    if (MODE != MODE_DMA_SN && NEED_NORM && s_norm2 != nullptr) {  // cached norms win over computed ones
+        for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
+        __syncthreads();
+    }
+
+    NW_FSTAMP(2);
+    const bool consumer = wave < NCONS;  // waves 4-7 (loaders) hold no accumulators
+    float scale = 1.f;
+    if (KIND == NW_SCORE_CLIP) scale = expf(*logit_scale);
+    const int qrow = 16 * (wave & 3) + i;
+    const int b = q0 + qrow;
+    const float qn = NEED_NORM ? qn2[qrow] : 0.f;
+
+    float sc[RS][4];
+    float mloc = -INFINITY;
+    if (consumer) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NEED_NORM) n2 = *reinterpret_cast<const float4*>(sn2 + 16 * r + 4 * g);
+            const float nn[4] = {n2.x, n2.y, n2.z, n2.w};
+            const int j = s0 + 16 * r + 4 * g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = score_from_dot<KIND>(acc[r][e], qn, nn[e], scale);
+                sc[r][e] = (j + e < N) ? v : -INFINITY;
+                mloc = fmaxf(mloc, sc[r][e]);
+            }
+        }
+        if (WRITE_SCORES && b < B) {
+            float* orow = scores + (size_t)b * N;
+            const bool vec_ok = (N & 3) == 0;
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const int j = s0 + 16 * r + 4 * g;
+                if (j >= N) continue;
+                if (vec_ok) {
+                    *reinterpret_cast<float4*>(orow + j) = make_float4(sc[r][0], sc[r][1], sc[r][2], sc[r][3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j + e < N) orow[j + e] = sc[r][e];
+                }
+            }
+        }
+        // tile-local max over the wave's 16 query columns: lanes i, i+16, i+32, i+48 hold one query
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    }
+
+    NW_FSTAMP(3);
+    // ---- e^(s - m) and its sums over the runs of equal labels, on the matrix cores:
+    //   P[run][query] = sum_t [runid_t == run] * E[t][query]
+    // E is already laid out as an MFMA B operand (lane (i,g) holds E[16r+4g+e][query i]: for fixed
+    // (r,e) the four lane groups are the four k-slots of one 16x16x4 MFMA), the indicator is the A
+    // operand (lane (i,g) supplies [runid[16r+4g+e] == run_base + i]), so 4*RS MFMAs per 16 runs give
+    // every lane its four (run, query) sums: no LDS atomics, no divergence, bit-reproducible.
+    if (consumer) {
+        float dloc = 0.f;
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc[r][e] = fast_exp_neg(sc[r][e] - mloc);
+                dloc += sc[r][e];
+            }
+        dloc += __shfl_xor(dloc, 16);
+        dloc += __shfl_xor(dloc, 32);
+        NW_FSTAMP(4);
+        const int nrun = *nrun_s;
+        for (int run_base = 0; run_base < nrun; run_base += 16) {
+            f32x4 P = {0.f, 0.f, 0.f, 0.f};
+            const int want = run_base + i;
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const int4 rid = *reinterpret_cast<const int4*>(runid + 16 * r + 4 * g);
+                P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.x == want ? 1.f : 0.f, sc[r][0], P, 0, 0, 0);
+                P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.y == want ? 1.f : 0.f, sc[r][1], P, 0, 0, 0);
+                P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.z == want ? 1.f : 0.f, sc[r][2], P, 0, 0, 0);
+                P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.w == want ? 1.f : 0.f, sc[r][3], P, 0, 0, 0);
+            }
+            // P[j] = sum of run (run_base + 4g + j) for query column i
+            if (b < B) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int run = run_base + 4 * g + j;
+                    if (run < nrun) ws_num[((size_t)st * BS + run) * B + b] = P[j];
+                }
+            }
+        }
+        NW_FSTAMP(5);
+        if (g == 0 && b < B) {
+            ws_m[(size_t)st * B + b] = mloc;
+            ws_den[(size_t)st * B + b] = dloc;
+        }
+    }
+    if (qt == 0) {  // run table is a property of the support tile: written once per tile
+        const int nrun = *nrun_s;
+        if (tid == 0) ws_nrun[st] = nrun;
+        for (int x = tid; x < nrun; x += TILE_THREADS) ws_lab[(size_t)st * BS + x] = runlab[x];
+    }
+    NW_FSTAMP(6);
+}
+
+
+constexpr size_t FUSED_HDR = (64 + 3 * RUN_CAP + 4) * 4;
+
+template <int RS, int KIND>
+int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
+                    const float* ls, float* out, float* scores, float* lse, float* m, float* den,
+                    float* num, void* workspace, size_t workspace_bytes, int B, int N, int d, int C,
+                    hipStream_t st) {
+    constexpr int BS = 16 * RS;
+    const int n_stiles = (N + BS - 1) / BS;
+    const int n_qtiles = (B + BQ - 1) / BQ;
+    FusedWs ws;
+    const size_t need = fused_layout(B, n_stiles, BS, static_cast<char*>(workspace), &ws);
+    if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
+    const int grid = padded_grid(n_stiles, n_qtiles);
+    const bool dma = (d % BK) == 0 && (uint64_t)N * d * 4 < 0xffffffffull && (uint64_t)B * d * 4 < 0xffffffffull;
+    const size_t lds_reg = FUSED_HDR + TileCfg<RS>::STAGE_BYTES, lds_dma = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
+#define NW_LAUNCH(WS_, MODE_, LDS_)                                                                      \
+    hipLaunchKernelGGL((nw_fused_kernel<RS, KIND, WS_, MODE_>), dim3(grid), dim3(TILE_THREADS), LDS_, st, \
+                       q, s, sy, s_norm2, ls, scores, ws.m, ws.den, ws.nrun, ws.lab, ws.num, B, N, d, C,   \
+                       n_stiles, n_qtiles)
+    if (dma && s_norm2 && KIND != NW_SCORE_DOT) {
+        if (scores) NW_LAUNCH(true, MODE_DMA_SN, lds_dma); else NW_LAUNCH(false, MODE_DMA_SN, lds_dma);
+    } else if (dma) {
+        if (scores) NW_LAUNCH(true, MODE_DMA, lds_dma); else NW_LAUNCH(false, MODE_DMA, lds_dma);
+    } else {
+        if (scores) NW_LAUNCH(true, MODE_REG, lds_reg); else NW_LAUNCH(false, MODE_REG, lds_reg);
+    }
+#undef NW_LAUNCH
+    NW_CHECK_LAUNCH();
+    return launch_merge_runs(ws, out, lse, m, den, num, B, C, n_stiles, BS, st);
+}
+
+}  // namespace
+
+template <int KIND>
+int launch_fused_kind(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
+                      const float* ls, float* out, float* scores, float* lse, float* m, float* den,
+                      float* num, void* workspace, size_t wsb, int B, int N, int d, int C, hipStream_t st) {
+#define NW_RS_CASE(R) \
+    case R: return launch_fused_rs<R, KIND>(q, s, sy, s_norm2, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st)
+    switch (pick_rs(B, N)) {
+        NW_RS_CASE(2);
+        NW_RS_CASE(4);
+        NW_RS_CASE(6);
+        NW_RS_CASE(8);
+        NW_RS_CASE(10);
+        default: return launch_fused_rs<12, KIND>(q, s, sy, s_norm2, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st);
+    }
+#undef NW_RS_CASE
+}
+
+#define NW_INSTANTIATE_FUSED_KIND(K)                                                                   \
+    template int launch_fused_kind<K>(const float*, const float*, const int64_t*, const float*,        \
+                                      const float*, float*, float*, float*, float*, float*, float*,    \
+                                      void*, size_t, int, int, int, int, hipStream_t);
+
+}  // namespace nw

@@ -28,6 +28,19 @@ int launch_aggregate(const float* scores, const int64_t* sy, int labels_batched,
 int launch_merge(const float* m, const float* den, const float* num, float* out, int64_t G,
                  int64_t B, int64_t C, int64_t sm, int64_t sd, int64_t sn, hipStream_t st);
 
+// squared row norms of a (rows,d) matrix (backward.hip)
+int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStream_t st);
+
+// fused forward (fused.hip)
+int pick_rs(int64_t B, int64_t N);
+bool fused_eligible(const float* q, const float* s, int64_t B, int64_t N, int64_t d, int64_t C);
+size_t fused_workspace_bytes(int64_t B, int64_t N);
+int launch_fused(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
+                 const float* logit_scale_dev, float* out, float* scores, float* lse, float* m,
+                 float* den, float* num,
+                 void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C,
+                 int kind, hipStream_t st);
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -61,18 +74,35 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return r;
 }
 
+// exp(x) for x <= 0 in ~6 VALU instructions (libm expf is ~20; in an fp32-MFMA kernel every VALU
+// instruction is matrix-pipe time).  exp(x) = 2^(x*log2e): the product is split into its rounded
+// value t and its rounding error e (one FMA), 2^t comes from v_exp_f32 (<= 1 ulp) and the error is
+// folded back as 2^t * (1 + e*ln2).  Relative error ~2e-7 over [-100, 0]; exact 0 for -inf.
+__device__ __forceinline__ float fast_exp_neg(float x) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+    const float t = x * L2E_HI;
+    const float e = __builtin_fmaf(x, L2E_HI, -t) + x * L2E_LO;
+    const float r = __builtin_amdgcn_exp2f(t);
+    return (x == -INFINITY) ? 0.f : __builtin_fmaf(r * e, 0.693147182464599609375f, r);
+}
+
+// sqrt(max(x,0)) with the hardware v_sqrt_f32 (<= 1 ulp) instead of the ~12-instruction correctly
+// rounded sequence; x is a squared distance, 1 ulp of its root is below the fp32 spacing the
+// reference's own result has.
+__device__ __forceinline__ float fast_sqrt_pos(float x) { return __builtin_amdgcn_sqrtf(fmaxf(x, 0.f)); }
+
 // score from (dot, |q|^2, |s|^2); shared by the MFMA and the generic kernels
 template <int KIND>
 __device__ __forceinline__ float score_from_dot(float dot, float qn2, float sn2, float scale) {
     if (KIND == NW_SCORE_DOT) return dot;
-    if (KIND == NW_SCORE_EUCLIDEAN) return -sqrtf(fmaxf(qn2 + sn2 - 2.f * dot, 0.f));
+    if (KIND == NW_SCORE_EUCLIDEAN) return -fast_sqrt_pos(qn2 + sn2 - 2.f * dot);
     const float nq = fmaxf(sqrtf(qn2), NW_NORM_EPS), ns = fmaxf(sqrtf(sn2), NW_NORM_EPS);
     const float c = dot / (nq * ns);
     if (KIND == NW_SCORE_COSINE) return c;
     if (KIND == NW_SCORE_CLIP) return scale * c;
     // hypersphere: -||x/|x| - y/|y|||, matmul form like torch's cdist for N > 25
     const float a = qn2 / (nq * nq), b = sn2 / (ns * ns);
-    return -sqrtf(fmaxf(a + b - 2.f * c, 0.f));
+    return -fast_sqrt_pos(a + b - 2.f * c);
 }
 
 }  // namespace nw

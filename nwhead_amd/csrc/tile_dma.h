@@ -1,0 +1,180 @@
+// tile_dma.h -- main loop of the MFMA kernels, LDS-DMA edition (gfx950 / MI355X only).
+//
+// Same tile and the same consumer stream as tile_core.h (64 queries x 16*RS supports per 512-thread
+// workgroup, waves 0-3 = MFMA consumers, waves 4-7 = loaders), but the loaders move the stage tiles
+// with global_load_lds_dwordx4 (HBM/L2 -> LDS directly, no VGPR data, no ds_write) into a FOUR-buffer
+// ring, two to three stages ahead of the consumers:
+//
+//   loader wave, iteration kt :  issue the 2 + RS/2 DMAs of stage kt+3 (1 KB each: 8 rows x 128 B)
+//                                s_waitcnt vmcnt(2 + RS/2)   -> stage kt+2 has landed
+//                                barrier                      -> ... and is published
+//   consumer wave, iteration kt: reads stage kt (and prefetches the first fragments of stage kt+1),
+//                                MFMAs, barrier.
+//
+// A loader executes ~10 instructions per stage, so it hardly competes with the MFMA wave it shares a
+// SIMD with (the register-staged loader of tile_core.h needs ~70).  That matters because on gfx950
+// the fp32 MFMA runs at exactly the fp32 VALU rate and, as measured here, does NOT overlap with VALU
+// work on the same SIMD: every v_fma issued by either wave of a SIMD costs ~10 cycles of MFMA time
+// (88 norm FMAs per stage in the consumers = +14 k cycles on a 41 k-cycle loop).  So the consumer
+// stream is kept to ds_read_b128 + MFMA, and the row norms are either
+//   * skipped for the supports when the caller passes precomputed norms (the resident bank of
+//     'full' inference: NWNet.precompute() caches them), or
+//   * accumulated by the consumers from their fragments (generic path, ~25 % slower: measured 66 k
+//     vs 51 k cycles per workgroup at B=256 N=10000 d=512; splitting the work over the waves by
+//     stage or by block did not help with hipcc's code for it -- a hand-scheduled version is open).
+//
+// The LDS image is the same XOR-swizzled [row][8 x 16 B] layout; an LDS-DMA writes lane l of a wave
+// at M0 + 16*l, i.e. linearly, so the swizzle is applied to the per-lane SOURCE address instead.
+// Requires d % 32 == 0 (a DMA cannot zero-fill a partial stage); other d use tile_core.h.
+#pragma once
+#include "tile_core.h"
+
+namespace nw {
+
+constexpr int NBUF_DMA = 4;
+
+template <int RS>
+struct DmaCfg {
+    static constexpr int BS = 16 * RS;
+    static constexpr int TILE_F4 = (BQ + BS) * ROW_F4;
+    static constexpr int NI = (BQ + BS) / 8 / NLOAD;  // DMA instructions per loader wave per stage
+    static constexpr size_t STAGE_BYTES = (size_t)NBUF_DMA * TILE_F4 * 16;
+    static_assert((BQ + BS) % (8 * NLOAD) == 0, "stage rows must split evenly over the loader waves");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Must be called by all 512 threads; d % 32 == 0, d >= 32.
+// NEED_QN / NEED_SN: accumulate squared norms of the query / support rows into qn2[0..63] / sn2[0..BS)
+// (LDS, outside the stage ring).  On return a barrier has been passed and the ring is dead.
+template <int RS, bool NEED_QN, bool NEED_SN>
+__device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const float* __restrict__ s,
+                                              int B, int N, int d, int q0, int s0, float4* stage,
+                                              float* qn2, float* sn2, f32x4 (&acc)[RS], int rot) {
+    using Cfg = DmaCfg<RS>;
+    constexpr int TILE_F4 = Cfg::TILE_F4, NI = Cfg::NI;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = d / BK;
+
+    if (wave >= NCONS) {
+        // ================================ LOADER ================================
+        const int lw = wave - NCONS;
+        // instruction n = lw + NLOAD*m covers stage rows 8n .. 8n+7 (Q rows first, then S rows)
+        // source = wave-uniform base (q or s, advanced by the stage's k offset) + a per-lane 32-bit
+        // byte offset that never changes: no vector arithmetic per DMA.
+        unsigned voff[NI];
+#pragma unroll
+        for (int m = 0; m < NI; ++m) {
+            const int R = 8 * (lw + NLOAD * m) + (lane >> 3);
+            const int lslot = (lane & 7) ^ ((R >> 1) & 7);  // source-side swizzle
+            const int grow = (8 * NLOAD * m < BQ) ? min(q0 + R, B - 1) : min(s0 + R - BQ, N - 1);
+            voff[m] = ((unsigned)grow * (unsigned)d + lslot * 4) * 4u;
+        }
+        auto issue = [&](int kt) {
+            int kc = kt + rot;
+            if (kc >= nk) kc -= nk;
+            float4* buf = stage + (kt & (NBUF_DMA - 1)) * TILE_F4;
+            const char* qb = reinterpret_cast<const char*>(q) + (size_t)kc * BK * 4;
+            const char* sb = reinterpret_cast<const char*>(s) + (size_t)kc * BK * 4;
+#pragma unroll
+            for (int m = 0; m < NI; ++m) {
+                const char* g = ((8 * NLOAD * m < BQ) ? qb : sb) + voff[m];  // rows 8n..8n+7 are all Q or all S
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(buf + 64 * (lw + NLOAD * m)),
+                                                 16, 0, 0);
+            }
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        if (nk > 2) {
+            issue(2);
+            wait_vmcnt<NI>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        tile_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 3 < nk) {
+                issue(kt + 3);
+                wait_vmcnt<NI>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            tile_barrier();
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};  // loaders hold no results
+    } else {
+        // ================================ CONSUMER ================================
+        const int i = lane & 15, g = lane >> 4;
+        struct Frag {
+            float4 b;
+            float4 a[RS];
+        };
+        const int qrow = 16 * wave + i;
+        const int rsw = (i >> 1) & 7;
+        float sqq = 0.f, sqs[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sqs[r] = 0.f;
+        }
+        auto load_frags = [&](Frag& f, int buf, int t) {
+            const float4* Qs = stage + buf * TILE_F4;
+            const float4* Ss = Qs + BQ * ROW_F4;
+            const int slot = (4 * t + g) ^ rsw;
+            f.b = Qs[qrow * ROW_F4 + slot];
+#pragma unroll
+            for (int r = 0; r < RS; ++r) f.a[r] = Ss[(16 * r + i) * ROW_F4 + slot];
+        };
+        auto mfma_step = [&](const Frag& f) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r].x, f.b.x, acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RS; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r].y, f.b.y, acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RS; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r].z, f.b.z, acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RS; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r].w, f.b.w, acc[r], 0, 0, 0);
+            if (NEED_QN) sqq += dot4(f.b);  // a wave's 16 query rows are its own
+            if (NEED_SN) {                  // generic path (no cached support norms): every wave, every block
+#pragma unroll
+                for (int r = 0; r < RS; ++r) sqs[r] += dot4(f.a[r]);
+            }
+        };
+
+        tile_barrier();  // stages 0 and 1 have landed
+        Frag f0, f1;
+        load_frags(f0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int b0 = kt & (NBUF_DMA - 1), b1 = (kt + 1) & (NBUF_DMA - 1);
+            load_frags(f1, b0, 1);
+            mfma_step(f0);
+            if (kt + 1 < nk) load_frags(f0, b1, 0);
+            mfma_step(f1);
+            tile_barrier();
+        }
+        // lanes i, i+16, i+32, i+48 hold the four k-slices of one row's squared norm
+        if (NEED_QN) {
+            sqq += __shfl_xor(sqq, 16);
+            sqq += __shfl_xor(sqq, 32);
+            if (g == 0) qn2[qrow] = sqq;
+        }
+        if (NEED_SN) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                float v = sqs[r];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if ((r & (NCONS - 1)) == wave && g == 0) sn2[16 * r + i] = v;  // all four waves hold the same value
+            }
+        }
+    }
+    if (NEED_QN || NEED_SN) __syncthreads();
+}
+
+}  // namespace nw

@@ -26,9 +26,9 @@ class NWHead(nn.Module):
         self.kernel = kernel
         self.n_classes = n_classes
 
-    def forward(self, x, sx, sy, return_weights=False):
+    def forward(self, x, sx, sy, return_weights=False, support_norm2=None):
         return ops.nw_head(x, sx, sy, self.n_classes, self.kernel.kind, self.kernel._logit_scale(),
-                           return_weights=return_weights)
+                           return_weights=return_weights, support_norm2=support_norm2)
 
 
 class NWNet(nn.Module):
@@ -81,6 +81,7 @@ class NWNet(nn.Module):
         assert not self.featurizer.training
         info = self._compute_all_support_feats()
         self.full_feat, self.full_y = info[0], info[1]
+        self.full_norm2 = ops.row_norm2(self.full_feat)   # cached for predict(mode='full')
         self.support_eval.build_infer_iters(*info)
 
     def predict(self, x, mode='random'):
@@ -93,6 +94,9 @@ class NWNet(nn.Module):
         if mode == 'ensemble':
             probs = sum(self.nwhead(qfeat, f.to(x.device), y.to(x.device)).exp() for f, y in zip(sfeat, sy))
             out = torch.log(probs / len(sfeat))
+        elif mode == 'full':
+            out = self.nwhead(qfeat, sfeat.to(x.device), sy.to(x.device),
+                              support_norm2=self.full_norm2.to(x.device))
         else:
             out = self.nwhead(qfeat, sfeat.to(x.device), sy.to(x.device))
         if self.return_mask:

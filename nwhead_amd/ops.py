@@ -59,12 +59,24 @@ def nw_scores(q, s, kind="euclidean", logit_scale=None):
     return out
 
 
+def row_norm2(x):
+    """Squared L2 norm of every row of a (rows,d) fp32 HIP tensor -> (rows,).  Cache this for a support
+    bank that does not change between calls and pass it as ``support_norm2``."""
+    _need_hip(x)
+    lib = _lib.load()
+    xc = _f32c(x)
+    out = torch.empty(xc.shape[0], dtype=torch.float32, device=xc.device)
+    with torch.cuda.device(xc.device):
+        _lib.check(lib.nw_row_norm2_f32(_ptr(xc), _ptr(out), xc.shape[0], xc.shape[1], _stream(xc)), "nw_row_norm2_f32")
+    return out
+
+
 class _NWHeadFn(torch.autograd.Function):
     """autograd node for NWHead.forward (nwhead/nw.py:266-289)."""
 
     @staticmethod
-    def forward(ctx, q, s, sy, logit_scale, n_classes, kind_id, want_weights):
-        _need_hip(q, s, sy, logit_scale)
+    def forward(ctx, q, s, sy, logit_scale, n_classes, kind_id, want_weights, sn2):
+        _need_hip(q, s, sy, logit_scale, sn2)
         lib = _lib.load()
         qc, sc = _f32c(q), _f32c(s)
         syc = sy.detach().to(torch.int64).contiguous()
@@ -79,10 +91,10 @@ class _NWHeadFn(torch.autograd.Function):
         lse = torch.empty(B, dtype=torch.float32, device=dev) if need_bwd else None
         weights = torch.empty(B, N, dtype=torch.float32, device=dev) if want_weights else None
         ls = None if logit_scale is None else _f32c(logit_scale)
-        ws_bytes = 0 if need_bwd else lib.nw_fwd_workspace_bytes(B, N, d, n_classes)
+        ws_bytes = lib.nw_fwd_workspace_bytes(B, N, d, n_classes)
         ws = _workspace(ws_bytes, dev) if ws_bytes else None
         with torch.cuda.device(dev):
-            _lib.check(lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(out), _ptr(scores), _ptr(lse),
+            _lib.check(lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(out), _ptr(scores), _ptr(lse),
                                       _ptr(weights), _ptr(ws), ws_bytes, B, N, d, n_classes, kind_id,
                                       _ptr(ls), int(sup_b), int(lab_b), _stream(qc)), "nw_fwd_f32")
         if need_bwd:
@@ -110,17 +122,23 @@ class _NWHeadFn(torch.autograd.Function):
                                       _ptr(g), _ptr(gq), _ptr(gs), _ptr(gls), _ptr(ws), ws_bytes,
                                       B, N, d, C, kind_id, _ptr(ls) if has_ls else None,
                                       int(sup_b), int(lab_b), _stream(qc)), "nw_bwd_f32")
-        return gq, gs, None, gls, None, None, None
+        return gq, gs, None, gls, None, None, None, None
 
 
-def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weights=False):
-    """NWHead.forward(x, sx, sy) -> (B,C) log-probs (and the (B,N) softmax weights on request)."""
+def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weights=False,
+            support_norm2=None):
+    """NWHead.forward(x, sx, sy) -> (B,C) log-probs (and the (B,N) softmax weights on request).
+    support_norm2: optional cached ``row_norm2(s)`` for a shared (N,d) support."""
     kid = _kind_id(kind)
     if kid == SCORE_KINDS["clip"] and logit_scale is None:
         raise ValueError("clip kernel needs logit_scale")
     if s.dim() == 2 and sy.dim() != 1 or s.dim() == 3 and sy.dim() != 2:
         raise ValueError("support labels must be (N,) for (N,d) supports and (B,N) for (B,N,d)")
-    return _NWHeadFn.apply(q, s, sy, logit_scale, int(n_classes), kid, bool(return_weights))
+    if support_norm2 is not None:
+        if s.dim() != 2 or support_norm2.shape != (s.shape[0],):
+            raise ValueError("support_norm2 must be (N,) for an (N,d) support")
+        support_norm2 = _f32c(support_norm2)
+    return _NWHeadFn.apply(q, s, sy, logit_scale, int(n_classes), kid, bool(return_weights), support_norm2)
 
 
 def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None):
@@ -136,7 +154,7 @@ def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None):
     return nw_partials_into(packed, qc, sc, syc, n_classes, kind, logit_scale)
 
 
-def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_scale=None, ws=None):
+def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_scale=None, ws=None, sn2=None):
     """Write partials into ``packed`` laid out as [m (B) | den (B) | num (B*C)] (flat, contiguous):
     one buffer = one collective.  Inputs must already be fp32/int64 contiguous HIP tensors."""
     lib = _lib.load()
@@ -150,7 +168,7 @@ def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_sca
         ws = _workspace(ws_bytes, qc.device)
     ls = None if logit_scale is None else _f32c(logit_scale)
     with torch.cuda.device(qc.device):
-        _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(m), _ptr(den), _ptr(num),
+        _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(m), _ptr(den), _ptr(num),
                                           _ptr(ws), ws.numel(), B, N, d, C, _kind_id(kind), _ptr(ls),
                                           _stream(qc)), "nw_fwd_partial_f32")
     return packed

@@ -35,6 +35,8 @@ class ShardedBank:
         self._partial = partial_fn or self._hip_partial
         self._merge = merge_fn or self._hip_merge
         self._ws = None
+        # the shard never changes: cache its squared row norms once (hot loop = matrix cores only)
+        self.norm2 = ops.row_norm2(self.feat) if (partial_fn is None and self.feat.is_cuda) else None
 
     # ---- HIP compute hooks (the product path)
     def _hip_partial(self, packed_row, q):
@@ -43,7 +45,8 @@ class ShardedBank:
         need = ops._lib.load().nw_fwd_workspace_bytes(B, N, d, self.C)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=q.device)
-        ops.nw_partials_into(packed_row, q, self.feat, self.y, self.C, self.kind, self.logit_scale, ws=self._ws)
+        ops.nw_partials_into(packed_row, q, self.feat, self.y, self.C, self.kind, self.logit_scale, ws=self._ws,
+                             sn2=self.norm2)
 
     def _hip_merge(self, gathered_rows, B):
         return ops.nw_merge(gathered_rows, B, self.C)

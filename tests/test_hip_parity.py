@@ -78,10 +78,19 @@ def test_g3_backward(dev, ops, tag, kind):
     ls = _ls(dev).requires_grad_(True) if kind == "clip" else None
     out = ops.nw_head(x, sx, sy, C, kind, ls)
     F.nll_loss(out, t).backward()
-    close(out, g[f"{tag}_{kind}_out"])
+    noisy = kind in ("euclidean", "hypersphere_euclidean") and tag == "n64"
+    if noisy:
+        # queries 0 and 3 sit exactly on a support row: in the matmul-form regime (N > 25) the
+        # reference's distance there is sqrt(rounding residue) ~ 1e-3, not 0 -- a noise value of
+        # the reference's own making.  Those two rows are held to 5e-3, the others to the bar.
+        ok = [i for i in range(out.shape[0]) if i not in (0, 3)]
+        close(out[ok], g[f"{tag}_{kind}_out"][ok])
+        close(out, g[f"{tag}_{kind}_out"], rtol=1e-3, atol=5e-3)
+    else:
+        close(out, g[f"{tag}_{kind}_out"])
     gx_ref, gs_ref = g[f"{tag}_{kind}_gx"], g[f"{tag}_{kind}_gs"]
     gx, gs = x.grad.cpu().numpy(), sx.grad.cpu().numpy()
-    if kind in ("euclidean", "hypersphere_euclidean") and tag == "n64":
+    if noisy:
         # D == 0 pairs (query 0 <-> support 1, query 3 <-> support N-1) in the matmul-form regime:
         # the reference divides by a rounding residue there, so those rows carry noise-sized
         # gradients in the reference itself -- compare every other row.
@@ -137,7 +146,7 @@ def test_g7_shard_merge(dev, ops):
             for i in range(G)]
     out = ops.nw_merge(torch.stack(rows), B, C)
     close(out, g["out"])
-    close(out, ops.nw_head(x, sx, sy, C), rtol=1e-6, atol=1e-6)     # sharded == unsharded
+    close(out, ops.nw_head(x, sx, sy, C).cpu().numpy(), rtol=1e-6, atol=2e-6)     # sharded == unsharded
 
 
 def test_g8_adversarial(dev, ops, O):
@@ -230,3 +239,16 @@ def test_influence_full_size(dev, ops, O):
     np.testing.assert_array_equal(np.isfinite(infl.numpy()), np.isfinite(ref.numpy()))
     fin = np.isfinite(ref.numpy())
     np.testing.assert_allclose(infl.numpy()[fin], ref.numpy()[fin], rtol=1e-5, atol=1e-6)
+
+
+def test_cached_support_norms(dev, ops, O):
+    """predict('full') path: squared norms of the bank cached once (nw_row_norm2_f32) == in-kernel norms."""
+    q, s, sy, C = _t_inputs(dev, B=96, N=3000)
+    sn2 = ops.row_norm2(s)
+    close(sn2, (s.double() ** 2).sum(-1).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    for kind in ("euclidean", "cosine", "hypersphere_euclidean"):
+        a = ops.nw_head(q, s, sy, C, kind, support_norm2=sn2)
+        b = ops.nw_head(q, s, sy, C, kind)
+        close(a, b.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    ref = O.nw_head_f64(q[:32].cpu(), s.cpu(), sy.cpu(), C)
+    close(ops.nw_head(q, s, sy, C, support_norm2=sn2)[:32], ref.numpy(), rtol=RTOL, atol=3e-5)

@@ -1,0 +1,44 @@
+// Diagnostic harness: phase stamps of nw_fused_kernel (build with -DNW_DIAG_FUSED).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "fused_impl.h"
+using namespace nw;
+namespace nw {
+size_t fused_layout(int64_t, int64_t, int, char*, FusedWs*) { return 0; }
+int launch_merge_runs(const FusedWs&, float*, float*, float*, float*, float*, int, int, int, int, hipStream_t) { return 0; }
+int pick_rs(int64_t, int64_t) { return 10; }
+}
+int main(int argc, char** argv) {
+    const int B = atoi(argv[1]), N = atoi(argv[2]), d = atoi(argv[3]), C = atoi(argv[4]);
+    constexpr int RS = 10, BS = 160;
+    std::vector<float> hq((size_t)B * d), hs((size_t)N * d);
+    srand(1);
+    for (auto& v : hq) v = (rand() / (float)RAND_MAX) * 2 - 1;
+    for (auto& v : hs) v = (rand() / (float)RAND_MAX) * 2 - 1;
+    std::vector<int64_t> hy(N);
+    for (int j = 0; j < N; ++j) hy[j] = (int64_t)j * C / N;
+    const int n_stiles = (N + BS - 1) / BS, n_qtiles = (B + 63) / 64;
+    float *q, *s, *sn, *m, *den, *num; int64_t* sy; int *nrun, *lab; unsigned long long* dbg;
+    hipMalloc(&q, hq.size() * 4); hipMalloc(&s, hs.size() * 4); hipMalloc(&sn, N * 4); hipMalloc(&sy, N * 8);
+    hipMalloc(&m, (size_t)n_stiles * B * 4); hipMalloc(&den, (size_t)n_stiles * B * 4); hipMalloc(&nrun, n_stiles * 4);
+    hipMalloc(&lab, (size_t)n_stiles * BS * 4); hipMalloc(&num, (size_t)n_stiles * BS * B * 4); hipMalloc(&dbg, 1 << 22);
+    hipMemcpy(q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice); hipMemcpy(s, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(sy, hy.data(), N * 8, hipMemcpyHostToDevice); hipMemset(sn, 0, N * 4);
+    const int grid = padded_grid(n_stiles, n_qtiles);
+    const size_t lds = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&] { hipLaunchKernelGGL((nw_fused_kernel<RS, 0, false, MODE_DMA_SN>), dim3(grid), dim3(TILE_THREADS), lds, 0, q, s, sy, sn,
+                        (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles); };
+    for (int i = 0; i < 5; ++i) launch();
+    hipEventRecord(e0); for (int i = 0; i < 100; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(8 * grid);
+    hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    double ph[6] = {0}; int n = 0;
+    for (int b = 0; b < grid; ++b) { if (!h[8 * b + 6]) continue; ++n; for (int k = 0; k < 6; ++k) ph[k] += (double)(h[8 * b + k + 1] - h[8 * b + k]); }
+    printf("kernel %.2f us | cycles per WG: scan %.0f, main loop %.0f, scores+max %.0f, exp+den %.0f, run sums (MFMA)+store %.0f, tail %.0f (n=%d)\n",
+           ms * 10, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, n);
+    return 0;
+}
