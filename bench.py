@@ -78,7 +78,13 @@ def cpu_baseline(B_sample, N, d, C, budget_s=20.0):
     q = torch.randn(B_sample, d, generator=g)
     s = torch.randn(N, d, generator=g)
     sy = (torch.arange(N) % C).sort().values
-    cores = os.cpu_count() or 1
+    # threads actually usable: the scheduler affinity of this process, capped at the GPU box's CPU
+    # share for one GPU (16); os.cpu_count() reports every core of the host (256 on the MI355X node)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("NW_CPU_BASELINE_THREADS", "16"))))
     torch.set_num_threads(cores)
     with torch.no_grad():
         O.nw_head_f32(q, s, sy, C)                          # warm-up

@@ -1,0 +1,349 @@
+"""Headless CNN featurizers that feed the NW head: image batch (n,3,H,W) -> feature rows (n,feat).
+
+Own definitions of the architectures the reference trains (model/resnet.py, model/densenet.py,
+model/densenet3.py), with the same parameter/buffer names so that reference checkpoints load
+(`featurizer.*` keys) and the same initialisation schemes.  The convolutions run on
+MIOpen (MFMA) through PyTorch-ROCm; what is specific here:
+
+  * DenseNet blocks run concat-free under `torch.no_grad()` (precompute()/predict(), the bulk of the
+    backbone work in 'full' inference): one channel slab per block is allocated up front and every
+    layer writes its `growth_rate` new channels into it instead of re-concatenating all previous
+    features (the reference's `torch.cat` per layer, densenet.py:70-75, copies O(L^2) channels);
+  * the factories the reference ships broken (`densenet121`, `CIFAR_DenseNet121` pass arguments their
+    constructors do not take: SURVEY section 2 rows 6-7) work here and return the intended networks.
+
+Feature widths: resnet18 / CIFAR_ResNet18 512, densenet121 1024, CIFAR_DenseNet121 1024.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv(cin, cout, k, stride=1, pad=0):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=False)
+
+
+def _no_pretrained(pretrained):
+    if pretrained:
+        raise RuntimeError("pretrained weights need a download; load a state_dict instead")
+
+
+# ----------------------------------------------------------------------------- ImageNet-style ResNet
+class BasicBlock(nn.Module):
+    """conv3x3-bn-relu-conv3x3-bn (+ identity or 1x1 projection) - relu; model/resnet.py:31-66."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(inplanes, planes, 3, stride, 1), nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2, self.bn2 = _conv(planes, planes, 3, 1, 1), nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class Bottleneck(nn.Module):
+    """1x1-3x3-1x1 bottleneck with expansion 4; model/resnet.py:69-108."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(inplanes, planes, 1), nn.BatchNorm2d(planes)
+        self.conv2, self.bn2 = _conv(planes, planes, 3, stride, 1), nn.BatchNorm2d(planes)
+        self.conv3, self.bn3 = _conv(planes, planes * 4, 1), nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class ResNet(nn.Module):
+    """7x7/2 stem, max-pool, four stages, global average pool; no fc (model/resnet.py:136-207)."""
+
+    def __init__(self, block, layers, zero_init_residual=False):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1, self.bn1 = _conv(3, 64, 7, 2, 3), nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        for idx, (planes, n, stride) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 2, 2)), start=1):
+            setattr(self, f"layer{idx}", self._stage(block, planes, n, stride))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.zeros_(m.bn3.weight)
+                elif isinstance(m, BasicBlock):
+                    nn.init.zeros_(m.bn2.weight)
+
+    def _stage(self, block, planes, n, stride):
+        out = planes * block.expansion
+        down = None
+        if stride != 1 or self.inplanes != out:
+            down = nn.Sequential(_conv(self.inplanes, out, 1, stride), nn.BatchNorm2d(out))
+        blocks = [block(self.inplanes, planes, stride, down)]
+        self.inplanes = out
+        blocks += [block(out, planes) for _ in range(1, n)]
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return torch.flatten(self.avgpool(x), 1)
+
+
+# ----------------------------------------------------------------------------- CIFAR pre-act ResNet
+class PreActBlock(nn.Module):
+    """bn-relu-conv3x3-bn-relu-conv3x3 with the shortcut taken after the first activation
+    (model/resnet.py:111-134)."""
+    expansion = 1
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        self.bn1, self.conv1 = nn.BatchNorm2d(in_planes), _conv(in_planes, planes, 3, stride, 1)
+        self.bn2, self.conv2 = nn.BatchNorm2d(planes), _conv(planes, planes, 3, 1, 1)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != planes:
+            self.shortcut = nn.Sequential(_conv(in_planes, planes, 1, stride))
+
+    def forward(self, x):
+        a = F.relu(self.bn1(x))
+        y = self.conv2(F.relu(self.bn2(self.conv1(a))))
+        return y + self.shortcut(a)
+
+
+class CIFAR_ResNet(nn.Module):
+    """3x3 stem, four stages, 4x4 average pool: 32x32 inputs only (model/resnet.py:209-239)."""
+
+    def __init__(self, block, num_blocks):
+        super().__init__()
+        self.in_planes = 64
+        self.conv1, self.bn1 = _conv(3, 64, 3, 1, 1), nn.BatchNorm2d(64)
+        for idx, (planes, n, stride) in enumerate(zip((64, 128, 256, 512), num_blocks, (1, 2, 2, 2)), start=1):
+            blocks = []
+            for s in [stride] + [1] * (n - 1):
+                blocks.append(block(self.in_planes, planes, s))
+                self.in_planes = planes * block.expansion
+            setattr(self, f"layer{idx}", nn.Sequential(*blocks))
+
+    def forward(self, x, lin=0, lout=5):
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return torch.flatten(F.avg_pool2d(x, 4), 1)
+
+
+# ----------------------------------------------------------------------------- DenseNet-BC (ImageNet)
+class _DenseLayer(nn.Sequential):
+    """norm1-relu1-conv1(1x1, bn_size*k) - norm2-relu2-conv2(3x3, k); densenet.py:33-60."""
+
+    def __init__(self, cin, growth_rate, bn_size, drop_rate):
+        super().__init__(OrderedDict([
+            ("norm1", nn.BatchNorm2d(cin)), ("relu1", nn.ReLU(inplace=True)),
+            ("conv1", _conv(cin, bn_size * growth_rate, 1)),
+            ("norm2", nn.BatchNorm2d(bn_size * growth_rate)), ("relu2", nn.ReLU(inplace=True)),
+            ("conv2", _conv(bn_size * growth_rate, growth_rate, 3, 1, 1))]))
+        self.drop_rate = drop_rate
+
+    def forward(self, x):
+        # relu1 must not run in place on a slab/concat that later layers re-read
+        y = self.conv1(F.relu(self.norm1(x)))
+        y = self.conv2(self.relu2(self.norm2(y)))
+        return F.dropout(y, self.drop_rate, self.training) if self.drop_rate > 0 else y
+
+
+class _DenseBlock(nn.Module):
+    def __init__(self, num_layers, cin, bn_size, growth_rate, drop_rate):
+        super().__init__()
+        self.cin, self.growth_rate = cin, growth_rate
+        for i in range(num_layers):
+            self.add_module(f"denselayer{i + 1}", _DenseLayer(cin + i * growth_rate, growth_rate, bn_size, drop_rate))
+
+    def forward(self, x):
+        layers = list(self.children())
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            feats = [x]
+            for layer in layers:
+                feats.append(layer(torch.cat(feats, 1)))
+            return torch.cat(feats, 1)
+        # inference: one slab, each layer appends its channels (no per-layer re-concatenation)
+        n, c, h, w = x.shape
+        slab = x.new_empty(n, c + len(layers) * self.growth_rate, h, w)
+        slab[:, :c] = x
+        for layer in layers:
+            slab[:, c:c + self.growth_rate] = layer(slab[:, :c])
+            c += self.growth_rate
+        return slab
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__(OrderedDict([("norm", nn.BatchNorm2d(cin)), ("relu", nn.ReLU(inplace=True)),
+                                      ("conv", _conv(cin, cout, 1)), ("pool", nn.AvgPool2d(2, 2))]))
+
+
+class DenseNet(nn.Module):
+    """densenet.py:93-163, classifier removed: relu + global average pool of `features`."""
+
+    def __init__(self, growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4,
+                 drop_rate=0, memory_efficient=False, bias=True):
+        super().__init__()
+        self.features = nn.Sequential(OrderedDict([
+            ("conv0", _conv(3, num_init_features, 7, 2, 3)), ("norm0", nn.BatchNorm2d(num_init_features)),
+            ("relu0", nn.ReLU(inplace=True)), ("pool0", nn.MaxPool2d(3, 2, 1))]))
+        c = num_init_features
+        for i, n in enumerate(block_config, start=1):
+            self.features.add_module(f"denseblock{i}", _DenseBlock(n, c, bn_size, growth_rate, drop_rate))
+            c += n * growth_rate
+            if i != len(block_config):
+                self.features.add_module(f"transition{i}", _Transition(c, c // 2))
+                c //= 2
+        self.features.add_module("norm5", nn.BatchNorm2d(c))
+        self.num_features = c
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        return torch.flatten(F.adaptive_avg_pool2d(F.relu(self.features(x)), (1, 1)), 1)
+
+
+# ----------------------------------------------------------------------------- CIFAR DenseNet
+class CifarBottleneck(nn.Module):
+    """bn1-relu-conv1(1x1,4k)-bn2-relu-conv2(3x3,k), output = cat(new, x); densenet3.py:10-22."""
+
+    def __init__(self, in_planes, growth_rate):
+        super().__init__()
+        self.bn1, self.conv1 = nn.BatchNorm2d(in_planes), _conv(in_planes, 4 * growth_rate, 1)
+        self.bn2, self.conv2 = nn.BatchNorm2d(4 * growth_rate), _conv(4 * growth_rate, growth_rate, 3, 1, 1)
+
+    def forward(self, x):
+        y = self.conv2(F.relu(self.bn2(self.conv1(F.relu(self.bn1(x))))))
+        return torch.cat([y, x], 1)
+
+
+class CifarTransition(nn.Module):
+    def __init__(self, in_planes, out_planes):
+        super().__init__()
+        self.bn, self.conv = nn.BatchNorm2d(in_planes), _conv(in_planes, out_planes, 1)
+
+    def forward(self, x):
+        return F.avg_pool2d(self.conv(F.relu(self.bn(x))), 2)
+
+
+class CIFAR_DenseNet(nn.Module):
+    """densenet3.py:37-83 (32x32 inputs)."""
+
+    def __init__(self, block, nblocks, growth_rate=12, reduction=0.5):
+        super().__init__()
+        self.growth_rate = growth_rate
+        c = 2 * growth_rate
+        self.conv1 = _conv(3, c, 3, 1, 1)
+        for i, n in enumerate(nblocks, start=1):
+            layers = []
+            for _ in range(n):
+                layers.append(block(c, growth_rate))
+                c += growth_rate
+            setattr(self, f"dense{i}", nn.Sequential(*layers))
+            if i != len(nblocks):
+                out = int(math.floor(c * reduction))
+                setattr(self, f"trans{i}", CifarTransition(c, out))
+                c = out
+        self.bn = nn.BatchNorm2d(c)
+        self.num_features = c
+
+    def forward(self, x):
+        x = self.conv1(x)
+        x = self.trans1(self.dense1(x))
+        x = self.trans2(self.dense2(x))
+        x = self.trans3(self.dense3(x))
+        x = self.dense4(x)
+        return torch.flatten(F.avg_pool2d(F.relu(self.bn(x)), 4), 1)
+
+
+# ----------------------------------------------------------------------------- factories (load_model names)
+def resnet10(pretrained=False, **kw):
+    _no_pretrained(pretrained)
+    return ResNet(BasicBlock, [1, 1, 1, 1], **kw)
+
+
+def resnet18(pretrained=False, **kw):
+    _no_pretrained(pretrained)
+    return ResNet(BasicBlock, [2, 2, 2, 2], **kw)
+
+
+def resnet34(pretrained=False, **kw):
+    _no_pretrained(pretrained)
+    return ResNet(BasicBlock, [3, 4, 6, 3], **kw)
+
+
+def resnet50(pretrained=False, **kw):
+    _no_pretrained(pretrained)
+    return ResNet(Bottleneck, [3, 4, 6, 3], **kw)
+
+
+def resnet101(pretrained=False, **kw):
+    _no_pretrained(pretrained)
+    return ResNet(Bottleneck, [3, 4, 23, 3], **kw)
+
+
+def resnet152(pretrained=False, **kw):
+    _no_pretrained(pretrained)
+    return ResNet(Bottleneck, [3, 8, 36, 3], **kw)
+
+
+def CIFAR_ResNet10(pretrained=False, **kw):
+    return CIFAR_ResNet(PreActBlock, [1, 1, 1, 1], **kw)
+
+
+def CIFAR_ResNet18(pretrained=False, **kw):
+    return CIFAR_ResNet(PreActBlock, [2, 2, 2, 2], **kw)
+
+
+def CIFAR_ResNet34(pretrained=False, **kw):
+    return CIFAR_ResNet(PreActBlock, [3, 4, 6, 3], **kw)
+
+
+def _densenet(growth_rate, block_config, num_init_features, pretrained, num_classes=None, **kw):
+    _no_pretrained(pretrained)          # num_classes is accepted and ignored: the net is headless
+    return DenseNet(growth_rate, block_config, num_init_features, **kw)
+
+
+def densenet121(pretrained=False, progress=True, **kw):
+    return _densenet(32, (6, 12, 24, 16), 64, pretrained, **kw)
+
+
+def densenet161(pretrained=False, progress=True, **kw):
+    return _densenet(48, (6, 12, 36, 24), 96, pretrained, **kw)
+
+
+def densenet169(pretrained=False, progress=True, **kw):
+    return _densenet(32, (6, 12, 32, 32), 64, pretrained, **kw)
+
+
+def densenet201(pretrained=False, progress=True, **kw):
+    return _densenet(32, (6, 12, 48, 32), 64, pretrained, **kw)
+
+
+def CIFAR_DenseNet121(pretrained=False, num_classes=10, bias=True, **kw):
+    return CIFAR_DenseNet(CifarBottleneck, [6, 12, 24, 16], growth_rate=32)

@@ -253,7 +253,40 @@ def g8():
     #  rejects mixed dtypes -- the fp64 "true values" come from oracle/nw_oracle.py instead)
 
 
+def g6():
+    """Backbones with procedural weights (tests/procedural.py): eval and train-mode outputs."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from procedural import fill_procedural
+    from model.resnet import resnet18, CIFAR_ResNet18
+    from model.densenet import DenseNet
+    from model.densenet3 import CIFAR_DenseNet, Bottleneck as CBott
+    g = torch.Generator().manual_seed(606)
+    out = {}
+    cases = {
+        "resnet18": (lambda: resnet18(), (3, 3, 64, 64)),
+        "CIFAR_ResNet18": (lambda: CIFAR_ResNet18(), (3, 3, 32, 32)),
+        # the reference factories densenet121 / CIFAR_DenseNet121 raise TypeError (SURVEY section 2):
+        # construct the classes directly with the intended arguments
+        "densenet121": (lambda: DenseNet(32, (6, 12, 24, 16), 64), (2, 3, 64, 64)),
+        "CIFAR_DenseNet121": (lambda: CIFAR_DenseNet(CBott, [6, 12, 24, 16], growth_rate=32), (2, 3, 32, 32)),
+    }
+    for name, (ctor, shape) in cases.items():
+        net = fill_procedural(ctor())
+        x = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            net.eval()
+            out[f"{name}_x"] = x
+            out[f"{name}_eval"] = net(x)
+            net.train()
+            out[f"{name}_train"] = net(x)          # batch statistics; running stats get updated
+            out[f"{name}_nkeys"] = np.array(len(net.state_dict()))
+            bn_name = [k for k in net.state_dict() if k.endswith("running_mean")][0]
+            out[f"{name}_rm_name"] = np.array(bn_name)
+            out[f"{name}_rm_after"] = net.state_dict()[bn_name].clone()
+    npz("g6_backbones.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    for fn in (g1, g2, g3, g4, g5, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
         fn()

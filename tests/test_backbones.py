@@ -1,0 +1,41 @@
+"""A10: backbone definitions reproduce the reference's modules (fixture G6, procedural weights)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden
+from procedural import fill_procedural
+
+
+@pytest.mark.parametrize("name", ["resnet18", "CIFAR_ResNet18", "densenet121", "CIFAR_DenseNet121"])
+def test_backbone_matches_reference(name):
+    from nwhead_amd.model import load_model
+    g = load_golden("g6_backbones.npz")
+    torch.manual_seed(0)
+    net = fill_procedural(load_model(name))
+    assert len(net.state_dict()) == int(g[f"{name}_nkeys"])          # same parameter/buffer names
+    assert str(g[f"{name}_rm_name"]) in net.state_dict()
+    x = T(g[f"{name}_x"])
+    with torch.no_grad():
+        net.eval()
+        ev = net(x)                                   # DenseNet: concat-free slab path
+        np.testing.assert_allclose(ev.numpy(), g[f"{name}_eval"], rtol=1e-4, atol=1e-5)
+    # the autograd (torch.cat) path of the DenseNet block gives the same features as the slab path
+    xg = x.clone().requires_grad_(True)
+    np.testing.assert_allclose(net(xg).detach().numpy(), ev.numpy(), rtol=1e-5, atol=1e-6)
+    # training forward = autograd enabled (nw_step, train.py:409): batch statistics, running stats
+    # updated.  (The batch-2 DenseNet fixture ends on 2x2 maps: 8 samples per channel make the
+    # batch-norm statistics ill-conditioned, so only the exact training path is compared.)
+    net.train()
+    tr = net(x.clone().requires_grad_(True)).detach()
+    np.testing.assert_allclose(tr.numpy(), g[f"{name}_train"], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        np.testing.assert_allclose(net.state_dict()[str(g[f"{name}_rm_name"])].numpy(), g[f"{name}_rm_after"],
+                                   rtol=1e-5, atol=1e-6)
+
+
+def test_load_model_contract():
+    from nwhead_amd.model import load_model
+    with pytest.raises(KeyError):
+        load_model("no_such_net")
+    assert load_model("resnet18")(torch.zeros(1, 3, 64, 64)).shape == (1, 512)

@@ -1,0 +1,81 @@
+"""Host-side logic of the NWNet mirror that needs no GPU: bank ordering, sampler draws, env handling."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, data, targets):
+        self.data, self.targets = data, list(targets)
+
+    def __len__(self):
+        return len(self.targets)
+
+    def __getitem__(self, i):
+        return self.data[i], self.targets[i]
+
+
+def test_separated_indices_and_full_dataset_order():
+    from nwhead_amd.nwhead.utils import FullDataset, get_separated_indices
+    assert get_separated_indices([0, 1, 1, 2, 3]) == [[0], [1, 2], [3], [4]]
+    assert get_separated_indices(torch.tensor([7, 3, 7, 5])) == [[1], [3], [0, 2]]     # ranked by value
+    g = load_golden("g5_nwnet_plumbing.npz")
+    ds = _DS(T(g["ds_data"]), g["ds_targets"].tolist())
+    full = FullDataset(ds, 7)
+    ys = [full[i][1] for i in range(len(full))]
+    np.testing.assert_array_equal(np.array(ys), g["full_y"])           # class-sorted, balanced
+
+
+def test_sampler_draws_match_reference_for_a_seed():
+    from nwhead_amd.nwhead.support import SupportSetTrain
+    g = load_golden("g5_nwnet_plumbing.npz")
+    ds = _DS(T(g["ds_data"]), g["ds_targets"].tolist())
+    st = SupportSetTrain(ds, 10, "random", n_shot=2, n_way=6)
+    np.random.seed(99)
+    sx, sy, sm = st.get_support(T(g["yq"]))
+    np.testing.assert_array_equal(sy.numpy(), g["train_sy"])
+    np.testing.assert_array_equal(sx.numpy(), g["train_sx"])
+    assert sm.dtype == torch.float64 and float(sm.abs().sum()) == 0.0
+    with pytest.raises(AssertionError):
+        st.get_support(torch.arange(7))                     # more query classes than n_way
+
+
+def test_eval_modes_error_contract():
+    from nwhead_amd.nwhead.support import SupportSetEval
+    g = load_golden("g5_nwnet_plumbing.npz")
+    ds = _DS(T(g["ds_data"]), g["ds_targets"].tolist())
+    ev = SupportSetEval(ds, 10, 1, 7)
+    with pytest.raises(NotImplementedError):
+        ev.get_support("bogus")
+    with pytest.raises(AttributeError, match="precompute"):
+        ev.get_support("full")
+    assert len(ev.support_loaders) == 1 and len(ev.full_datasets[0]) == 70
+
+
+def test_env_array_split():
+    from nwhead_amd.nwhead.support import SupportSetEval
+    data = torch.zeros(12, 2)
+    ds = _DS(data, [0, 1, 2] * 4)
+    ev = SupportSetEval(ds, 3, 1, 2, env_array=np.array([0] * 6 + [5] * 6))
+    assert len(ev.env_datasets) == 2 and ev.env_map == {0: 0, 5: 1}
+    assert [len(d) for d in ev.full_datasets] == [6, 6]
+
+
+def test_shard_bounds_cover_the_bank():
+    from nwhead_amd.sharded import shard_bounds
+    for n, w in [(50000, 8), (10, 3), (7, 8), (0, 4)]:
+        spans = [shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def test_kernel_factory_contract():
+    from nwhead_amd.nwhead.kernel import get_kernel
+    for name in ("euclidean", "hypersphere_euclidean", "cosine", "dotproduct", "clip"):
+        assert get_kernel(name).kind == name
+    assert abs(float(get_kernel("clip").logit_scale) - np.log(1 / 0.07)) < 1e-6
+    with pytest.raises(NotImplementedError):
+        get_kernel("relationnet")

@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 gloo, compute hooks replaced by the oracle (checker), the collective
+plumbing (packing, bucketing, all-gather, merge order) is the product code in nwhead_amd/sharded.py."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from nwhead_amd.sharded import ShardedBank, shard_bounds
+        from oracle import nw_oracle as O
+        g = torch.Generator().manual_seed(11)
+        B, N, d, C = 6, 103, 24, 5
+        s = torch.randn(N, d, generator=g)
+        sy = (torch.arange(N) % C).sort().values
+        batches = [torch.randn(B, d, generator=g) for _ in range(5)]
+        lo, hi = shard_bounds(N, world, rank)
+
+        def partial_fn(row, qb):                      # oracle stands in for nw_fwd_partial_f32
+            m, den, num = O.nw_partials_f64(qb, s[lo:hi], sy[lo:hi], C)
+            row[:B] = m.float()
+            row[B:2 * B] = den.float()
+            row[2 * B:] = num.float().reshape(-1)
+
+        def merge_fn(rows, Bq):                       # oracle stands in for nw_merge_finalize_f32
+            G = rows.shape[0]
+            ms = [rows[k, :Bq].double() for k in range(G)]
+            dens = [rows[k, Bq:2 * Bq].double() for k in range(G)]
+            nums = [rows[k, 2 * Bq:2 * Bq + Bq * C].double().reshape(Bq, C) for k in range(G)]
+            return O.nw_merge_f64(ms, dens, nums).float()
+
+        bank = ShardedBank(s[lo:hi], sy[lo:hi], C, partial_fn=partial_fn, merge_fn=merge_fn)
+        outs = bank.predict_stream(batches, bucket=2)          # buckets of 2, 2, 1
+        one = bank.predict(batches[0])
+        ref = [O.nw_head_f64(qb, s, sy, C).float() for qb in batches]
+        err = max((o - r).abs().max().item() for o, r in zip(outs, ref))
+        err = max(err, (one - ref[0]).abs().max().item())
+        q.put((rank, len(outs), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_predict_stream_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n, err in res:
+        assert n == 5 and err < 2e-5, (rank, n, err)

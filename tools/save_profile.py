@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<TAG>/ rocprofv3 output tree into profiles/<NAME>_{stats.csv,pmc.json,summary.md}.
+usage: python tools/save_profile.py gpurun_out/prof_bench_r01_v2 r01_bench "command that was profiled"
+"""
+import collections, csv, glob, json, os, re, sys
+src, name = sys.argv[1], sys.argv[2]
+cmd = sys.argv[3] if len(sys.argv) > 3 else ""
+os.makedirs("profiles", exist_ok=True)
+def kname(full):
+    m = re.search(r"(nw_[a-z_0-9]+(<[^>]*>)?)", full)
+    return m.group(1) if m else full[:80]
+stats = []
+for f in glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        stats.append({"kernel": kname(r["Name"]), "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                      "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])})
+stats.sort(key=lambda r: -r["pct"])
+with open(f"profiles/{name}_stats.csv", "w") as fh:
+    w = csv.DictWriter(fh, fieldnames=list(stats[0].keys())); w.writeheader(); w.writerows(stats)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(src + "/pmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+pmc = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+for k, d in pmc.items():
+    if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+        # MI355X_MICROARCH.md, HBM section: FETCH_SIZE (KB) reports exactly half of a wide coalesced
+        # read stream on gfx950 -> doubled; WRITE_SIZE (KB) is exact for 16-B streaming stores.
+        d["hbm_read_bytes_corrected"] = 2 * d.get("FETCH_SIZE", 0.0) * 1024
+        d["hbm_write_bytes"] = d.get("WRITE_SIZE", 0.0) * 1024
+        d["hbm_bytes_per_launch"] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
+json.dump(pmc, open(f"profiles/{name}_pmc.json", "w"), indent=1, sort_keys=True)
+with open(f"profiles/{name}_summary.md", "w") as fh:
+    fh.write(f"# rocprofv3 summary `{name}`\n\ncommand: `{cmd}`\n\n## --kernel-trace --stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
+    for r in stats:
+        fh.write(f"| `{r['kernel']}` | {r['calls']} | {r['avg_us']:.2f} | {r['min_us']:.2f} | {r['max_us']:.2f} | {r['pct']:.1f} |\n")
+    fh.write("\n## --pmc (separate passes; mean per dispatch)\n\n")
+    for k, d in pmc.items():
+        fh.write(f"### `{k}`\n\n| counter | mean per dispatch |\n|---|---|\n")
+        for c, v in sorted(d.items()):
+            fh.write(f"| {c} | {v:,.1f} |\n")
+        fh.write("\n")
+print(open(f"profiles/{name}_summary.md").read())
