@@ -50,6 +50,7 @@ size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws
 namespace {
 
 // One workgroup per query.  Tiles are rescaled to the global max M; run sums go to their class.
+// ws_m is in base-2 units (u = score * log2 e, see nw_fused_kernel).
 template <bool PARTIAL>
 __global__ __launch_bounds__(256) void nw_merge_runs_kernel(
     const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void nw_merge_runs_kernel(
 
     float den = 0.f;
     for (int t = tid; t < n_stiles; t += 256) {
-        const float f = expf(ws_m[(size_t)t * B + b] - M);
+        const float f = __builtin_amdgcn_exp2f(ws_m[(size_t)t * B + b] - M);
         den += ws_den[(size_t)t * B + b] * f;
         const int nr = ws_nrun[t];
         for (int r = 0; r < nr; ++r) {
@@ -80,13 +81,13 @@ __global__ __launch_bounds__(256) void nw_merge_runs_kernel(
     __syncthreads();
     if (PARTIAL) {
         if (tid == 0) {
-            m_out[b] = M;
+            m_out[b] = M * 0.693147180559945309417f;  // back to natural units
             den_out[b] = den;
         }
         for (int c = tid; c < C; c += 256) num_out[(size_t)b * C + c] = num[c];
     } else {
         const float inv = 1.f / den;
-        if (tid == 0 && lse) lse[b] = M + logf(den);
+        if (tid == 0 && lse) lse[b] = M * 0.693147180559945309417f + logf(den);
         for (int c = tid; c < C; c += 256) out[(size_t)b * C + c] = logf(num[c] * inv + NW_LOG_EPS);
     }
 }

@@ -120,11 +120,18 @@ __global__ __launch_bounds__(TILE_THREADS) void nw_fused_kernel(
 
     NW_FSTAMP(2);
     const bool consumer = wave < NCONS;  // waves 4-7 (loaders) hold no accumulators
+    // The softmax part works in BASE-2 units u = score * log2(e): e^(s-m) = 2^(u-mu) is then one
+    // subtract and one v_exp_f32, and for the Euclidean kernel the constant is folded into the
+    // squared distance (u = -sqrt(log2(e)^2 * d2)), so an element costs fma, fma, max, sqrt, sub,
+    // exp2 + its share of the reductions -- in an fp32-MFMA kernel every VALU instruction is
+    // matrix-pipe time.  Tile statistics (ws_m) are kept in base-2 units; the merge converts.
+    constexpr float L2E = 1.44269504088896340736f, LN2 = 0.693147180559945309417f;
     float scale = 1.f;
     if (KIND == NW_SCORE_CLIP) scale = expf(*logit_scale);
     const int qrow = 16 * (wave & 3) + i;
     const int b = q0 + qrow;
     const float qn = NEED_NORM ? qn2[qrow] : 0.f;
+    const bool partial_tile = s0 + BS > N;  // only the last support tile has rows past the bank
 
     float sc[RS][4];
     float mloc = -INFINITY;
@@ -134,15 +141,26 @@ __global__ __launch_bounds__(TILE_THREADS) void nw_fused_kernel(
             float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (NEED_NORM) n2 = *reinterpret_cast<const float4*>(sn2 + 16 * r + 4 * g);
             const float nn[4] = {n2.x, n2.y, n2.z, n2.w};
-            const int j = s0 + 16 * r + 4 * g;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = score_from_dot<KIND>(acc[r][e], qn, nn[e], scale);
-                sc[r][e] = (j + e < N) ? v : -INFINITY;
-                mloc = fmaxf(mloc, sc[r][e]);
+                if (KIND == NW_SCORE_EUCLIDEAN) {
+                    const float base = __builtin_fmaf(nn[e], L2E * L2E, qn * (L2E * L2E));
+                    sc[r][e] = -fast_sqrt_pos(__builtin_fmaf(acc[r][e], -2.f * L2E * L2E, base));
+                } else {
+                    sc[r][e] = score_from_dot<KIND>(acc[r][e], qn, nn[e], scale) * L2E;
+                }
             }
         }
-        if (WRITE_SCORES && b < B) {
+        if (partial_tile) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (s0 + 16 * r + 4 * g + e >= N) sc[r][e] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) mloc = fmaxf(mloc, fmaxf(fmaxf(sc[r][0], sc[r][1]), fmaxf(sc[r][2], sc[r][3])));
+        if (WRITE_SCORES && b < B) {  // natural units for the caller (backward, neighbour search)
             float* orow = scores + (size_t)b * N;
             const bool vec_ok = (N & 3) == 0;
 #pragma unroll
@@ -150,11 +168,12 @@ __global__ __launch_bounds__(TILE_THREADS) void nw_fused_kernel(
                 const int j = s0 + 16 * r + 4 * g;
                 if (j >= N) continue;
                 if (vec_ok) {
-                    *reinterpret_cast<float4*>(orow + j) = make_float4(sc[r][0], sc[r][1], sc[r][2], sc[r][3]);
+                    *reinterpret_cast<float4*>(orow + j) =
+                        make_float4(sc[r][0] * LN2, sc[r][1] * LN2, sc[r][2] * LN2, sc[r][3] * LN2);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (j + e < N) orow[j + e] = sc[r][e];
+                        if (j + e < N) orow[j + e] = sc[r][e] * LN2;
                 }
             }
         }
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(TILE_THREADS) void nw_fused_kernel(
     }
 
     NW_FSTAMP(3);
-    // ---- e^(s - m) and its sums over the runs of equal labels, on the matrix cores:
+    // ---- 2^(u - mu) and its sums over the runs of equal labels, on the matrix cores:
     //   P[run][query] = sum_t [runid_t == run] * E[t][query]
     // E is already laid out as an MFMA B operand (lane (i,g) holds E[16r+4g+e][query i]: for fixed
     // (r,e) the four lane groups are the four k-slots of one 16x16x4 MFMA), the indicator is the A
@@ -176,13 +195,16 @@ __global__ __launch_bounds__(TILE_THREADS) void nw_fused_kernel(
         for (int r = 0; r < RS; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sc[r][e] = fast_exp_neg(sc[r][e] - mloc);
+                sc[r][e] = __builtin_amdgcn_exp2f(sc[r][e] - mloc);  // 2^-inf = 0 for padded rows
                 dloc += sc[r][e];
             }
         dloc += __shfl_xor(dloc, 16);
         dloc += __shfl_xor(dloc, 32);
         NW_FSTAMP(4);
         const int nrun = *nrun_s;
+        if (nrun == 1) {  // the whole tile is one class: its run sum is the denominator
+            if (g == 0 && b < B) ws_num[((size_t)st * BS) * B + b] = dloc;
+        } else
         for (int run_base = 0; run_base < nrun; run_base += 16) {
             f32x4 P = {0.f, 0.f, 0.f, 0.f};
             const int want = run_base + i;

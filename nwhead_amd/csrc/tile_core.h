@@ -59,10 +59,15 @@ struct TileCfg {
 // Workgroup barrier that publishes this wave's LDS writes but does NOT drain its global loads:
 // __syncthreads() fences with s_waitcnt vmcnt(0), which would park a loader wave (and with it every
 // consumer waiting at the same barrier) for the full latency of the loads it has just issued.
+// The sched_barrier(0) pair pins the instruction order around it: without it hipcc moves the (register-
+// only) MFMAs of a stage BELOW the barrier and the wait, i.e. behind "wait for every LDS read in
+// flight", which exposes the full LDS latency once per stage (measured: 49.7 k -> see DESIGN.md).
 __device__ __forceinline__ void tile_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
@@ -267,9 +272,14 @@ __device__ __forceinline__ void tile_dots(const float* __restrict__ q, const flo
         int b0 = 0, b1 = 1, b2 = 2;  // buffers of stage kt, kt+1, kt+2
         if (nk > 0) load_frags(f0, 0, 0);
         for (int kt = 0; kt < nk; ++kt) {
+            // sched_barrier(0): keep the fragment reads of the NEXT step in front of this step's MFMAs
+            // (hipcc otherwise sinks them behind most of the MFMAs they are meant to hide under)
             load_frags(f1, b0, 1);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_step(f0);
+            __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < nk) load_frags(f0, b1, 0);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_step(f1);
             NW_STAMP(c0);
             tile_barrier();

@@ -98,13 +98,17 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
         }
         tile_barrier();
         for (int kt = 0; kt < nk; ++kt) {
+#ifndef NW_ABL_NODMA
             if (kt + 3 < nk) {
                 issue(kt + 3);
                 wait_vmcnt<NI>();
             } else {
                 wait_vmcnt<0>();
             }
+#endif
+#ifndef NW_ABL_NOBAR
             tile_barrier();
+#endif
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};  // loaders hold no results
@@ -117,7 +121,8 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
         };
         const int qrow = 16 * wave + i;
         const int rsw = (i >> 1) & 7;
-        float sqq = 0.f, sqs[RS];
+        float4 sq4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sqs[RS];
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -140,7 +145,12 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
             for (int r = 0; r < RS; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r].z, f.b.z, acc[r], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < RS; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r].w, f.b.w, acc[r], 0, 0, 0);
-            if (NEED_QN) sqq += dot4(f.b);  // a wave's 16 query rows are its own
+            if (NEED_QN) {  // a wave's 16 query rows are its own; four independent FMAs, no dependent chain
+                sq4.x = __builtin_fmaf(f.b.x, f.b.x, sq4.x);
+                sq4.y = __builtin_fmaf(f.b.y, f.b.y, sq4.y);
+                sq4.z = __builtin_fmaf(f.b.z, f.b.z, sq4.z);
+                sq4.w = __builtin_fmaf(f.b.w, f.b.w, sq4.w);
+            }
             if (NEED_SN) {                  // generic path (no cached support norms): every wave, every block
 #pragma unroll
                 for (int r = 0; r < RS; ++r) sqs[r] += dot4(f.a[r]);
@@ -152,14 +162,22 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
         load_frags(f0, 0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             const int b0 = kt & (NBUF_DMA - 1), b1 = (kt + 1) & (NBUF_DMA - 1);
+            // sched_barrier(0): keep the fragment reads of the NEXT step in front of this step's MFMAs
+            // (hipcc otherwise sinks them behind most of the MFMAs they are meant to hide under)
             load_frags(f1, b0, 1);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_step(f0);
+            __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < nk) load_frags(f0, b1, 0);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_step(f1);
+#ifndef NW_ABL_NOBAR
             tile_barrier();
+#endif
         }
         // lanes i, i+16, i+32, i+48 hold the four k-slices of one row's squared norm
         if (NEED_QN) {
+            float sqq = (sq4.x + sq4.y) + (sq4.z + sq4.w);
             sqq += __shfl_xor(sqq, 16);
             sqq += __shfl_xor(sqq, 32);
             if (g == 0) qn2[qrow] = sqq;
