@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--classes", type=int, default=200)
     ap.add_argument("--bucket", type=int, default=8, help="query batches per RCCL all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-extras", action="store_true", help="only the timed workload (for profiling)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,8 +120,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # NW_FORCE_DIST=1 rehearses the RCCL code path on a single rank (the 1-GPU box cannot host two)
+    use_dist = world > 1 or os.environ.get("NW_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from nwhead_amd import ops
@@ -136,15 +140,11 @@ def main():
     qs = [torch.randn(B, d, generator=gq).to(dev) for _ in range(4)]
 
     def run(nsteps):
-        if world == 1:
-            outs = None
-            for i in range(nsteps):
-                outs = ops.nw_head(qs[i % 4], bank.feat, bank.y, C, support_norm2=bank.norm2)
-            return outs
+        # same code path at every N: buckets of query batches coalesced per launch (sharded.py)
         return bank.predict_stream([qs[i % 4] for i in range(nsteps)], bucket=args.bucket)[-1]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,7 +154,7 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -163,29 +163,35 @@ def main():
     if rank == 0:
         n_shard = hi - lo
         # one launch = one forward over this rank's shard = nw_fused_kernel (+ the small merge kernel)
-        t_sc = time_kernel_events(lambda: ops.nw_partials(qs[0], bank.feat, bank.y, C) if world > 1 else
-                                  ops.nw_head(qs[0], bank.feat, bank.y, C, support_norm2=bank.norm2), 50)
-        flops = 2.0 * B * n_shard * d
+        # one launch = the partial forward of one bucket (bucket*B queries) over this rank's shard:
+        # nw_fused_kernel + nw_merge_runs_kernel
+        Bl = B * args.bucket
+        qcat = torch.cat([qs[i % 4] for i in range(args.bucket)], dim=0)
+        pk = torch.empty(bank.row_len(Bl), dtype=torch.float32, device=dev)
+        t_sc = time_kernel_events(lambda: bank._partial(pk, qcat), 20)
+        flops = 2.0 * Bl * n_shard * d
         roof = {"bound": "mfma", "kernel": "nw_fused_kernel (+nw_merge_runs_kernel)", "achieved": flops / t_sc / 1e12,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                 "launch_us": t_sc * 1e6, "alg_flops_per_launch": flops,
-                "alg_bytes_per_launch": alg_bytes(B, n_shard, d, C),
-                "alg_GBps": alg_bytes(B, n_shard, d, C) / t_sc / 1e9}
+                "queries_per_launch": Bl,
+                "alg_bytes_per_launch": alg_bytes(Bl, n_shard, d, C),
+                "alg_GBps": alg_bytes(Bl, n_shard, d, C) / t_sc / 1e9}
         line = {"metric": "query-predictions/sec", "value": args.steps * B / dt, "unit": "query-predictions/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"K3 predict('full'): B={B} queries/step vs bank N={N} d={d} C={C}, "
-                                       f"bank sharded {world}-way" + (f", all-gather bucket {args.bucket}" if world > 1 else ""),
+                                       f"bank sharded {world}-way, {args.bucket} query batches coalesced per launch"
+                                       + (" and per RCCL all-gather" if world > 1 else ""),
                            "B": B, "N_support": N, "d": d, "C": C, "parallelism": f"support-shard x{world}"},
                 "roofline": roof}
-        if world == 1:
+        if world == 1 and not args.skip_extras:
             line["north_star_T"] = measure_shape(256, 10000, 512, 200, dev, 100)
             line["config_K2_head"] = measure_shape(64, 1000, 512, 200, dev, 100)
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(32, N, d, C)
-    if world > 1:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(32, N, d, C)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

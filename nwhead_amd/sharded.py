@@ -58,41 +58,44 @@ class ShardedBank:
         """One query batch: (B,d) -> (B,C) log-probabilities, identical on every rank."""
         return self.predict_stream([q], bucket=1)[0]
 
-    def predict_stream(self, batches, bucket=4):
+    def predict_stream(self, batches, bucket=8):
         """Pipelined prediction of a list of equally-shaped query batches.
 
-        Per bucket of `bucket` batches: partial kernels write their rows of one packed buffer, one
-        async all-gather ships it, and the merge of the previous bucket runs while it flies."""
+        Every `bucket` consecutive batches are coalesced into ONE launch of the partial forward (the
+        kernel tiles over queries anyway, and one launch over bucket*B queries amortises the launch,
+        the tile prologue and the merge), ONE packed buffer [m | den | num] and ONE all-gather; the
+        merge of bucket i runs after the kernels of bucket i+1 have been queued, so the collective
+        flies under them.  Outputs are returned per batch, in order."""
         if not batches:
             return []
         B = batches[0].shape[0]
-        L = self.row_len(B)
         dev, G = self.feat.device, self.world
         outs, pending = [], None
-        ring = [None, None, None]
+        ring = {}
 
         def finish(p):
             work, gathered, nb = p
             if work is not None:
                 work.wait()
-            for k in range(nb):
-                rows = gathered[:, k, :]                 # (G, L): shard g's partials of batch k
-                outs.append(self._merge(rows if rows.is_contiguous() else rows.contiguous(), B))
+            out = self._merge(gathered, nb * B)            # (nb*B, C)
+            outs.extend(out[k * B:(k + 1) * B] for k in range(nb))
 
-        for i0 in range(0, len(batches), bucket):
+        for n_bucket, i0 in enumerate(range(0, len(batches), bucket)):
             chunk = batches[i0:i0 + bucket]
             nb = len(chunk)
-            slot = (i0 // bucket) % 3
-            if ring[slot] is None or ring[slot][0].shape[0] != nb:
-                ring[slot] = (torch.empty(nb, L, dtype=torch.float32, device=dev),
-                              torch.empty(G, nb, L, dtype=torch.float32, device=dev))
-            packed, gathered = ring[slot]
-            for k, q in enumerate(chunk):
-                self._partial(packed[k], q.detach().to(torch.float32).contiguous())
+            Bq = nb * B
+            L = self.row_len(Bq)
+            key = (n_bucket % 3, nb)
+            if key not in ring:
+                ring[key] = (torch.empty(L, dtype=torch.float32, device=dev),
+                             torch.empty(G, L, dtype=torch.float32, device=dev))
+            packed, gathered = ring[key]
+            qcat = chunk[0] if nb == 1 else torch.cat(chunk, dim=0)
+            self._partial(packed, qcat.detach().to(torch.float32).contiguous())
             if G > 1:
-                work = dist.all_gather_into_tensor(gathered.view(G * nb, L), packed, group=self.group, async_op=True)
+                work = dist.all_gather_into_tensor(gathered.view(-1), packed, group=self.group, async_op=True)
             else:
-                gathered, work = packed.view(1, nb, L), None
+                gathered, work = packed.view(1, L), None
             if pending is not None:
                 finish(pending)
             pending = (work, gathered, nb)

@@ -34,9 +34,10 @@ def _worker(rank, world, port, q):
 
         def partial_fn(row, qb):                      # oracle stands in for nw_fwd_partial_f32
             m, den, num = O.nw_partials_f64(qb, s[lo:hi], sy[lo:hi], C)
-            row[:B] = m.float()
-            row[B:2 * B] = den.float()
-            row[2 * B:] = num.float().reshape(-1)
+            nq = qb.shape[0]                          # a bucket of batches arrives coalesced
+            row[:nq] = m.float()
+            row[nq:2 * nq] = den.float()
+            row[2 * nq:] = num.float().reshape(-1)
 
         def merge_fn(rows, Bq):                       # oracle stands in for nw_merge_finalize_f32
             G = rows.shape[0]
