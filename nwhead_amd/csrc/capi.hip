@@ -49,7 +49,7 @@ extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_
     (void)d; (void)C;
     if (B <= 0 || N <= 0) return 0;
     const size_t plain = align256((size_t)B * (size_t)N * sizeof(float));
-    const size_t fused = nw::fused_workspace_bytes(B, N);
+    const size_t fused = nw::fused_workspace_bytes(B, N, d);
     return plain > fused ? plain : fused;
 }
 

@@ -28,7 +28,7 @@ namespace {
 enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2 };
 
 template <int RS, int KIND, bool WRITE_SCORES, int MODE>
-__global__ __launch_bounds__(TILE_THREADS) void nw_fused_kernel(
+__global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kernel(
     const float* __restrict__ q, const float* __restrict__ s, const int64_t* __restrict__ sy,
     const float* __restrict__ s_norm2, const float* __restrict__ logit_scale,
     float* __restrict__ scores, float* __restrict__ ws_m,
@@ -254,7 +254,10 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
     const size_t need = fused_layout(B, n_stiles, BS, static_cast<char*>(workspace), &ws);
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
     const int grid = padded_grid(n_stiles, n_qtiles);
+    // RS = 5 exists for the LDS-DMA modes only (two workgroups per CU); the register-staged loaders
+    // need an even split of the tile rows
     const bool dma = (d % BK) == 0 && (uint64_t)N * d * 4 < 0xffffffffull && (uint64_t)B * d * 4 < 0xffffffffull;
+    if (!dma && (RS & 1)) return NW_ERR_UNSUPPORTED;
     const size_t lds_reg = FUSED_HDR + TileCfg<RS>::STAGE_BYTES, lds_dma = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
 #define NW_LAUNCH(WS_, MODE_, LDS_)                                                                      \
     hipLaunchKernelGGL((nw_fused_kernel<RS, KIND, WS_, MODE_>), dim3(grid), dim3(TILE_THREADS), LDS_, st, \
@@ -280,9 +283,10 @@ int launch_fused_kind(const float* q, const float* s, const int64_t* sy, const f
                       float* num, void* workspace, size_t wsb, int B, int N, int d, int C, hipStream_t st) {
 #define NW_RS_CASE(R) \
     case R: return launch_fused_rs<R, KIND>(q, s, sy, s_norm2, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st)
-    switch (pick_rs(B, N)) {
+    switch (pick_rs(B, N, d)) {
         NW_RS_CASE(2);
         NW_RS_CASE(4);
+        NW_RS_CASE(5);
         NW_RS_CASE(6);
         NW_RS_CASE(8);
         NW_RS_CASE(10);

@@ -32,9 +32,9 @@ int launch_merge(const float* m, const float* den, const float* num, float* out,
 int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStream_t st);
 
 // fused forward (fused.hip)
-int pick_rs(int64_t B, int64_t N);
+int pick_rs(int64_t B, int64_t N, int64_t d);
 bool fused_eligible(const float* q, const float* s, int64_t B, int64_t N, int64_t d, int64_t C);
-size_t fused_workspace_bytes(int64_t B, int64_t N);
+size_t fused_workspace_bytes(int64_t B, int64_t N, int64_t d);
 int launch_fused(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
                  const float* logit_scale_dev, float* out, float* scores, float* lse, float* m,
                  float* den, float* num,

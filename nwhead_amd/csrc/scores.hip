@@ -138,7 +138,7 @@ int launch_kind(const float* q, const float* s, float* scores, int64_t B, int64_
     const bool mfma_ok = !sup_batched && N > 25 && d >= 4 && (d % 4) == 0 && aligned &&
                          B < (1 << 30) && N < (1 << 30) && d < (1 << 30);
     if (mfma_ok) {
-        switch (pick_rs(B, N)) {
+        switch (pick_rs(B, N, /*d: register-staged path, even tiles only*/ 1)) {
             case 2: return launch_mfma_rs<2, KIND>(q, s, scores, ls, (int)B, (int)N, (int)d, st);
             case 4: return launch_mfma_rs<4, KIND>(q, s, scores, ls, (int)B, (int)N, (int)d, st);
             case 6: return launch_mfma_rs<6, KIND>(q, s, scores, ls, (int)B, (int)N, (int)d, st);

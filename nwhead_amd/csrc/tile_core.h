@@ -54,6 +54,7 @@ struct TileCfg {
     static constexpr int TILE_F4 = (BQ + BS) * ROW_F4;         // float4 per stage buffer
     static constexpr size_t STAGE_BYTES = (size_t)3 * TILE_F4 * 16;  // three stage buffers
     static_assert(BQ * ROW_F4 % LOADER_THREADS == 0 && BS * ROW_F4 % LOADER_THREADS == 0, "tile/loader split");
+    static_assert(3 * TILE_F4 * 16 <= 160 * 1024, "stage ring exceeds LDS");
 };
 
 // Workgroup barrier that publishes this wave's LDS writes but does NOT drain its global loads:

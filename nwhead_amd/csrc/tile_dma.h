@@ -31,16 +31,21 @@
 
 namespace nw {
 
-constexpr int NBUF_DMA = 4;
-
+// Ring depth.  Tiles of up to 5 support blocks keep a workgroup under 80 KB of LDS and 128 VGPRs,
+// so TWO workgroups share a CU (4 waves per SIMD): one's barrier bubbles, DMA prologue and VALU
+// epilogue run under the other's MFMAs.
 template <int RS>
 struct DmaCfg {
     static constexpr int BS = 16 * RS;
     static constexpr int TILE_F4 = (BQ + BS) * ROW_F4;
-    static constexpr int NI = (BQ + BS) / 8 / NLOAD;  // DMA instructions per loader wave per stage
-    static constexpr size_t STAGE_BYTES = (size_t)NBUF_DMA * TILE_F4 * 16;
-    static_assert((BQ + BS) % (8 * NLOAD) == 0, "stage rows must split evenly over the loader waves");
+    static constexpr int NT = (BQ + BS) / 8;                 // DMA instructions per stage (1 KB each)
+    static constexpr int NI = (NT + NLOAD - 1) / NLOAD;      // ... per loader wave (waves lw < NT % NLOAD, or all)
+    static constexpr int NI_LO = NT / NLOAD;                 // ... for the other loader waves
+    static constexpr int NBUF = 4;
+    static constexpr size_t STAGE_BYTES = (size_t)NBUF * TILE_F4 * 16;
+    static constexpr int WAVES_PER_SIMD = (RS <= 5) ? 4 : 2; // launch bound: 128 or 256 VGPRs
 };
+constexpr int NBUF_DMA = 4;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -55,7 +60,7 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
                                               int B, int N, int d, int q0, int s0, float4* stage,
                                               float* qn2, float* sn2, f32x4 (&acc)[RS], int rot) {
     using Cfg = DmaCfg<RS>;
-    constexpr int TILE_F4 = Cfg::TILE_F4, NI = Cfg::NI;
+    constexpr int TILE_F4 = Cfg::TILE_F4, NI = Cfg::NI, NI_LO = Cfg::NI_LO, NT = Cfg::NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = d / BK;
@@ -82,17 +87,23 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
             const char* sb = reinterpret_cast<const char*>(s) + (size_t)kc * BK * 4;
 #pragma unroll
             for (int m = 0; m < NI; ++m) {
+                if (NI != NI_LO && m == NI - 1 && lw + NLOAD * m >= NT) break;  // uneven split: last slot of the short waves
                 const char* g = ((8 * NLOAD * m < BQ) ? qb : sb) + voff[m];  // rows 8n..8n+7 are all Q or all S
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(buf + 64 * (lw + NLOAD * m)),
                                                  16, 0, 0);
             }
         };
+        // stage kt+2 has landed once at most this wave's DMAs of stage kt+3 are outstanding
+        const bool long_wave = (NI == NI_LO) || (lw < NT % NLOAD);
+        auto wait_next = [&]() {
+            if (long_wave) wait_vmcnt<NI>(); else wait_vmcnt<NI_LO>();
+        };
         issue(0);
         if (nk > 1) issue(1);
         if (nk > 2) {
             issue(2);
-            wait_vmcnt<NI>();
+            wait_next();
         } else {
             wait_vmcnt<0>();
         }
@@ -101,7 +112,7 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
 #ifndef NW_ABL_NODMA
             if (kt + 3 < nk) {
                 issue(kt + 3);
-                wait_vmcnt<NI>();
+                wait_next();
             } else {
                 wait_vmcnt<0>();
             }

@@ -21,7 +21,7 @@ using namespace nw;
 #endif
 
 template <int RS>
-__global__ __launch_bounds__(TILE_THREADS) void dots_kernel(const float* q, const float* s, float* out, int B, int N, int d,
+__global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void dots_kernel(const float* q, const float* s, float* out, int B, int N, int d,
                                                     int n_stiles, int n_qtiles, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qn2 = reinterpret_cast<float*>(smem);
@@ -101,6 +101,8 @@ int main(int argc, char** argv) {
     switch (RS) {
         case 4: us = run<4>(q, s, out, B, N, d, iters); break;
         case 6: us = run<6>(q, s, out, B, N, d, iters); break;
+        case 5: us = run<5>(q, s, out, B, N, d, iters); break;
+        case 3: us = run<3>(q, s, out, B, N, d, iters); break;
         case 8: us = run<8>(q, s, out, B, N, d, iters); break;
         case 10: us = run<10>(q, s, out, B, N, d, iters); break;
         default: us = run<12>(q, s, out, B, N, d, iters); break;
