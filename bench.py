@@ -21,6 +21,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA peak (= vector peak)
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+# The 'full'-inference fast path evaluates every fp32 multiply-add of the dot products with THREE fp16
+# MFMA multiply-adds (x = h + l split, tile_f16.h), so its matrix-pipe roofline in ALGORITHMIC flops is
+PEAK_SPLIT_F16_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -38,6 +42,22 @@ def make_inputs(B, N, d, C, dev, seed=0):
     s = torch.randn(N, d, generator=g)
     sy = (torch.arange(N) % C).sort().values            # class-sorted, balanced like the 'full' bank
     return q.to(dev), s.to(dev), sy.to(dev)
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass of this very
+    command (profiles/*_pmc.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            for k, v in json.load(open(f)).items():
+                if "nw_fused_kernel" in k and "hbm_bytes_per_launch" in v:
+                    if best is None or v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) >= best[0]:
+                        best = (v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), v["hbm_bytes_per_launch"], os.path.basename(f))
+        except Exception:
+            pass
+    return None if best is None else best[1]
 
 
 def time_kernel_events(fn, iters, warmup=3):
@@ -58,17 +78,20 @@ def measure_shape(B, N, d, C, dev, iters):
     """Single-GPU forward at one shape: whole-op time and the dominant (scores) kernel's time."""
     from nwhead_amd import ops
     q, s, sy = make_inputs(B, N, d, C, dev)
-    sn2 = ops.row_norm2(s)
-    t_fwd = time_kernel_events(lambda: ops.nw_head(q, s, sy, C, support_norm2=sn2), iters)
+    cache = ops.SplitBank(s)       # what precompute() keeps for the bank: norms + split-fp16 rows
+    t_fwd = time_kernel_events(lambda: ops.nw_head(q, s, sy, C, support_cache=cache), iters)
+    t_n32 = time_kernel_events(lambda: ops.nw_head(q, s, sy, C, support_norm2=cache.norm2), iters)
     t_gen = time_kernel_events(lambda: ops.nw_head(q, s, sy, C), iters)
     t_sc = t_fwd
     fl = alg_flops(B, N, d)
     return {"B": B, "N": N, "d": d, "C": C, "ms_per_call": t_fwd * 1e3, "query_pred_per_s": B / t_fwd,
-            "ms_per_call_without_cached_bank_norms": t_gen * 1e3,
+            "ms_per_call_fp32_mfma_cached_norms": t_n32 * 1e3,
+            "ms_per_call_generic_forward_no_cache": t_gen * 1e3,
             "alg_GBps": alg_bytes(B, N, d, C) / t_fwd / 1e9, "frac_hbm": alg_bytes(B, N, d, C) / t_fwd / 1e9 / PEAK_HBM_GBS,
             "fwd_TFLOPs": 2 * B * N * d / t_sc / 1e12,
-            "frac_mfma_f32": 2 * B * N * d / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "whole_op_frac_of_roofline": max(alg_bytes(B, N, d, C) / (PEAK_HBM_GBS * 1e9), fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) / t_fwd}
+            "frac_of_fp32_mfma_peak": 2 * B * N * d / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "frac_of_split_fp16_peak": 2 * B * N * d / t_sc / 1e12 / PEAK_SPLIT_F16_TFLOPS,
+            "whole_op_frac_of_roofline": max(alg_bytes(B, N, d, C) / (PEAK_HBM_GBS * 1e9), fl / (PEAK_SPLIT_F16_TFLOPS * 1e12)) / t_fwd}
 
 
 def cpu_baseline(B_sample, N, d, C, budget_s=20.0):
@@ -170,9 +193,13 @@ def main():
         pk = torch.empty(bank.row_len(Bl), dtype=torch.float32, device=dev)
         t_sc = time_kernel_events(lambda: bank._partial(pk, qcat), 20)
         flops = 2.0 * Bl * n_shard * d
+        fast = bank.cache is not None and bank.cache.split is not None
+        peak = PEAK_SPLIT_F16_TFLOPS if fast else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma", "kernel": "nw_fused_kernel (+nw_merge_runs_kernel)", "achieved": flops / t_sc / 1e12,
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "peak": peak, "unit": "TFLOP/s", "frac": flops / t_sc / 1e12 / peak, "traffic": pmc_traffic(),
+                "peak_note": ("fp16 dense MFMA peak 2500 / 3 fp16 products per fp32 multiply-add (split-fp16 operands)"
+                              if fast else "fp32 dense MFMA peak"),
+                "achieved_vs_fp32_mfma_peak": flops / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "launch_us": t_sc * 1e6, "alg_flops_per_launch": flops,
                 "queries_per_launch": Bl,
                 "alg_bytes_per_launch": alg_bytes(Bl, n_shard, d, C),

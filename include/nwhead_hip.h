@@ -74,6 +74,15 @@ int nw_scores_f32(const float *q, const float *s, float *scores,
  * hot loop for operands that do not change between calls (the precomputed support bank). */
 int nw_row_norm2_f32(const float *x, float *n2, int64_t rows, int64_t d, void *stream);
 
+/* Split-fp16 form of a dense (rows,d) fp32 matrix, d % 32 == 0 (NW_ERR_UNSUPPORTED otherwise):
+ *   out_split (rows,d) floats-worth of bytes: every 128-byte chunk of a row = [32 x h | 32 x l] fp16 with
+ *             h + l = x * 2^e to 2^-23 relative, e per row such that the row's largest magnitude lands
+ *             in [2^13, 2^14) (fp16 normal range whatever the feature scale);
+ *   row_scale (rows,) = 2^-e;   row_norm2 (rows,) = sum_k x_k^2 of the original values.
+ * Like nw_row_norm2_f32 this belongs to precompute() (nwhead/nw.py:118-125): the bank is split once. */
+int nw_split_rows_f16x2(const float *x, float *out_split, float *row_scale, float *row_norm2,
+                        int64_t rows, int64_t d, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Forward.  Replaces NWHead.forward nwhead/nw.py:266-289:
  *     one_hot(sy) -> kernel scores -> softmax over supports -> bmm with one-hot -> log(. + 1e-12)
@@ -82,6 +91,12 @@ int nw_row_norm2_f32(const float *x, float *n2, int64_t rows, int64_t d, void *s
  *               bank of 'full' inference (NWNet.precompute, nwhead/nw.py:118-125) caches them so
  *               that the hot loop is matrix-core work only; NULL = computed inside the kernel.
  *               Only read for a shared 2-D support.
+ *   s_split, s_scale   optional, d % 32 == 0 only: the support in split-fp16 form as written by
+ *               nw_split_rows_f16x2 (with s_norm2 from the same call).  Selects the fast path of
+ *               'full' inference: dot products on the fp16 matrix cores at fp32-grade accuracy
+ *               (x = h + l, three fp16 MFMAs per product block; error ~1e-7 * sum|a_k b_k|, the
+ *               level of an fp32 FMA chain).  The queries are split inside the call.  NULL = fp32
+ *               matrix cores on the original operands.
  *   out         (B,C) log-probabilities
  *   scores_out  optional (B,N): raw scores (saved for backward / neighbour search)
  *   lse_out     optional (B,):  log sum_j exp(score_bj)  (saved for backward)
@@ -90,6 +105,7 @@ int nw_row_norm2_f32(const float *x, float *n2, int64_t rows, int64_t d, void *s
  * ------------------------------------------------------------------------------------------- */
 size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C);
 int nw_fwd_f32(const float *q, const float *s, const int64_t *sy, const float *s_norm2,
+               const float *s_split, const float *s_scale,
                float *out, float *scores_out, float *lse_out, float *weights_out,
                void *workspace, size_t workspace_bytes,
                int64_t B, int64_t N, int64_t d, int64_t C,
@@ -109,6 +125,7 @@ int nw_fwd_f32(const float *q, const float *s, const int64_t *sy, const float *s
  *   three sections of each shard are packed in one all-gathered buffer).
  * ------------------------------------------------------------------------------------------- */
 int nw_fwd_partial_f32(const float *q, const float *s, const int64_t *sy, const float *s_norm2,
+                       const float *s_split, const float *s_scale,
                        float *m, float *den, float *num,
                        void *workspace, size_t workspace_bytes,
                        int64_t B, int64_t N, int64_t d, int64_t C,

@@ -49,9 +49,29 @@ extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_
     (void)d; (void)C;
     if (B <= 0 || N <= 0) return 0;
     const size_t plain = align256((size_t)B * (size_t)N * sizeof(float));
-    const size_t fused = nw::fused_workspace_bytes(B, N, d);
-    return plain > fused ? plain : fused;
+    const size_t fused = align256(nw::fused_workspace_bytes(B, N, d));
+    // + room for the split-fp16 form of the queries (rows, scales, norms) behind the fused area
+    const size_t qsplit = align256((size_t)B * (size_t)d * sizeof(float)) + 2 * align256((size_t)B * sizeof(float));
+    return (plain > fused ? plain : fused) + qsplit;
 }
+
+namespace {
+// Carves the query-split area out of the tail of the workspace and fills it (one small kernel).
+struct QSplit {
+    float *rows, *scale, *norm2;
+};
+int split_queries(const float* q, void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t d,
+                  int64_t C, QSplit* qs, hipStream_t st) {
+    const size_t total = nw_fwd_workspace_bytes(B, N, d, C);
+    if (!workspace || workspace_bytes < total) return NW_ERR_WORKSPACE;
+    const size_t a = align256((size_t)B * (size_t)d * sizeof(float)), b = align256((size_t)B * sizeof(float));
+    char* base = static_cast<char*>(workspace) + (total - a - 2 * b);
+    qs->rows = reinterpret_cast<float*>(base);
+    qs->scale = reinterpret_cast<float*>(base + a);
+    qs->norm2 = reinterpret_cast<float*>(base + a + b);
+    return nw::launch_split_rows(q, qs->rows, qs->scale, qs->norm2, B, d, st);
+}
+}  // namespace
 
 extern "C" int nw_row_norm2_f32(const float* x, float* n2, int64_t rows, int64_t d, void* stream) {
     if (rows < 0 || d < 0) return NW_ERR_INVALID_ARG;
@@ -61,7 +81,7 @@ extern "C" int nw_row_norm2_f32(const float* x, float* n2, int64_t rows, int64_t
 }
 
 extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
-                          float* out, float* scores_out, float* lse_out, float* weights_out, void* workspace,
+                          const float* s_split, const float* s_scale, float* out, float* scores_out, float* lse_out, float* weights_out, void* workspace,
                           size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C,
                           int kind, const float* logit_scale_dev, int sup_batched,
                           int labels_batched, void* stream) {
@@ -76,8 +96,17 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, con
     if (N > 0 && C > 0 && !sup_batched && !weights_out && nw::fused_eligible(q, s, B, N, d, C) &&
         (!scores_out || (reinterpret_cast<uintptr_t>(scores_out) & 15) == 0)) {
         if (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C)) return NW_ERR_WORKSPACE;
-        return nw::launch_fused(q, s, sy, s_norm2, logit_scale_dev, out, scores_out, lse_out, nullptr,
-                                nullptr, nullptr, workspace, workspace_bytes, B, N, d, C, kind, st);
+        if (s_split && s_scale && s_norm2 && d % 32 == 0 &&
+            ((reinterpret_cast<uintptr_t>(s_split) | reinterpret_cast<uintptr_t>(q)) & 15) == 0) {
+            QSplit qs;
+            const int rc = split_queries(q, workspace, workspace_bytes, B, N, d, C, &qs, st);
+            if (rc != NW_OK) return rc;
+            return nw::launch_fused(qs.rows, s_split, sy, s_norm2, s_scale, qs.norm2, qs.scale, logit_scale_dev,
+                                    out, scores_out, lse_out, nullptr, nullptr, nullptr, workspace,
+                                    workspace_bytes, B, N, d, C, kind, st);
+        }
+        return nw::launch_fused(q, s, sy, s_norm2, nullptr, nullptr, nullptr, logit_scale_dev, out, scores_out,
+                                lse_out, nullptr, nullptr, nullptr, workspace, workspace_bytes, B, N, d, C, kind, st);
     }
     float* scores = scores_out;
     if (!scores && N > 0) {
@@ -91,7 +120,8 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, con
 }
 
 extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t* sy,
-                                  const float* s_norm2, float* m, float* den, float* num, void* workspace, size_t workspace_bytes,
+                                  const float* s_norm2, const float* s_split, const float* s_scale,
+                                  float* m, float* den, float* num, void* workspace, size_t workspace_bytes,
                                   int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                                   const float* logit_scale_dev, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -103,9 +133,19 @@ extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t*
     if (kind == NW_SCORE_CLIP && !logit_scale_dev) return NW_ERR_INVALID_ARG;
     float* scores = static_cast<float*>(workspace);
     if (N > 0 && (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C))) return NW_ERR_WORKSPACE;
-    if (N > 0 && C > 0 && nw::fused_eligible(q, s, B, N, d, C))
-        return nw::launch_fused(q, s, sy, s_norm2, logit_scale_dev, nullptr, nullptr, nullptr, m, den,
-                                num, workspace, workspace_bytes, B, N, d, C, kind, st);
+    if (N > 0 && C > 0 && nw::fused_eligible(q, s, B, N, d, C)) {
+        if (s_split && s_scale && s_norm2 && d % 32 == 0 &&
+            ((reinterpret_cast<uintptr_t>(s_split) | reinterpret_cast<uintptr_t>(q)) & 15) == 0) {
+            QSplit qs;
+            const int rc = split_queries(q, workspace, workspace_bytes, B, N, d, C, &qs, st);
+            if (rc != NW_OK) return rc;
+            return nw::launch_fused(qs.rows, s_split, sy, s_norm2, s_scale, qs.norm2, qs.scale, logit_scale_dev,
+                                    nullptr, nullptr, nullptr, m, den, num, workspace, workspace_bytes, B, N, d,
+                                    C, kind, st);
+        }
+        return nw::launch_fused(q, s, sy, s_norm2, nullptr, nullptr, nullptr, logit_scale_dev, nullptr, nullptr,
+                                nullptr, m, den, num, workspace, workspace_bytes, B, N, d, C, kind, st);
+    }
     int rc = nw::launch_scores(q, s, scores, B, N, d, kind, logit_scale_dev, 0, st);
     if (rc != NW_OK) return rc;
     return nw::launch_aggregate(scores, sy, 0, nullptr, nullptr, nullptr, m, den, num, B, N, C, st);

@@ -19,6 +19,7 @@ namespace nw {
 // instantiated in fused_k0.hip .. fused_k4.hip
 #define NW_EXTERN_FUSED_KIND(K)                                                                          \
     extern template int launch_fused_kind<K>(const float*, const float*, const int64_t*, const float*,   \
+                                             const float*, const float*, const float*,                   \
                                              const float*, float*, float*, float*, float*, float*,       \
                                              float*, void*, size_t, int, int, int, int, hipStream_t);
 NW_EXTERN_FUSED_KIND(NW_SCORE_EUCLIDEAN)
@@ -118,7 +119,7 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
 // Support-tile height (in 16-row blocks).  Model: workgroups run in rounds of 256 (one per CU at
 // full MFMA rate; two co-resident ones share the pipe but fill each other's barrier bubbles, worth
 // ~15 %), each costs RS blocks of MFMA work plus a fixed prologue/epilogue.
-int pick_rs(int64_t B, int64_t N, int64_t d) {
+int pick_rs(int64_t B, int64_t N, int64_t d, bool f16) {
     const int forced = env_rs();
     if (forced == 2 || forced == 4 || forced == 5 || forced == 6 || forced == 8 || forced == 10 || forced == 12)
         return forced;
@@ -126,11 +127,15 @@ int pick_rs(int64_t B, int64_t N, int64_t d) {
     // LDS-DMA path (d % 32 == 0): 80-row tiles keep a workgroup under 80 KB of LDS and 128 VGPRs, so
     // two share a CU and hide each other's prologue, barriers and epilogue (measured 111.6 vs 105.2
     // TFLOP/s at B=2048 N=50000, 36.2 vs 37.0 us at T) -- worth it once they fill the 512 slots.
-    if (forced == 0 && d % BK == 0 && nq * ((N + 79) / 80) >= 480) return 5;
+    // (the split-fp16 path is bound by the L2->LDS stream, not by the matrix pipe: the larger tile,
+    //  which moves fewer bytes per flop, wins there: 470 vs 509 us at B=2048 N=50000)
+    if (forced == 0 && !f16 && d % BK == 0 && nq * ((N + 79) / 80) >= 480) return 5;
     const int cand[] = {2, 4, 6, 8, 10, 12};  // even: the four loader waves split a tile evenly
+    const int ncand = f16 ? 5 : 6;           // split-fp16: 12 blocks of fragments do not fit 256 VGPRs
     double best = 1e30;
     int best_rs = 8;
-    for (int rs : cand) {
+    for (int ci = 0; ci < ncand; ++ci) {
+        const int rs = cand[ci];
         const int64_t ns = (N + 16 * rs - 1) / (16 * rs);
         const int64_t nwg = nq * ns;
         const int64_t rounds = (nwg + 255) / 256;
@@ -145,9 +150,14 @@ int pick_rs(int64_t B, int64_t N, int64_t d) {
 }
 
 size_t fused_workspace_bytes(int64_t B, int64_t N, int64_t d) {
-    const int rs = pick_rs(B, N, d);
-    const int64_t n_stiles = (N + 16 * rs - 1) / (16 * rs);
-    return fused_layout(B, n_stiles, 16 * rs, nullptr, nullptr);
+    size_t need = 0;
+    for (int f16 = 0; f16 < 2; ++f16) {  // either operand form may be chosen at launch
+        const int rs = pick_rs(B, N, d, f16 != 0);
+        const int64_t n_stiles = (N + 16 * rs - 1) / (16 * rs);
+        const size_t n = fused_layout(B, n_stiles, 16 * rs, nullptr, nullptr);
+        need = n > need ? n : need;
+    }
+    return need;
 }
 
 bool fused_eligible(const float* q, const float* s, int64_t B, int64_t N, int64_t d, int64_t C) {
@@ -157,12 +167,13 @@ bool fused_eligible(const float* q, const float* s, int64_t B, int64_t N, int64_
 }
 
 // out != nullptr: final log-probabilities (+ optional scores / lse); out == nullptr: (m, den, num).
-int launch_fused(const float* q, const float* s, const int64_t* sy, const float* s_norm2, const float* ls, float* out,
+int launch_fused(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
+                 const float* s_scale, const float* q_norm2, const float* q_scale, const float* ls, float* out,
                  float* scores, float* lse, float* m, float* den, float* num, void* workspace,
                  size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                  hipStream_t st) {
 #define NW_KIND_CASE(K) \
-    case K: return launch_fused_kind<K>(q, s, sy, s_norm2, ls, out, scores, lse, m, den, num, workspace, workspace_bytes, (int)B, (int)N, (int)d, (int)C, st)
+    case K: return launch_fused_kind<K>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, out, scores, lse, m, den, num, workspace, workspace_bytes, (int)B, (int)N, (int)d, (int)C, st)
     switch (kind) {
         NW_KIND_CASE(NW_SCORE_EUCLIDEAN);
         NW_KIND_CASE(NW_SCORE_HYPERSPHERE);

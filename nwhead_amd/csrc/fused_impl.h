@@ -4,6 +4,7 @@
 #include <type_traits>
 #include "tile_core.h"
 #include "tile_dma.h"
+#include "tile_f16.h"
 
 namespace nw {
 
@@ -25,12 +26,15 @@ namespace {
 // MODE_REG : register-staged loaders (tile_core.h), any d % 4 == 0; loaders compute both norms
 // MODE_DMA : LDS-DMA loaders (tile_dma.h), d % 32 == 0; consumers compute both norms
 // MODE_DMA_SN : LDS-DMA loaders, support norms supplied by the caller (cached bank)
-enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2 };
+// MODE_F16 : LDS-DMA loaders, split-fp16 operands on the fp16 matrix cores (tile_f16.h): q and s are
+//            SPLIT rows, norms and row scales of both are supplied
+enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2, MODE_F16 = 3 };
 
 template <int RS, int KIND, bool WRITE_SCORES, int MODE>
 __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kernel(
     const float* __restrict__ q, const float* __restrict__ s, const int64_t* __restrict__ sy,
-    const float* __restrict__ s_norm2, const float* __restrict__ logit_scale,
+    const float* __restrict__ s_norm2, const float* __restrict__ s_scale, const float* __restrict__ q_norm2,
+    const float* __restrict__ q_scale, const float* __restrict__ logit_scale,
     float* __restrict__ scores, float* __restrict__ ws_m,
     float* __restrict__ ws_den, int* __restrict__ ws_nrun, int* __restrict__ ws_lab,
     float* __restrict__ ws_num, int B, int N, int d, int C, int n_stiles, int n_qtiles) {
@@ -38,13 +42,14 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
     constexpr int BS = Cfg::BS;
     constexpr bool NEED_NORM = (KIND != NW_SCORE_DOT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // header: qn2[64] | sn2[RUN_CAP] | runid[RUN_CAP] | runlab[RUN_CAP] | nrun ; then the stage buffers
+    // header: qn2[64] | sn2[RUN_CAP] | ssc[RUN_CAP] | runid[RUN_CAP] | runlab[RUN_CAP] | nrun ; then the ring
     float* qn2 = reinterpret_cast<float*>(smem);
     float* sn2 = qn2 + 64;
-    int* runid = reinterpret_cast<int*>(sn2 + RUN_CAP);
+    float* ssc = sn2 + RUN_CAP;   // MODE_F16: per-support row scale 2^-e
+    int* runid = reinterpret_cast<int*>(ssc + RUN_CAP);
     int* runlab = runid + RUN_CAP;
     int* nrun_s = runlab + RUN_CAP;
-    constexpr int HDR = (64 + 3 * RUN_CAP + 4) * 4;
+    constexpr int HDR = (64 + 4 * RUN_CAP + 4) * 4;
     static_assert(HDR % 16 == 0, "stage buffers must stay 16-byte aligned");
     float4* stage = reinterpret_cast<float4*>(smem + HDR);
 
@@ -62,8 +67,13 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
 
     // cached support norms: fetched now, long before the epilogue needs them (the DMA loop never
     // touches sn2 in this mode)
-    if (MODE == MODE_DMA_SN && NEED_NORM) {
+    if ((MODE == MODE_DMA_SN || MODE == MODE_F16) && NEED_NORM) {
         for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
+    }
+    if (MODE == MODE_F16) {
+        for (int t = tid; t < BS; t += TILE_THREADS) ssc[t] = s_scale[min(s0 + t, N - 1)];
+        if (NEED_NORM)
+            for (int t = tid; t < BQ; t += TILE_THREADS) qn2[t] = q_norm2[min(q0 + t, B - 1)];
     }
     // ---- runs of equal consecutive labels inside this support tile (one wave, 3 rows per lane)
     if (wave == 0) {
@@ -106,14 +116,17 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
     const int nk = (d + BK - 1) / BK;
     const int rot = st % nk;
     f32x4 acc[RS];
-    if (MODE == MODE_REG) {
+    if (MODE == MODE_F16) {
+        tile_dots_f16x2<RS>(q, s, B, N, d, q0, s0, stage, acc, rot);
+        __syncthreads();  // header tables written at kernel start are visible; the ring is dead
+    } else if (MODE == MODE_REG) {
         tile_dots<RS, NEED_NORM>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
     } else {
         tile_dots_dma<RS, NEED_NORM, NEED_NORM && MODE == MODE_DMA>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
     }
     // (both end behind a barrier: the run tables above and the norms are visible, and the stage
     //  buffers are dead from here on)
-    if (MODE != MODE_DMA_SN && NEED_NORM && s_norm2 != nullptr) {  // cached norms win over computed ones
+    if (MODE != MODE_DMA_SN && MODE != MODE_F16 && NEED_NORM && s_norm2 != nullptr) {  // cached norms win over computed ones
         for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
         __syncthreads();
     }
@@ -131,6 +144,7 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
     const int qrow = 16 * (wave & 3) + i;
     const int b = q0 + qrow;
     const float qn = NEED_NORM ? qn2[qrow] : 0.f;
+    const float qsc = (MODE == MODE_F16) ? q_scale[min(b, B - 1)] : 1.f;  // 2^-e of this lane's query row
     const bool partial_tile = s0 + BS > N;  // only the last support tile has rows past the bank
 
     float sc[RS][4];
@@ -141,13 +155,18 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
             float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (NEED_NORM) n2 = *reinterpret_cast<const float4*>(sn2 + 16 * r + 4 * g);
             const float nn[4] = {n2.x, n2.y, n2.z, n2.w};
+            float kk[4] = {1.f, 1.f, 1.f, 1.f};  // MODE_F16: dot = acc * 2^-(e_q + e_s)
+            if (MODE == MODE_F16) {
+                const float4 s4 = *reinterpret_cast<const float4*>(ssc + 16 * r + 4 * g);
+                kk[0] = s4.x * qsc; kk[1] = s4.y * qsc; kk[2] = s4.z * qsc; kk[3] = s4.w * qsc;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (KIND == NW_SCORE_EUCLIDEAN) {
                     const float base = __builtin_fmaf(nn[e], L2E * L2E, qn * (L2E * L2E));
-                    sc[r][e] = -fast_sqrt_pos(__builtin_fmaf(acc[r][e], -2.f * L2E * L2E, base));
+                    sc[r][e] = -fast_sqrt_pos(__builtin_fmaf(acc[r][e], (-2.f * L2E * L2E) * kk[e], base));
                 } else {
-                    sc[r][e] = score_from_dot<KIND>(acc[r][e], qn, nn[e], scale) * L2E;
+                    sc[r][e] = score_from_dot<KIND>(acc[r][e] * kk[e], qn, nn[e], scale) * L2E;
                 }
             }
         }
@@ -240,10 +259,11 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
 }
 
 
-constexpr size_t FUSED_HDR = (64 + 3 * RUN_CAP + 4) * 4;
+constexpr size_t FUSED_HDR = (64 + 4 * RUN_CAP + 4) * 4;
 
 template <int RS, int KIND>
 int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
+                    const float* s_scale, const float* q_norm2, const float* q_scale,
                     const float* ls, float* out, float* scores, float* lse, float* m, float* den,
                     float* num, void* workspace, size_t workspace_bytes, int B, int N, int d, int C,
                     hipStream_t st) {
@@ -261,9 +281,13 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
     const size_t lds_reg = FUSED_HDR + TileCfg<RS>::STAGE_BYTES, lds_dma = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
 #define NW_LAUNCH(WS_, MODE_, LDS_)                                                                      \
     hipLaunchKernelGGL((nw_fused_kernel<RS, KIND, WS_, MODE_>), dim3(grid), dim3(TILE_THREADS), LDS_, st, \
-                       q, s, sy, s_norm2, ls, scores, ws.m, ws.den, ws.nrun, ws.lab, ws.num, B, N, d, C,   \
+                       q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, scores, ws.m, ws.den, ws.nrun, ws.lab, \
+                       ws.num, B, N, d, C,                                                                  \
                        n_stiles, n_qtiles)
-    if (dma && s_norm2 && KIND != NW_SCORE_DOT) {
+    if (s_scale) {  // split-fp16 operands (the caller has checked d % 32 == 0 and supplied everything)
+        if (!dma || !s_norm2 || !q_norm2 || !q_scale) return NW_ERR_INVALID_ARG;
+        if (scores) NW_LAUNCH(true, MODE_F16, lds_dma); else NW_LAUNCH(false, MODE_F16, lds_dma);
+    } else if (dma && s_norm2 && KIND != NW_SCORE_DOT) {
         if (scores) NW_LAUNCH(true, MODE_DMA_SN, lds_dma); else NW_LAUNCH(false, MODE_DMA_SN, lds_dma);
     } else if (dma) {
         if (scores) NW_LAUNCH(true, MODE_DMA, lds_dma); else NW_LAUNCH(false, MODE_DMA, lds_dma);
@@ -279,24 +303,26 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
 
 template <int KIND>
 int launch_fused_kind(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
+                      const float* s_scale, const float* q_norm2, const float* q_scale,
                       const float* ls, float* out, float* scores, float* lse, float* m, float* den,
                       float* num, void* workspace, size_t wsb, int B, int N, int d, int C, hipStream_t st) {
 #define NW_RS_CASE(R) \
-    case R: return launch_fused_rs<R, KIND>(q, s, sy, s_norm2, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st)
-    switch (pick_rs(B, N, d)) {
+    case R: return launch_fused_rs<R, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st)
+    switch (pick_rs(B, N, d, s_scale != nullptr)) {
         NW_RS_CASE(2);
         NW_RS_CASE(4);
         NW_RS_CASE(5);
         NW_RS_CASE(6);
         NW_RS_CASE(8);
         NW_RS_CASE(10);
-        default: return launch_fused_rs<12, KIND>(q, s, sy, s_norm2, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st);
+        default: return launch_fused_rs<12, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st);
     }
 #undef NW_RS_CASE
 }
 
 #define NW_INSTANTIATE_FUSED_KIND(K)                                                                   \
     template int launch_fused_kind<K>(const float*, const float*, const int64_t*, const float*,        \
+                                      const float*, const float*, const float*,                        \
                                       const float*, float*, float*, float*, float*, float*, float*,    \
                                       void*, size_t, int, int, int, int, hipStream_t);
 

@@ -1,0 +1,82 @@
+// split.hip -- fp32 rows -> "split rows" for the fp16 matrix cores (gfx950 / MI355X only).
+//
+// For every row: e = power-of-two exponent that brings the row's largest magnitude into
+// [2^13, 2^14); every 32-float chunk of the scaled row becomes [32 x h | 32 x l] (fp16), h = fp16(x),
+// l = fp16(x - h): same bytes, same row stride as the fp32 original (format: tile_f16.h).  Also written:
+// scale[r] = 2^-e (what undoes the scaling of a dot product) and norm2[r] = sum_k x_k^2 in fp32 of the
+// ORIGINAL values (the pow(2).sum(-1) half of torch.cdist's matmul form).
+// One wave per row; HBM-bound streaming (8*d bytes per row).
+#include "nw_internal.h"
+
+namespace nw {
+namespace {
+
+__global__ __launch_bounds__(256) void nw_split_rows_kernel(const float* __restrict__ x,
+                                                             float* __restrict__ out,
+                                                             float* __restrict__ scale,
+                                                             float* __restrict__ norm2, int64_t rows,
+                                                             int64_t d) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float4* src = reinterpret_cast<const float4*>(x + r * d);
+    const int64_t n4 = d / 4;
+    float mx = 0.f, n2 = 0.f;
+    for (int64_t c = lane; c < n4; c += 64) {
+        const float4 v = src[c];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        n2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    mx = wave_max(mx);
+    n2 = wave_sum(n2);
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) {
+        frexpf(mx, &e);   // mx = f * 2^e, f in [0.5, 1)
+        e = 14 - e;       // mx * 2^e in [2^13, 2^14)
+    }
+    const float up = ldexpf(1.f, e);
+    if (lane == 0) {
+        scale[r] = ldexpf(1.f, -e);
+        norm2[r] = n2;
+    }
+    // chunk c4 (4 floats) of the row -> halves 4*(c4 % 8) .. +3 of the 32-k chunk c4 / 8
+    _Float16* dst = reinterpret_cast<_Float16*>(out + r * d);
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    for (int64_t c = lane; c < n4; c += 64) {
+        const float4 v = src[c];
+        const float s[4] = {v.x * up, v.y * up, v.z * up, v.w * up};
+        half4 h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (_Float16)s[k];
+            l[k] = (_Float16)(s[k] - (float)h[k]);
+        }
+        const int64_t chunk = c >> 3, within = (c & 7) * 4;
+        *reinterpret_cast<half4*>(dst + chunk * 64 + within) = h;
+        *reinterpret_cast<half4*>(dst + chunk * 64 + 32 + within) = l;
+    }
+}
+
+}  // namespace
+
+int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d,
+                      hipStream_t st) {
+    if (rows <= 0) return NW_OK;
+    if ((rows + 3) / 4 > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(nw_split_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, out, scale,
+                       norm2, rows, d);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+}  // namespace nw
+
+extern "C" int nw_split_rows_f16x2(const float* x, float* out_split, float* row_scale, float* row_norm2,
+                                   int64_t rows, int64_t d, void* stream) {
+    if (rows < 0 || d < 0) return NW_ERR_INVALID_ARG;
+    if (d % 32 != 0) return NW_ERR_UNSUPPORTED;
+    if (rows == 0) return NW_OK;
+    if (!x || !out_split || !row_scale || !row_norm2) return NW_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out_split)) & 15) return NW_ERR_INVALID_ARG;
+    return nw::launch_split_rows(x, out_split, row_scale, row_norm2, rows, d, static_cast<hipStream_t>(stream));
+}

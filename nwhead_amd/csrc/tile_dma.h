@@ -52,21 +52,16 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Must be called by all 512 threads; d % 32 == 0, d >= 32.
-// NEED_QN / NEED_SN: accumulate squared norms of the query / support rows into qn2[0..63] / sn2[0..BS)
-// (LDS, outside the stage ring).  On return a barrier has been passed and the ring is dead.
-template <int RS, bool NEED_QN, bool NEED_SN>
-__device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const float* __restrict__ s,
-                                              int B, int N, int d, int q0, int s0, float4* stage,
-                                              float* qn2, float* sn2, f32x4 (&acc)[RS], int rot) {
+// The loader role (waves 4-7), shared by the fp32 and the split-fp16 consumers: the stage image in
+// LDS is byte-identical in both (128 B per row per stage).
+template <int RS>
+__device__ __forceinline__ void dma_loader_run(const float* __restrict__ q, const float* __restrict__ s,
+                                               int B, int N, int d, int q0, int s0, float4* stage,
+                                               int rot, int wave, int lane) {
     using Cfg = DmaCfg<RS>;
     constexpr int TILE_F4 = Cfg::TILE_F4, NI = Cfg::NI, NI_LO = Cfg::NI_LO, NT = Cfg::NT;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = d / BK;
-
-    if (wave >= NCONS) {
-        // ================================ LOADER ================================
+    {
         const int lw = wave - NCONS;
         // instruction n = lw + NLOAD*m covers stage rows 8n .. 8n+7 (Q rows first, then S rows)
         // source = wave-uniform base (q or s, advanced by the stage's k offset) + a per-lane 32-bit
@@ -121,6 +116,25 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
             tile_barrier();
 #endif
         }
+    }
+}
+
+
+// Must be called by all 512 threads; d % 32 == 0, d >= 32.
+// NEED_QN / NEED_SN: accumulate squared norms of the query / support rows into qn2[0..63] / sn2[0..BS)
+// (LDS, outside the stage ring).  On return a barrier has been passed and the ring is dead.
+template <int RS, bool NEED_QN, bool NEED_SN>
+__device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const float* __restrict__ s,
+                                              int B, int N, int d, int q0, int s0, float4* stage,
+                                              float* qn2, float* sn2, f32x4 (&acc)[RS], int rot) {
+    using Cfg = DmaCfg<RS>;
+    constexpr int TILE_F4 = Cfg::TILE_F4, NI = Cfg::NI, NI_LO = Cfg::NI_LO, NT = Cfg::NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = d / BK;
+
+    if (wave >= NCONS) {
+        dma_loader_run<RS>(q, s, B, N, d, q0, s0, stage, rot, wave, lane);
 #pragma unroll
         for (int r = 0; r < RS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};  // loaders hold no results
     } else {

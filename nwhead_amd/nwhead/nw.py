@@ -26,9 +26,10 @@ class NWHead(nn.Module):
         self.kernel = kernel
         self.n_classes = n_classes
 
-    def forward(self, x, sx, sy, return_weights=False, support_norm2=None):
+    def forward(self, x, sx, sy, return_weights=False, support_norm2=None, support_cache=None):
         return ops.nw_head(x, sx, sy, self.n_classes, self.kernel.kind, self.kernel._logit_scale(),
-                           return_weights=return_weights, support_norm2=support_norm2)
+                           return_weights=return_weights, support_norm2=support_norm2,
+                           support_cache=support_cache)
 
 
 class NWNet(nn.Module):
@@ -81,7 +82,8 @@ class NWNet(nn.Module):
         assert not self.featurizer.training
         info = self._compute_all_support_feats()
         self.full_feat, self.full_y = info[0], info[1]
-        self.full_norm2 = ops.row_norm2(self.full_feat)   # cached for predict(mode='full')
+        self.full_cache = ops.SplitBank(self.full_feat)   # norms + split-fp16 rows for predict('full')
+        self.full_norm2 = self.full_cache.norm2
         self.support_eval.build_infer_iters(*info)
 
     def predict(self, x, mode='random'):
@@ -95,8 +97,7 @@ class NWNet(nn.Module):
             probs = sum(self.nwhead(qfeat, f.to(x.device), y.to(x.device)).exp() for f, y in zip(sfeat, sy))
             out = torch.log(probs / len(sfeat))
         elif mode == 'full':
-            out = self.nwhead(qfeat, sfeat.to(x.device), sy.to(x.device),
-                              support_norm2=self.full_norm2.to(x.device))
+            out = self.nwhead(qfeat, sfeat.to(x.device), sy.to(x.device), support_cache=self.full_cache)
         else:
             out = self.nwhead(qfeat, sfeat.to(x.device), sy.to(x.device))
         if self.return_mask:

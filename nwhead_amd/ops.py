@@ -71,12 +71,38 @@ def row_norm2(x):
     return out
 
 
+class SplitBank:
+    """A support matrix prepared once for repeated 'full' inference: split-fp16 rows, row scales and
+    squared norms (nw_split_rows_f16x2).  Pass it as ``support_cache`` to nw_head / nw_partials.
+    Falls back to norms only (fp32 matrix cores) when d % 32 != 0."""
+
+    def __init__(self, s):
+        _need_hip(s)
+        lib = _lib.load()
+        sc = _f32c(s)
+        N, d = sc.shape
+        self.shape = (N, d)
+        self.split = self.scale = None
+        if d % 32 == 0 and N > 0:
+            self.split = torch.empty_like(sc)
+            self.scale = torch.empty(N, dtype=torch.float32, device=sc.device)
+            self.norm2 = torch.empty(N, dtype=torch.float32, device=sc.device)
+            with torch.cuda.device(sc.device):
+                _lib.check(lib.nw_split_rows_f16x2(_ptr(sc), _ptr(self.split), _ptr(self.scale), _ptr(self.norm2),
+                                                   N, d, _stream(sc)), "nw_split_rows_f16x2")
+        else:
+            self.norm2 = row_norm2(sc)
+
+
 class _NWHeadFn(torch.autograd.Function):
     """autograd node for NWHead.forward (nwhead/nw.py:266-289)."""
 
     @staticmethod
-    def forward(ctx, q, s, sy, logit_scale, n_classes, kind_id, want_weights, sn2):
+    def forward(ctx, q, s, sy, logit_scale, n_classes, kind_id, want_weights, sn2, cache):
         _need_hip(q, s, sy, logit_scale, sn2)
+        ssplit = sscale = None
+        if cache is not None:
+            sn2, ssplit, sscale = cache.norm2, cache.split, cache.scale
         lib = _lib.load()
         qc, sc = _f32c(q), _f32c(s)
         syc = sy.detach().to(torch.int64).contiguous()
@@ -94,7 +120,8 @@ class _NWHeadFn(torch.autograd.Function):
         ws_bytes = lib.nw_fwd_workspace_bytes(B, N, d, n_classes)
         ws = _workspace(ws_bytes, dev) if ws_bytes else None
         with torch.cuda.device(dev):
-            _lib.check(lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(out), _ptr(scores), _ptr(lse),
+            _lib.check(lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale), _ptr(out),
+                                      _ptr(scores), _ptr(lse),
                                       _ptr(weights), _ptr(ws), ws_bytes, B, N, d, n_classes, kind_id,
                                       _ptr(ls), int(sup_b), int(lab_b), _stream(qc)), "nw_fwd_f32")
         if need_bwd:
@@ -122,13 +149,14 @@ class _NWHeadFn(torch.autograd.Function):
                                       _ptr(g), _ptr(gq), _ptr(gs), _ptr(gls), _ptr(ws), ws_bytes,
                                       B, N, d, C, kind_id, _ptr(ls) if has_ls else None,
                                       int(sup_b), int(lab_b), _stream(qc)), "nw_bwd_f32")
-        return gq, gs, None, gls, None, None, None, None
+        return gq, gs, None, gls, None, None, None, None, None
 
 
 def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weights=False,
-            support_norm2=None):
+            support_norm2=None, support_cache=None):
     """NWHead.forward(x, sx, sy) -> (B,C) log-probs (and the (B,N) softmax weights on request).
-    support_norm2: optional cached ``row_norm2(s)`` for a shared (N,d) support."""
+    support_norm2: optional cached ``row_norm2(s)`` for a shared (N,d) support.
+    support_cache: optional ``SplitBank(s)`` (norms + split-fp16 rows: the fast 'full' inference path)."""
     kid = _kind_id(kind)
     if kid == SCORE_KINDS["clip"] and logit_scale is None:
         raise ValueError("clip kernel needs logit_scale")
@@ -138,7 +166,10 @@ def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weig
         if s.dim() != 2 or support_norm2.shape != (s.shape[0],):
             raise ValueError("support_norm2 must be (N,) for an (N,d) support")
         support_norm2 = _f32c(support_norm2)
-    return _NWHeadFn.apply(q, s, sy, logit_scale, int(n_classes), kid, bool(return_weights), support_norm2)
+    if support_cache is not None and (s.dim() != 2 or tuple(s.shape) != support_cache.shape):
+        raise ValueError("support_cache was built for a different support")
+    return _NWHeadFn.apply(q, s, sy, logit_scale, int(n_classes), kid, bool(return_weights), support_norm2,
+                           support_cache)
 
 
 def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None):
@@ -154,7 +185,8 @@ def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None):
     return nw_partials_into(packed, qc, sc, syc, n_classes, kind, logit_scale)
 
 
-def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_scale=None, ws=None, sn2=None):
+def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_scale=None, ws=None, sn2=None,
+                     cache=None):
     """Write partials into ``packed`` laid out as [m (B) | den (B) | num (B*C)] (flat, contiguous):
     one buffer = one collective.  Inputs must already be fp32/int64 contiguous HIP tensors."""
     lib = _lib.load()
@@ -167,8 +199,12 @@ def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_sca
     if ws is None:
         ws = _workspace(ws_bytes, qc.device)
     ls = None if logit_scale is None else _f32c(logit_scale)
+    ssplit = sscale = None
+    if cache is not None:
+        sn2, ssplit, sscale = cache.norm2, cache.split, cache.scale
     with torch.cuda.device(qc.device):
-        _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(m), _ptr(den), _ptr(num),
+        _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale),
+                                          _ptr(m), _ptr(den), _ptr(num),
                                           _ptr(ws), ws.numel(), B, N, d, C, _kind_id(kind), _ptr(ls),
                                           _stream(qc)), "nw_fwd_partial_f32")
     return packed

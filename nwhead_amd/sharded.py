@@ -35,8 +35,9 @@ class ShardedBank:
         self._partial = partial_fn or self._hip_partial
         self._merge = merge_fn or self._hip_merge
         self._ws = None
-        # the shard never changes: cache its squared row norms once (hot loop = matrix cores only)
-        self.norm2 = ops.row_norm2(self.feat) if (partial_fn is None and self.feat.is_cuda) else None
+        # the shard never changes: prepare it once (squared norms + split-fp16 rows, ops.SplitBank)
+        self.cache = ops.SplitBank(self.feat) if (partial_fn is None and self.feat.is_cuda) else None
+        self.norm2 = self.cache.norm2 if self.cache is not None else None
 
     # ---- HIP compute hooks (the product path)
     def _hip_partial(self, packed_row, q):
@@ -46,7 +47,7 @@ class ShardedBank:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=q.device)
         ops.nw_partials_into(packed_row, q, self.feat, self.y, self.C, self.kind, self.logit_scale, ws=self._ws,
-                             sn2=self.norm2)
+                             cache=self.cache)
 
     def _hip_merge(self, gathered_rows, B):
         return ops.nw_merge(gathered_rows, B, self.C)

@@ -252,3 +252,53 @@ def test_cached_support_norms(dev, ops, O):
         close(a, b.cpu().numpy(), rtol=1e-5, atol=2e-5)
     ref = O.nw_head_f64(q[:32].cpu(), s.cpu(), sy.cpu(), C)
     close(ops.nw_head(q, s, sy, C, support_norm2=sn2)[:32], ref.numpy(), rtol=RTOL, atol=3e-5)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_split_fp16_fast_path(dev, ops, O, kind):
+    """'full' inference fast path: bank prepared once (SplitBank: split-fp16 rows + scales + norms), dot
+    products on the fp16 matrix cores.  Same bar as the fp32 path."""
+    q, s, sy, C = _t_inputs(dev, B=96, N=3000)
+    q = q * 3.0 + 0.5
+    cache = ops.SplitBank(s)
+    ls = _ls(dev) if kind == "clip" else None
+    fast = ops.nw_head(q, s, sy, C, kind, ls, support_cache=cache)
+    slow = ops.nw_head(q, s, sy, C, kind, ls)
+    # dot-product scores are unbounded (|score| ~ 340 here, fp32 spacing 3e-5): the bar scales with them
+    smax = O.scores_f64(q.cpu(), s.cpu(), kind, O.CLIP_LOGIT_SCALE_INIT).abs().max().item()
+    atol = max(2e-5, 3e-6 * smax)
+    close(fast, slow.cpu().numpy(), rtol=1e-5, atol=atol)
+    ref = O.nw_head_f64(q[:32].cpu(), s.cpu(), sy.cpu(), C, kind)
+    close(fast[:32], ref.numpy(), rtol=RTOL, atol=max(3e-5, 3e-6 * smax))
+    # the fast path is at least as close to the fp64 truth as the fp32 matrix-core path
+    e_fast = (fast[:32].cpu().double() - ref).abs().max().item()
+    e_slow = (slow[:32].cpu().double() - ref).abs().max().item()
+    assert e_fast <= 2.0 * e_slow + 1e-6, (e_fast, e_slow)
+
+
+def test_split_fp16_dynamic_range(dev, ops, O):
+    """rows whose magnitudes span 1e-4 .. 1e4 (per-row power-of-two scaling keeps fp16 in range)."""
+    g = torch.Generator().manual_seed(3)
+    B, N, d, C = 64, 2048, 128, 16
+    scale_s = (10.0 ** torch.randint(-2, 3, (N, 1), generator=g).float())
+    s = (torch.randn(N, d, generator=g) * scale_s).to(dev)
+    q = (torch.randn(B, d, generator=g) * 10.0 ** torch.randint(-2, 3, (B, 1), generator=g).float()).to(dev)
+    sy = (torch.arange(N) % C).sort().values.to(dev)
+    cache = ops.SplitBank(s)
+    for kind in ("euclidean", "cosine"):
+        fast = ops.nw_head(q, s, sy, C, kind, support_cache=cache)
+        ref = O.nw_head_f64(q.cpu(), s.cpu(), sy.cpu(), C, kind)
+        close(fast, ref.numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_split_rows_format(dev, ops):
+    s = torch.randn(50, 64, device=dev) * 7
+    c = ops.SplitBank(s)
+    halves = c.split.view(torch.float16).view(50, 2, 2, 32).float()       # [row][chunk][h|l][32]
+    rebuilt = (halves[:, :, 0] + halves[:, :, 1]).reshape(50, 64) * c.scale[:, None]
+    # h + l reproduces x to 2^-23 of x, with an absolute floor (fp16 subnormals) far below the row's scale
+    assert torch.allclose(rebuilt, s, rtol=3e-7, atol=3e-7 * s.abs().max().item())
+    assert torch.allclose(c.norm2, (s * s).sum(-1), rtol=1e-6)
+    e = torch.log2(c.scale)
+    assert torch.equal(e, e.round())                                       # exact powers of two
+    assert ops.SplitBank(torch.randn(5, 48, device=dev)).split is None     # d % 32 != 0: norms only

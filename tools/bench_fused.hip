@@ -8,7 +8,7 @@ using namespace nw;
 namespace nw {
 size_t fused_layout(int64_t, int64_t, int, char*, FusedWs*) { return 0; }
 int launch_merge_runs(const FusedWs&, float*, float*, float*, float*, float*, int, int, int, int, hipStream_t) { return 0; }
-int pick_rs(int64_t, int64_t, int64_t) { return 10; }
+int pick_rs(int64_t, int64_t, int64_t, bool) { return 10; }
 }
 int main(int argc, char** argv) {
     const int B = atoi(argv[1]), N = atoi(argv[2]), d = atoi(argv[3]), C = atoi(argv[4]);

@@ -16,7 +16,7 @@ g = torch.Generator().manual_seed(0)
 q = torch.randn(B, d, generator=g).to(dev)
 s = torch.randn(N, d, generator=g).to(dev)
 sy = (torch.arange(N) % C).sort().values.to(dev)
-sn2 = ops.row_norm2(s)
+cache = ops.SplitBank(s)
 for _ in range(iters):
     if what == "scores":
         ops.nw_scores(q, s)
@@ -25,6 +25,6 @@ for _ in range(iters):
     elif what == "fwd_nonorm":
         ops.nw_head(q, s, sy, C)
     else:
-        ops.nw_head(q, s, sy, C, support_norm2=sn2)
+        ops.nw_head(q, s, sy, C, support_cache=cache)
 torch.cuda.synchronize()
 print("done", what, B, N, d, C, iters)
