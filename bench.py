@@ -94,6 +94,26 @@ def measure_shape(B, N, d, C, dev, iters):
             "whole_op_frac_of_roofline": max(alg_bytes(B, N, d, C) / (PEAK_HBM_GBS * 1e9), fl / (PEAK_SPLIT_F16_TFLOPS * 1e12)) / t_fwd}
 
 
+def measure_influence(B, N, C, dev, iters=100):
+    """K5: support_influence over a 10000-image support bank (HBM-bound streaming kernel)."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(5)
+    w = torch.softmax(torch.randn(B, N, generator=g), -1).to(dev)
+    probs = torch.softmax(torch.randn(B, C, generator=g), -1).to(dev)
+    qy = torch.randint(0, C, (B,), generator=g).to(dev)
+    sy = (torch.arange(N) % C).sort().values.to(dev)
+    # call the C ABI directly: at 20 MB the kernel is shorter than the Python wrapper's bookkeeping
+    from nwhead_amd import _lib
+    lib = _lib.load()
+    out = torch.empty(B, N, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    args = (probs.data_ptr(), qy.data_ptr(), w.data_ptr(), sy.data_ptr(), out.data_ptr(), B, N, C, stream)
+    t = time_kernel_events(lambda: lib.nw_support_influence_f32(*args), iters)
+    nbytes = 8 * B * N + 8 * N + 12 * B                      # SURVEY 8d
+    return {"B": B, "N": N, "C": C, "us_per_call": t * 1e6, "alg_GBps": nbytes / t / 1e9,
+            "frac_hbm": nbytes / t / 1e9 / PEAK_HBM_GBS}
+
+
 def cpu_baseline(B_sample, N, d, C, budget_s=20.0):
     """The reference's op sequence (oracle port) on this host's cores, bounded sample."""
     from oracle import nw_oracle as O
@@ -216,6 +236,7 @@ def main():
         if world == 1 and not args.skip_extras:
             line["north_star_T"] = measure_shape(256, 10000, 512, 200, dev, 100)
             line["config_K2_head"] = measure_shape(64, 1000, 512, 200, dev, 100)
+            line["config_K5_support_influence"] = measure_influence(256, 10000, 200, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(32, N, d, C)
     if use_dist:

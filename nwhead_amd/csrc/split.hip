@@ -21,11 +21,30 @@ __global__ __launch_bounds__(256) void nw_split_rows_kernel(const float* __restr
     if (r >= rows) return;
     const float4* src = reinterpret_cast<const float4*>(x + r * d);
     const int64_t n4 = d / 4;
+    // rows up to 64*4*KEEP floats stay in registers: ONE round of loads (the query batch is split
+    // inside every forward call, where this kernel is pure latency)
+    constexpr int KEEP = 8;
+    const bool in_regs = n4 <= 64 * KEEP;
+    float4 keep[KEEP];
     float mx = 0.f, n2 = 0.f;
-    for (int64_t c = lane; c < n4; c += 64) {
-        const float4 v = src[c];
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        n2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            const int64_t c = lane + 64 * u;
+            keep[u] = (c < n4) ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            const float4 v = keep[u];
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            n2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (int64_t c = lane; c < n4; c += 64) {
+            const float4 v = src[c];
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            n2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
     }
     mx = wave_max(mx);
     n2 = wave_sum(n2);
@@ -39,21 +58,29 @@ __global__ __launch_bounds__(256) void nw_split_rows_kernel(const float* __restr
         scale[r] = ldexpf(1.f, -e);
         norm2[r] = n2;
     }
-    // chunk c4 (4 floats) of the row -> halves 4*(c4 % 8) .. +3 of the 32-k chunk c4 / 8
+    // chunk c (4 floats) of the row -> halves 4*(c % 8) .. +3 of the 32-k chunk c / 8
     _Float16* dst = reinterpret_cast<_Float16*>(out + r * d);
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    for (int64_t c = lane; c < n4; c += 64) {
-        const float4 v = src[c];
-        const float s[4] = {v.x * up, v.y * up, v.z * up, v.w * up};
+    auto emit = [&](int64_t c, const float4 v) {
+        const float sv[4] = {v.x * up, v.y * up, v.z * up, v.w * up};
         half4 h, l;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            h[k] = (_Float16)s[k];
-            l[k] = (_Float16)(s[k] - (float)h[k]);
+            h[k] = (_Float16)sv[k];
+            l[k] = (_Float16)(sv[k] - (float)h[k]);
         }
         const int64_t chunk = c >> 3, within = (c & 7) * 4;
         *reinterpret_cast<half4*>(dst + chunk * 64 + within) = h;
         *reinterpret_cast<half4*>(dst + chunk * 64 + 32 + within) = l;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            const int64_t c = lane + 64 * u;
+            if (c < n4) emit(c, keep[u]);
+        }
+    } else {
+        for (int64_t c = lane; c < n4; c += 64) emit(c, src[c]);
     }
 }
 

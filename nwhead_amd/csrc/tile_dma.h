@@ -41,14 +41,19 @@ struct DmaCfg {
     static constexpr int NT = (BQ + BS) / 8;                 // DMA instructions per stage (1 KB each)
     static constexpr int NI = (NT + NLOAD - 1) / NLOAD;      // ... per loader wave (waves lw < NT % NLOAD, or all)
     static constexpr int NI_LO = NT / NLOAD;                 // ... for the other loader waves
-    static constexpr int NBUF = 4;
+#ifndef NW_NBUF
+#define NW_NBUF 4
+#endif
+    static constexpr int NBUF = NW_NBUF;                     // ring depth: NBUF-1 stages in flight
     static constexpr size_t STAGE_BYTES = (size_t)NBUF * TILE_F4 * 16;
     static constexpr int WAVES_PER_SIMD = (RS <= 5) ? 4 : 2; // launch bound: 128 or 256 VGPRs
 };
 constexpr int NBUF_DMA = 4;
+static_assert(NW_NBUF == 4, "ring indexing uses kt & (NBUF-1)");
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
@@ -63,6 +68,12 @@ __device__ __forceinline__ void dma_loader_run(const float* __restrict__ q, cons
     const int nk = d / BK;
     {
         const int lw = wave - NCONS;
+        // leave the K youngest stages of this wave's DMAs in flight
+        auto wait_ahead_impl = [](auto kc, bool lng) {
+            constexpr int K = decltype(kc)::value;
+            if (lng) wait_vmcnt<K * NI>(); else wait_vmcnt<K * NI_LO>();
+        };
+#define wait_ahead_K(K, lng) wait_ahead_impl(std::integral_constant<int, (K)>{}, (lng))
         // instruction n = lw + NLOAD*m covers stage rows 8n .. 8n+7 (Q rows first, then S rows)
         // source = wave-uniform base (q or s, advanced by the stage's k offset) + a per-lane 32-bit
         // byte offset that never changes: no vector arithmetic per DMA.
@@ -89,25 +100,21 @@ __device__ __forceinline__ void dma_loader_run(const float* __restrict__ q, cons
                                                  16, 0, 0);
             }
         };
-        // stage kt+2 has landed once at most this wave's DMAs of stage kt+3 are outstanding
         const bool long_wave = (NI == NI_LO) || (lw < NT % NLOAD);
-        auto wait_next = [&]() {
-            if (long_wave) wait_vmcnt<NI>(); else wait_vmcnt<NI_LO>();
-        };
-        issue(0);
-        if (nk > 1) issue(1);
-        if (nk > 2) {
-            issue(2);
-            wait_next();
-        } else {
-            wait_vmcnt<0>();
-        }
+        // prologue: stages 0 .. NBUF-2 in flight; the consumers start once 0 and 1 have landed
+        constexpr int AHEAD = Cfg::NBUF - 1;
+#pragma unroll
+        for (int k0 = 0; k0 < AHEAD; ++k0)
+            if (k0 < nk) issue(k0);
+        if (nk >= AHEAD) wait_ahead_K(AHEAD - 2, long_wave); else wait_vmcnt<0>();
         tile_barrier();
+        // iteration kt: issue stage kt+AHEAD into the buffer the consumers left at the last barrier,
+        // then wait until stage kt+2 has landed (all but the AHEAD-2 youngest stages of this wave)
         for (int kt = 0; kt < nk; ++kt) {
 #ifndef NW_ABL_NODMA
-            if (kt + 3 < nk) {
-                issue(kt + 3);
-                wait_next();
+            if (kt + AHEAD < nk) {
+                issue(kt + AHEAD);
+                wait_ahead_K(AHEAD - 2, long_wave);
             } else {
                 wait_vmcnt<0>();
             }

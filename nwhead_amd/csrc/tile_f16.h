@@ -75,22 +75,35 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
         };
 
         tile_barrier();  // stages 0 and 1 have landed
-        Frag f0, f1;
-        load_frags(f0, 0);
-        int kt = 0;
-        for (; kt + 1 < nk; kt += 2) {
-            load_frags(f1, (kt + 1) & (Cfg::NBUF - 1));
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_stage(f0);
-            tile_barrier();
-            if (kt + 2 < nk) load_frags(f0, (kt + 2) & (Cfg::NBUF - 1));
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_stage(f1);
-            tile_barrier();
-        }
-        if (kt < nk) {
-            mfma_stage(f0);
-            tile_barrier();
+        if (RS > 5) {
+            // one workgroup per CU: fragments double-buffered in registers (the reads of stage kt+1
+            // fly under the MFMAs of stage kt)
+            Frag f0, f1;
+            load_frags(f0, 0);
+            int kt = 0;
+            for (; kt + 1 < nk; kt += 2) {
+                load_frags(f1, (kt + 1) & (Cfg::NBUF - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_stage(f0);
+                tile_barrier();
+                if (kt + 2 < nk) load_frags(f0, (kt + 2) & (Cfg::NBUF - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_stage(f1);
+                tile_barrier();
+            }
+            if (kt < nk) {
+                mfma_stage(f0);
+                tile_barrier();
+            }
+        } else {
+            // two workgroups per CU (128 VGPRs): one fragment set; the other three waves of the SIMD
+            // cover the LDS latency
+            Frag f;
+            for (int kt = 0; kt < nk; ++kt) {
+                load_frags(f, kt & (Cfg::NBUF - 1));
+                mfma_stage(f);
+                tile_barrier();
+            }
         }
     }
 }

@@ -27,6 +27,8 @@ def _need_hip(*ts):
 
 
 def _f32c(t):
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t.detach() if t.requires_grad else t
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -39,8 +41,20 @@ def _kind_id(kind):
         raise NotImplementedError(kind)
 
 
+_WS_CACHE = {}
+
+
 def _workspace(nbytes, device):
-    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+    """Scratch for one call.  Cached per (device, stream) and only ever grown: work on one stream is
+    ordered, so the next call may reuse it; another stream gets its own."""
+    nbytes = max(int(nbytes), 1)
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WS_CACHE[key] = ws
+    return ws
 
 
 def nw_scores(q, s, kind="euclidean", logit_scale=None):
@@ -94,6 +108,15 @@ class SplitBank:
             self.norm2 = row_norm2(sc)
 
 
+class _NoCtx:
+    """Stand-in for the autograd context on the inference path."""
+    needs_input_grad = (False, False, False, False)
+
+    @staticmethod
+    def mark_non_differentiable(*a):
+        pass
+
+
 class _NWHeadFn(torch.autograd.Function):
     """autograd node for NWHead.forward (nwhead/nw.py:266-289)."""
 
@@ -105,7 +128,7 @@ class _NWHeadFn(torch.autograd.Function):
             sn2, ssplit, sscale = cache.norm2, cache.split, cache.scale
         lib = _lib.load()
         qc, sc = _f32c(q), _f32c(s)
-        syc = sy.detach().to(torch.int64).contiguous()
+        syc = sy if (sy.dtype == torch.int64 and sy.is_contiguous()) else sy.detach().to(torch.int64).contiguous()
         B, d = qc.shape
         sup_b = sc.dim() == 3
         lab_b = syc.dim() == 2
@@ -168,6 +191,11 @@ def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weig
         support_norm2 = _f32c(support_norm2)
     if support_cache is not None and (s.dim() != 2 or tuple(s.shape) != support_cache.shape):
         raise ValueError("support_cache was built for a different support")
+    needs_grad = torch.is_grad_enabled() and (q.requires_grad or s.requires_grad or
+                                              (logit_scale is not None and logit_scale.requires_grad))
+    if not needs_grad:   # inference: skip the autograd node (its bookkeeping costs more than the kernels at small sizes)
+        return _NWHeadFn.forward(_NoCtx, q, s, sy, logit_scale, int(n_classes), kid, bool(return_weights),
+                                 support_norm2, support_cache)
     return _NWHeadFn.apply(q, s, sy, logit_scale, int(n_classes), kid, bool(return_weights), support_norm2,
                            support_cache)
 

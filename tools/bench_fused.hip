@@ -9,6 +9,7 @@ namespace nw {
 size_t fused_layout(int64_t, int64_t, int, char*, FusedWs*) { return 0; }
 int launch_merge_runs(const FusedWs&, float*, float*, float*, float*, float*, int, int, int, int, hipStream_t) { return 0; }
 int pick_rs(int64_t, int64_t, int64_t, bool) { return 10; }
+int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d, hipStream_t st);
 }
 int main(int argc, char** argv) {
     const int B = atoi(argv[1]), N = atoi(argv[2]), d = atoi(argv[3]), C = atoi(argv[4]);
@@ -20,17 +21,27 @@ int main(int argc, char** argv) {
     std::vector<int64_t> hy(N);
     for (int j = 0; j < N; ++j) hy[j] = (int64_t)j * C / N;
     const int n_stiles = (N + BS - 1) / BS, n_qtiles = (B + 63) / 64;
-    float *q, *s, *sn, *m, *den, *num; int64_t* sy; int *nrun, *lab; unsigned long long* dbg;
+    const bool f16 = argc > 5 && atoi(argv[5]) == 1;
+    float *q, *s, *sn, *m, *den, *num, *qsp, *ssp, *qsc, *ssc, *qn; int64_t* sy; int *nrun, *lab; unsigned long long* dbg;
+    hipMalloc(&qsp, hq.size() * 4); hipMalloc(&ssp, hs.size() * 4); hipMalloc(&qsc, B * 4); hipMalloc(&ssc, N * 4); hipMalloc(&qn, B * 4);
     hipMalloc(&q, hq.size() * 4); hipMalloc(&s, hs.size() * 4); hipMalloc(&sn, N * 4); hipMalloc(&sy, N * 8);
     hipMalloc(&m, (size_t)n_stiles * B * 4); hipMalloc(&den, (size_t)n_stiles * B * 4); hipMalloc(&nrun, n_stiles * 4);
     hipMalloc(&lab, (size_t)n_stiles * BS * 4); hipMalloc(&num, (size_t)n_stiles * BS * B * 4); hipMalloc(&dbg, 1 << 22);
     hipMemcpy(q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice); hipMemcpy(s, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(sy, hy.data(), N * 8, hipMemcpyHostToDevice); hipMemset(sn, 0, N * 4);
+    launch_split_rows(q, qsp, qsc, qn, B, d, 0); launch_split_rows(s, ssp, ssc, sn, N, d, 0);
     const int grid = padded_grid(n_stiles, n_qtiles);
     const size_t lds = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&] { hipLaunchKernelGGL((nw_fused_kernel<RS, 0, false, MODE_DMA_SN>), dim3(grid), dim3(TILE_THREADS), lds, 0, q, s, sy, sn,
-                        (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles); };
+    auto launch = [&] {
+        if (f16)
+            hipLaunchKernelGGL((nw_fused_kernel<RS, 0, false, MODE_F16>), dim3(grid), dim3(TILE_THREADS), lds, 0, qsp, ssp, sy, sn, ssc, qn, qsc,
+                               (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles);
+        else
+            hipLaunchKernelGGL((nw_fused_kernel<RS, 0, false, MODE_DMA_SN>), dim3(grid), dim3(TILE_THREADS), lds, 0, q, s, sy, sn, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C,
+                               n_stiles, n_qtiles);
+    };
     for (int i = 0; i < 5; ++i) launch();
     hipEventRecord(e0); for (int i = 0; i < 100; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
