@@ -123,6 +123,10 @@ int nw_fwd_f32(const float *q, const float *s, const int64_t *sy, const float *s
  *   Shard g's arrays start at m + g*stride_m, den + g*stride_den, num + g*stride_num (strides in
  *   floats; pass B, B, B*C for dense (G,B) (G,B) (G,B,C) stacks, or the common row length when the
  *   three sections of each shard are packed in one all-gathered buffer).
+ *   class_lo (device, (G,)) / C_local: optional class windows.  A contiguous slice of a class-sorted
+ *   bank only holds the classes [class_lo[g], class_lo[g] + C_local); its partial forward is then run
+ *   with labels shifted by class_lo[g] and C = C_local, num is (B, C_local) per shard, and the rows
+ *   that cross xGMI shrink ~G-fold.  NULL = every shard carries all C classes.
  * ------------------------------------------------------------------------------------------- */
 int nw_fwd_partial_f32(const float *q, const float *s, const int64_t *sy, const float *s_norm2,
                        const float *s_split, const float *s_scale,
@@ -132,7 +136,8 @@ int nw_fwd_partial_f32(const float *q, const float *s, const int64_t *sy, const 
                        int kind, const float *logit_scale_dev, void *stream);
 int nw_merge_finalize_f32(const float *m, const float *den, const float *num, float *out,
                           int64_t G, int64_t B, int64_t C,
-                          int64_t stride_m, int64_t stride_den, int64_t stride_num, void *stream);
+                          int64_t stride_m, int64_t stride_den, int64_t stride_num,
+                          const int64_t *class_lo, int64_t C_local, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward.  Replaces the autograd graph the reference builds through nwhead/nw.py:276-289 and

@@ -30,7 +30,7 @@ SIGNATURES = {
     "nw_split_rows_f16x2": (_int, [_p, _p, _p, _p, _i64, _i64, _p]),
     "nw_fwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
     "nw_fwd_partial_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _p]),
-    "nw_merge_finalize_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "nw_merge_finalize_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     "nw_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int]),
     "nw_bwd_f32": (_int, [_p] * 10 + [_p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
     "nw_support_influence_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),

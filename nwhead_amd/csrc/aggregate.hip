@@ -82,12 +82,16 @@ __global__ void nw_fill_kernel(float* __restrict__ p, float v, int64_t n) {
 }
 
 // out[b,c] = log( sum_g num[g,b,c] e^(m_g - M) / sum_g den[g,b] e^(m_g - M) + 1e-12 )
+// With class_lo != nullptr shard g only carries the CL classes [class_lo[g], class_lo[g] + CL) (a slice
+// of a class-sorted bank holds ~C/G classes: the exchanged rows shrink G-fold) and num is (B, CL).
 __global__ __launch_bounds__(256) void nw_merge_kernel(const float* __restrict__ m,
                                                         const float* __restrict__ den,
                                                         const float* __restrict__ num,
                                                         float* __restrict__ out, int64_t G,
                                                         int64_t B, int64_t C, int64_t sm,
-                                                        int64_t sd, int64_t sn) {
+                                                        int64_t sd, int64_t sn,
+                                                        const int64_t* __restrict__ class_lo,
+                                                        int64_t CL) {
     const int64_t b = blockIdx.x;
     float M = -INFINITY;
     for (int64_t g = 0; g < G; ++g) M = fmaxf(M, m[g * sm + b]);
@@ -101,7 +105,13 @@ __global__ __launch_bounds__(256) void nw_merge_kernel(const float* __restrict__
         float a = 0.f;
         for (int64_t g = 0; g < G; ++g) {
             const float mg = m[g * sm + b];
-            if (mg > -INFINITY) a += num[g * sn + b * C + c] * expf(mg - M);
+            if (!(mg > -INFINITY)) continue;
+            if (class_lo) {
+                const int64_t j = c - class_lo[g];
+                if (j >= 0 && j < CL) a += num[g * sn + b * CL + j] * expf(mg - M);
+            } else {
+                a += num[g * sn + b * C + c] * expf(mg - M);
+            }
         }
         out[b * C + c] = logf(a * inv + NW_LOG_EPS);
     }
@@ -142,10 +152,11 @@ int launch_aggregate(const float* scores, const int64_t* sy, int labels_batched,
 }
 
 int launch_merge(const float* m, const float* den, const float* num, float* out, int64_t G,
-                 int64_t B, int64_t C, int64_t sm, int64_t sd, int64_t sn, hipStream_t st) {
+                 int64_t B, int64_t C, int64_t sm, int64_t sd, int64_t sn, const int64_t* class_lo,
+                 int64_t CL, hipStream_t st) {
     if (B <= 0 || C <= 0) return NW_OK;
     if (B > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(nw_merge_kernel, dim3((unsigned)B), dim3(256), 0, st, m, den, num, out, G, B, C, sm, sd, sn);
+    hipLaunchKernelGGL(nw_merge_kernel, dim3((unsigned)B), dim3(256), 0, st, m, den, num, out, G, B, C, sm, sd, sn, class_lo, CL);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

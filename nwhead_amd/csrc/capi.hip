@@ -153,10 +153,12 @@ extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t*
 
 extern "C" int nw_merge_finalize_f32(const float* m, const float* den, const float* num, float* out,
                                      int64_t G, int64_t B, int64_t C, int64_t stride_m,
-                                     int64_t stride_den, int64_t stride_num, void* stream) {
+                                     int64_t stride_den, int64_t stride_num,
+                                     const int64_t* class_lo, int64_t C_local, void* stream) {
     if (G < 0 || B < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (B == 0 || C == 0) return NW_OK;
     if (!m || !den || !num || !out) return NW_ERR_INVALID_ARG;
-    return nw::launch_merge(m, den, num, out, G, B, C, stride_m, stride_den, stride_num,
-                            static_cast<hipStream_t>(stream));
+    if (class_lo && C_local <= 0) return NW_ERR_INVALID_ARG;
+    return nw::launch_merge(m, den, num, out, G, B, C, stride_m, stride_den, stride_num, class_lo,
+                            class_lo ? C_local : C, static_cast<hipStream_t>(stream));
 }

@@ -26,7 +26,8 @@ int launch_aggregate(const float* scores, const int64_t* sy, int labels_batched,
                      int64_t N, int64_t C, hipStream_t st);
 
 int launch_merge(const float* m, const float* den, const float* num, float* out, int64_t G,
-                 int64_t B, int64_t C, int64_t sm, int64_t sd, int64_t sn, hipStream_t st);
+                 int64_t B, int64_t C, int64_t sm, int64_t sd, int64_t sn, const int64_t* class_lo,
+                 int64_t CL, hipStream_t st);
 
 // squared row norms of a (rows,d) matrix (backward.hip)
 int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStream_t st);

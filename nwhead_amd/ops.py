@@ -238,22 +238,24 @@ def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_sca
     return packed
 
 
-def nw_merge(packed_all, B, n_classes, out=None):
-    """packed_all: (G, L>=2B+B*C) all-gathered partial buffers, each row [m | den | num] -> (B,C)
-    log-probs.  The merge kernel reads the three sections in place through shard strides."""
-    _need_hip(packed_all)
+def nw_merge(packed_all, B, n_classes, out=None, class_lo=None, c_local=None):
+    """packed_all: (G, L) all-gathered partial buffers, each row [m (B) | den (B) | num (B*CL)] -> (B,C)
+    log-probs.  CL = n_classes, or ``c_local`` when every shard only carries the class window
+    [class_lo[g], class_lo[g] + c_local).  The merge kernel reads the sections in place."""
+    _need_hip(packed_all, class_lo)
     lib = _lib.load()
     assert packed_all.dim() == 2 and packed_all.is_contiguous() and packed_all.dtype == torch.float32
     G, L = packed_all.shape
     C = int(n_classes)
-    assert L >= 2 * B + B * C
+    CL = C if class_lo is None else int(c_local)
+    assert L >= 2 * B + B * CL
     dev = packed_all.device
     if out is None:
         out = torch.empty(B, C, dtype=torch.float32, device=dev)
     base = packed_all.data_ptr()
     with torch.cuda.device(dev):
         _lib.check(lib.nw_merge_finalize_f32(base, base + 4 * B, base + 8 * B, _ptr(out), G, B, C, L, L, L,
-                                             _stream(packed_all)), "nw_merge_finalize_f32")
+                                             _ptr(class_lo), CL, _stream(packed_all)), "nw_merge_finalize_f32")
     return out
 
 

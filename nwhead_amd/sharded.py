@@ -35,6 +35,21 @@ class ShardedBank:
         self._partial = partial_fn or self._hip_partial
         self._merge = merge_fn or self._hip_merge
         self._ws = None
+        # Class windows: a contiguous slice of a class-sorted bank holds only ~C/G classes, so its
+        # partial forward runs on labels shifted by the slice's lowest class with CL = widest window
+        # over the ranks; the exchanged rows are (2 + CL) instead of (2 + C) floats per query.
+        self.class_lo, self.CL, self.y_local = None, self.C, self.y
+        if self.world > 1:
+            lo = int(self.y.min()) if self.y.numel() else 0
+            hi = int(self.y.max()) if self.y.numel() else -1
+            box = torch.tensor([lo, hi], dtype=torch.int64, device=self.feat.device)
+            allb = torch.empty(self.world, 2, dtype=torch.int64, device=self.feat.device)
+            dist.all_gather_into_tensor(allb.view(-1), box, group=group)
+            width = int((allb[:, 1] - allb[:, 0] + 1).clamp_min(1).max())
+            if width < self.C:
+                self.CL = width
+                self.class_lo = allb[:, 0].clamp(0, max(self.C - 1, 0)).contiguous()
+                self.y_local = (self.y - lo).contiguous()
         # the shard never changes: prepare it once (squared norms + split-fp16 rows, ops.SplitBank)
         self.cache = ops.SplitBank(self.feat) if (partial_fn is None and self.feat.is_cuda) else None
         self.norm2 = self.cache.norm2 if self.cache is not None else None
@@ -43,17 +58,17 @@ class ShardedBank:
     def _hip_partial(self, packed_row, q):
         N, d = self.feat.shape
         B = q.shape[0]
-        need = ops._lib.load().nw_fwd_workspace_bytes(B, N, d, self.C)
+        need = ops._lib.load().nw_fwd_workspace_bytes(B, N, d, self.CL)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=q.device)
-        ops.nw_partials_into(packed_row, q, self.feat, self.y, self.C, self.kind, self.logit_scale, ws=self._ws,
-                             cache=self.cache)
+        ops.nw_partials_into(packed_row, q, self.feat, self.y_local, self.CL, self.kind, self.logit_scale,
+                             ws=self._ws, cache=self.cache)
 
     def _hip_merge(self, gathered_rows, B):
-        return ops.nw_merge(gathered_rows, B, self.C)
+        return ops.nw_merge(gathered_rows, B, self.C, class_lo=self.class_lo, c_local=self.CL)
 
     def row_len(self, B):
-        return 2 * B + B * self.C
+        return 2 * B + B * self.CL
 
     def predict(self, q):
         """One query batch: (B,d) -> (B,C) log-probabilities, identical on every rank."""
@@ -92,6 +107,11 @@ class ShardedBank:
                              torch.empty(G, L, dtype=torch.float32, device=dev))
             packed, gathered = ring[key]
             qcat = chunk[0] if nb == 1 else torch.cat(chunk, dim=0)
+            if G == 1 and self._partial == self._hip_partial:
+                # one rank: nothing to exchange, the forward finalises in place
+                out = ops.nw_head(qcat, self.feat, self.y, self.C, self.kind, self.logit_scale, support_cache=self.cache)
+                outs.extend(out[k * B:(k + 1) * B] for k in range(nb))
+                continue
             self._partial(packed, qcat.detach().to(torch.float32).contiguous())
             if G > 1:
                 work = dist.all_gather_into_tensor(gathered.view(-1), packed, group=self.group, async_op=True)
@@ -100,5 +120,6 @@ class ShardedBank:
             if pending is not None:
                 finish(pending)
             pending = (work, gathered, nb)
-        finish(pending)
+        if pending is not None:
+            finish(pending)
         return outs

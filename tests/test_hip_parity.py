@@ -302,3 +302,17 @@ def test_split_rows_format(dev, ops):
     e = torch.log2(c.scale)
     assert torch.equal(e, e.round())                                       # exact powers of two
     assert ops.SplitBank(torch.randn(5, 48, device=dev)).split is None     # d % 32 != 0: norms only
+
+
+def test_class_window_merge(dev, ops):
+    """Sharded exchange with class windows: shard g carries only [class_lo[g], class_lo[g] + CL) (labels
+    shifted, C = CL in its partial forward); nw_merge_finalize scatters the windows back."""
+    q, s, sy, C = _t_inputs(dev, B=64, N=4000)
+    G, B, N = 8, q.shape[0], s.shape[0]
+    bounds = [(i * N // G, (i + 1) * N // G) for i in range(G)]
+    los = [int(sy[a:b].min()) for a, b in bounds]
+    CL = max(int(sy[a:b].max()) - lo + 1 for (a, b), lo in zip(bounds, los))
+    assert CL < C
+    rows = torch.stack([ops.nw_partials(q, s[a:b], sy[a:b] - lo, CL).view(-1) for (a, b), lo in zip(bounds, los)])
+    out = ops.nw_merge(rows, B, C, class_lo=torch.tensor(los, dtype=torch.int64, device=dev), c_local=CL)
+    close(out, ops.nw_head(q, s, sy, C).cpu().numpy(), rtol=1e-5, atol=2e-5)

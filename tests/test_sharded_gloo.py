@@ -33,17 +33,24 @@ def _worker(rank, world, port, q):
         lo, hi = shard_bounds(N, world, rank)
 
         def partial_fn(row, qb):                      # oracle stands in for nw_fwd_partial_f32
-            m, den, num = O.nw_partials_f64(qb, s[lo:hi], sy[lo:hi], C)
+            # (labels shifted into this rank's class window, CL classes: what the product path passes)
+            m, den, num = O.nw_partials_f64(qb, s[lo:hi], bank.y_local, bank.CL)
             nq = qb.shape[0]                          # a bucket of batches arrives coalesced
             row[:nq] = m.float()
             row[nq:2 * nq] = den.float()
             row[2 * nq:] = num.float().reshape(-1)
 
         def merge_fn(rows, Bq):                       # oracle stands in for nw_merge_finalize_f32
-            G = rows.shape[0]
+            G, CL = rows.shape[0], bank.CL
             ms = [rows[k, :Bq].double() for k in range(G)]
             dens = [rows[k, Bq:2 * Bq].double() for k in range(G)]
-            nums = [rows[k, 2 * Bq:2 * Bq + Bq * C].double().reshape(Bq, C) for k in range(G)]
+            nums = []
+            for k in range(G):                        # scatter every shard's window back to C classes
+                full = torch.zeros(Bq, C, dtype=torch.float64)
+                lo_k = int(bank.class_lo[k]) if bank.class_lo is not None else 0
+                win = rows[k, 2 * Bq:2 * Bq + Bq * CL].double().reshape(Bq, CL)
+                full[:, lo_k:lo_k + CL] = win[:, :C - lo_k]
+                nums.append(full)
             return O.nw_merge_f64(ms, dens, nums).float()
 
         bank = ShardedBank(s[lo:hi], sy[lo:hi], C, partial_fn=partial_fn, merge_fn=merge_fn)
@@ -52,6 +59,7 @@ def _worker(rank, world, port, q):
         ref = [O.nw_head_f64(qb, s, sy, C).float() for qb in batches]
         err = max((o - r).abs().max().item() for o, r in zip(outs, ref))
         err = max(err, (one - ref[0]).abs().max().item())
+        assert bank.CL < C and bank.class_lo is not None      # 2 ranks x 5 sorted classes: windows of 3
         q.put((rank, len(outs), err))
     finally:
         dist.destroy_process_group()
