@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--bank", type=int, default=50000)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--classes", type=int, default=200)
-    ap.add_argument("--bucket", type=int, default=8, help="query batches per RCCL all-gather")
+    ap.add_argument("--bucket", type=int, default=16, help="query batches coalesced per launch (and per RCCL all-gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="only the timed workload (for profiling)")
     args = ap.parse_args()

@@ -29,6 +29,20 @@ NW_EXTERN_FUSED_KIND(NW_SCORE_DOT)
 NW_EXTERN_FUSED_KIND(NW_SCORE_CLIP)
 #undef NW_EXTERN_FUSED_KIND
 
+int device_cu_count() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
+}
+bool env_flag(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] == '1';
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws) {
@@ -130,6 +144,8 @@ int pick_rs(int64_t B, int64_t N, int64_t d, bool f16) {
     // (the split-fp16 path is bound by the L2->LDS stream, not by the matrix pipe: the larger tile,
     //  which moves fewer bytes per flop, wins there: 470 vs 509 us at B=2048 N=50000)
     if (forced == 0 && !f16 && d % BK == 0 && nq * ((N + 79) / 80) >= 480) return 5;
+    // split-fp16 with >= 4 tiles per CU: the persistent kernel (fused_f16p.h) at its no-spill height
+    if (forced == 0 && f16 && d % BK == 0 && nq * ((N + 127) / 128) >= 4 * 256) return 8;
     const int cand[] = {2, 4, 6, 8, 10, 12};  // even: the four loader waves split a tile evenly
     const int ncand = f16 ? 5 : 6;           // split-fp16: 12 blocks of fragments do not fit 256 VGPRs
     double best = 1e30;

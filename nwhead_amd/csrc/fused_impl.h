@@ -20,6 +20,8 @@ struct FusedWs {  // views into the caller's workspace
 size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws);
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st);
+int device_cu_count();
+bool env_flag(const char* name);
 
 namespace {
 
@@ -30,108 +32,58 @@ namespace {
 //            SPLIT rows, norms and row scales of both are supplied
 enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2, MODE_F16 = 3 };
 
-template <int RS, int KIND, bool WRITE_SCORES, int MODE>
-__global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kernel(
-    const float* __restrict__ q, const float* __restrict__ s, const int64_t* __restrict__ sy,
-    const float* __restrict__ s_norm2, const float* __restrict__ s_scale, const float* __restrict__ q_norm2,
-    const float* __restrict__ q_scale, const float* __restrict__ logit_scale,
-    float* __restrict__ scores, float* __restrict__ ws_m,
-    float* __restrict__ ws_den, int* __restrict__ ws_nrun, int* __restrict__ ws_lab,
-    float* __restrict__ ws_num, int B, int N, int d, int C, int n_stiles, int n_qtiles) {
-    using Cfg = TileCfg<RS>;
-    constexpr int BS = Cfg::BS;
-    constexpr bool NEED_NORM = (KIND != NW_SCORE_DOT);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // header: qn2[64] | sn2[RUN_CAP] | ssc[RUN_CAP] | runid[RUN_CAP] | runlab[RUN_CAP] | nrun ; then the ring
-    float* qn2 = reinterpret_cast<float*>(smem);
-    float* sn2 = qn2 + 64;
-    float* ssc = sn2 + RUN_CAP;   // MODE_F16: per-support row scale 2^-e
-    int* runid = reinterpret_cast<int*>(ssc + RUN_CAP);
-    int* runlab = runid + RUN_CAP;
-    int* nrun_s = runlab + RUN_CAP;
-    constexpr int HDR = (64 + 4 * RUN_CAP + 4) * 4;
-    static_assert(HDR % 16 == 0, "stage buffers must stay 16-byte aligned");
-    float4* stage = reinterpret_cast<float4*>(smem + HDR);
+// Runs of equal consecutive labels inside one support tile, by ONE wave (3 rows per lane): fills
+// runid[t] (run of tile row t), runlab[run] (its class, -1 = padding / out-of-range label) and *nrun.
+// `lab` = this lane's three labels (tile rows 3*lane .. 3*lane+2), already mapped to -1 when invalid.
+template <int BS>
+__device__ __forceinline__ void run_scan_wave(const int (&lab)[3], int lane, int* runid, int* runlab, int* nrun_s) {
+    int flag[3];
+    const int prev_last = __shfl_up(lab[2], 1);
+    flag[0] = (lane == 0) || (lab[0] != prev_last);
+    flag[1] = lab[1] != lab[0];
+    flag[2] = lab[2] != lab[1];
+    int incl = flag[0] + flag[1] + flag[2];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    int id = incl - (flag[0] + flag[1] + flag[2]) - 1;  // run id before this lane's rows
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = 3 * lane + u;
+        id += flag[u];
+        if (t < BS) {
+            runid[t] = id;
+            if (flag[u]) runlab[id] = lab[u];
+            if (t == BS - 1) *nrun_s = id + 1;
+        }
+    }
+}
+template <int BS>
+__device__ __forceinline__ void load_tile_labels(const int64_t* __restrict__ sy, int s0, int N, int C, int lane, int (&lab)[3]) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = 3 * lane + u, j = s0 + t;
+        int64_t y = -1;
+        if (t < BS && j < N) y = sy[j];
+        lab[u] = ((uint64_t)y < (uint64_t)C) ? (int)y : -1;
+    }
+}
 
-    int qt, st;
-    if (!decode_block(n_stiles, n_qtiles, qt, st)) return;
-    const int q0 = qt * BQ, s0 = st * BS;
+// The epilogue of one tile: scores -> tile-local softmax statistics -> run sums -> workspace.
+// Called by all threads of the workgroup (loader waves only take part in the run-table copy).
+template <int RS, int KIND, bool WRITE_SCORES, int MODE>
+__device__ __forceinline__ void fused_epilogue(
+    f32x4 (&acc)[RS], const float* qn2, const float* sn2, const float* ssc, const int* runid,
+    const int* runlab, const int* nrun_s, const float* qsc_s,
+    const float* __restrict__ logit_scale, float* __restrict__ scores, float* __restrict__ ws_m,
+    float* __restrict__ ws_den, int* __restrict__ ws_nrun, int* __restrict__ ws_lab,
+    float* __restrict__ ws_num, int B, int N, int q0, int s0, int qt, int st) {
+    constexpr int BS = 16 * RS;
+    constexpr bool NEED_NORM = (KIND != NW_SCORE_DOT);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 15, g = lane >> 4;
-#ifdef NW_DIAG_FUSED   // diagnostic build only (tools/bench_fused.hip): phase stamps go to `scores`
-#define NW_FSTAMP(k) if (tid == 0) reinterpret_cast<unsigned long long*>(scores)[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime()
-#else
-#define NW_FSTAMP(k)
-#endif
-    NW_FSTAMP(0);
-
-    // cached support norms: fetched now, long before the epilogue needs them (the DMA loop never
-    // touches sn2 in this mode)
-    if ((MODE == MODE_DMA_SN || MODE == MODE_F16) && NEED_NORM) {
-        for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
-    }
-    if (MODE == MODE_F16) {
-        for (int t = tid; t < BS; t += TILE_THREADS) ssc[t] = s_scale[min(s0 + t, N - 1)];
-        if (NEED_NORM)
-            for (int t = tid; t < BQ; t += TILE_THREADS) qn2[t] = q_norm2[min(q0 + t, B - 1)];
-    }
-    // ---- runs of equal consecutive labels inside this support tile (one wave, 3 rows per lane)
-    if (wave == 0) {
-        int lab[3], flag[3];
-        int prev_last = 0;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int t = 3 * lane + u, j = s0 + t;
-            int64_t y = -1;
-            if (t < BS && j < N) y = sy[j];
-            lab[u] = ((uint64_t)y < (uint64_t)C) ? (int)y : -1;
-        }
-        prev_last = __shfl_up(lab[2], 1);
-        flag[0] = (lane == 0) || (lab[0] != prev_last);
-        flag[1] = lab[1] != lab[0];
-        flag[2] = lab[2] != lab[1];
-        int incl = flag[0] + flag[1] + flag[2];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        int id = incl - (flag[0] + flag[1] + flag[2]) - 1;  // run id before this lane's rows
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int t = 3 * lane + u;
-            id += flag[u];
-            if (t < BS) {
-                runid[t] = id;
-                if (flag[u]) runlab[id] = lab[u];
-                if (t == BS - 1) *nrun_s = id + 1;
-            }
-        }
-    }
-
-    NW_FSTAMP(1);
-    // the K walk of every support tile starts at a different chunk (see tile_core.h: spreads the
-    // simultaneous requests of all workgroups over the memory channels); the workgroups that share
-    // a support tile keep the same order so that they still hit each other's lines in L2
-    const int nk = (d + BK - 1) / BK;
-    const int rot = st % nk;
-    f32x4 acc[RS];
-    if (MODE == MODE_F16) {
-        tile_dots_f16x2<RS>(q, s, B, N, d, q0, s0, stage, acc, rot);
-        __syncthreads();  // header tables written at kernel start are visible; the ring is dead
-    } else if (MODE == MODE_REG) {
-        tile_dots<RS, NEED_NORM>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
-    } else {
-        tile_dots_dma<RS, NEED_NORM, NEED_NORM && MODE == MODE_DMA>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
-    }
-    // (both end behind a barrier: the run tables above and the norms are visible, and the stage
-    //  buffers are dead from here on)
-    if (MODE != MODE_DMA_SN && MODE != MODE_F16 && NEED_NORM && s_norm2 != nullptr) {  // cached norms win over computed ones
-        for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
-        __syncthreads();
-    }
-
-    NW_FSTAMP(2);
     const bool consumer = wave < NCONS;  // waves 4-7 (loaders) hold no accumulators
     // The softmax part works in BASE-2 units u = score * log2(e): e^(s-m) = 2^(u-mu) is then one
     // subtract and one v_exp_f32, and for the Euclidean kernel the constant is folded into the
@@ -144,7 +96,7 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
     const int qrow = 16 * (wave & 3) + i;
     const int b = q0 + qrow;
     const float qn = NEED_NORM ? qn2[qrow] : 0.f;
-    const float qsc = (MODE == MODE_F16) ? q_scale[min(b, B - 1)] : 1.f;  // 2^-e of this lane's query row
+    const float qsc = (MODE == MODE_F16) ? qsc_s[qrow] : 1.f;  // 2^-e of this lane's query row (LDS header)
     const bool partial_tile = s0 + BS > N;  // only the last support tile has rows past the bank
 
     float sc[RS][4];
@@ -201,7 +153,6 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     }
 
-    NW_FSTAMP(3);
     // ---- 2^(u - mu) and its sums over the runs of equal labels, on the matrix cores:
     //   P[run][query] = sum_t [runid_t == run] * E[t][query]
     // E is already laid out as an MFMA B operand (lane (i,g) holds E[16r+4g+e][query i]: for fixed
@@ -219,7 +170,6 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
             }
         dloc += __shfl_xor(dloc, 16);
         dloc += __shfl_xor(dloc, 32);
-        NW_FSTAMP(4);
         const int nrun = *nrun_s;
         if (nrun == 1) {  // the whole tile is one class: its run sum is the denominator
             if (g == 0 && b < B) ws_num[((size_t)st * BS) * B + b] = dloc;
@@ -244,7 +194,6 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
                 }
             }
         }
-        NW_FSTAMP(5);
         if (g == 0 && b < B) {
             ws_m[(size_t)st * B + b] = mloc;
             ws_den[(size_t)st * B + b] = dloc;
@@ -255,11 +204,99 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
         if (tid == 0) ws_nrun[st] = nrun;
         for (int x = tid; x < nrun; x += TILE_THREADS) ws_lab[(size_t)st * BS + x] = runlab[x];
     }
+}
+
+
+template <int RS, int KIND, bool WRITE_SCORES, int MODE>
+__global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kernel(
+    const float* __restrict__ q, const float* __restrict__ s, const int64_t* __restrict__ sy,
+    const float* __restrict__ s_norm2, const float* __restrict__ s_scale, const float* __restrict__ q_norm2,
+    const float* __restrict__ q_scale, const float* __restrict__ logit_scale,
+    float* __restrict__ scores, float* __restrict__ ws_m,
+    float* __restrict__ ws_den, int* __restrict__ ws_nrun, int* __restrict__ ws_lab,
+    float* __restrict__ ws_num, int B, int N, int d, int C, int n_stiles, int n_qtiles) {
+    using Cfg = TileCfg<RS>;
+    constexpr int BS = Cfg::BS;
+    constexpr bool NEED_NORM = (KIND != NW_SCORE_DOT);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // header: qn2[64] | qsc[64] | sn2[RUN_CAP] | ssc[RUN_CAP] | runid[RUN_CAP] | runlab[RUN_CAP] | nrun ; then the ring
+    float* qn2 = reinterpret_cast<float*>(smem);
+    float* qsc_s = qn2 + 64;      // MODE_F16: per-query row scale 2^-e
+    float* sn2 = qsc_s + 64;
+    float* ssc = sn2 + RUN_CAP;   // MODE_F16: per-support row scale 2^-e
+    int* runid = reinterpret_cast<int*>(ssc + RUN_CAP);
+    int* runlab = runid + RUN_CAP;
+    int* nrun_s = runlab + RUN_CAP;
+    constexpr int HDR = (128 + 4 * RUN_CAP + 4) * 4;
+    static_assert(HDR % 16 == 0, "stage buffers must stay 16-byte aligned");
+    float4* stage = reinterpret_cast<float4*>(smem + HDR);
+
+    int qt, st;
+    if (!decode_block(n_stiles, n_qtiles, qt, st)) return;
+    const int q0 = qt * BQ, s0 = st * BS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, g = lane >> 4;
+#ifdef NW_DIAG_FUSED   // diagnostic build only (tools/bench_fused.hip): phase stamps go to `scores`
+#define NW_FSTAMP(k) if (tid == 0) reinterpret_cast<unsigned long long*>(scores)[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime()
+#else
+#define NW_FSTAMP(k)
+#endif
+    NW_FSTAMP(0);
+
+    // cached support norms: fetched now, long before the epilogue needs them (the DMA loop never
+    // touches sn2 in this mode)
+    if ((MODE == MODE_DMA_SN || MODE == MODE_F16) && NEED_NORM) {
+        for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
+    }
+    if (MODE == MODE_F16) {
+        for (int t = tid; t < BS; t += TILE_THREADS) ssc[t] = s_scale[min(s0 + t, N - 1)];
+        if (NEED_NORM)
+            for (int t = tid; t < BQ; t += TILE_THREADS) qn2[t] = q_norm2[min(q0 + t, B - 1)];
+        for (int t = tid; t < BQ; t += TILE_THREADS) qsc_s[t] = q_scale[min(q0 + t, B - 1)];
+    }
+    // ---- runs of equal consecutive labels inside this support tile (one wave)
+    if (wave == 0) {
+        int lab[3];
+        load_tile_labels<BS>(sy, s0, N, C, lane, lab);
+        run_scan_wave<BS>(lab, lane, runid, runlab, nrun_s);
+    }
+
+    NW_FSTAMP(1);
+    // the K walk of every support tile starts at a different chunk (see tile_core.h: spreads the
+    // simultaneous requests of all workgroups over the memory channels); the workgroups that share
+    // a support tile keep the same order so that they still hit each other's lines in L2
+    const int nk = (d + BK - 1) / BK;
+    const int rot = st % nk;
+    f32x4 acc[RS];
+    if (MODE == MODE_F16) {
+        tile_dots_f16x2<RS>(q, s, B, N, d, q0, s0, stage, acc, rot);
+        __syncthreads();  // header tables written at kernel start are visible; the ring is dead
+    } else if (MODE == MODE_REG) {
+        tile_dots<RS, NEED_NORM>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
+    } else {
+        tile_dots_dma<RS, NEED_NORM, NEED_NORM && MODE == MODE_DMA>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
+    }
+    // (both end behind a barrier: the run tables above and the norms are visible, and the stage
+    //  buffers are dead from here on)
+    if (MODE != MODE_DMA_SN && MODE != MODE_F16 && NEED_NORM && s_norm2 != nullptr) {  // cached norms win over computed ones
+        for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
+        __syncthreads();
+    }
+
+    NW_FSTAMP(2);
+    fused_epilogue<RS, KIND, WRITE_SCORES, MODE>(acc, qn2, sn2, ssc, runid, runlab, nrun_s, qsc_s, logit_scale,
+                                                 scores, ws_m, ws_den, ws_nrun, ws_lab, ws_num, B, N, q0, s0, qt, st);
     NW_FSTAMP(6);
 }
 
 
-constexpr size_t FUSED_HDR = (64 + 4 * RUN_CAP + 4) * 4;
+constexpr size_t FUSED_HDR = (128 + 4 * RUN_CAP + 4) * 4;
+
+template <int RS, int KIND>
+void launch_f16p(const float* q, const float* s, const int64_t* sy, const float* s_norm2, const float* s_scale,
+                 const float* q_norm2, const float* q_scale, const float* ls, float* ws_m, float* ws_den,
+                 int* ws_nrun, int* ws_lab, float* ws_num, int B, int N, int d, int C, int n_stiles,
+                 int n_qtiles, int n_tiles, size_t lds, hipStream_t st);
 
 template <int RS, int KIND>
 int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
@@ -286,7 +323,18 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
                        n_stiles, n_qtiles)
     if (s_scale) {  // split-fp16 operands (the caller has checked d % 32 == 0 and supplied everything)
         if (!dma || !s_norm2 || !q_norm2 || !q_scale) return NW_ERR_INVALID_ARG;
-        if (scores) NW_LAUNCH(true, MODE_F16, lds_dma); else NW_LAUNCH(false, MODE_F16, lds_dma);
+        if (scores) {
+            NW_LAUNCH(true, MODE_F16, lds_dma);
+        } else if (RS > 5 && (RS == 8 || env_flag("NW_PERSISTENT_ANY_RS")) && grid >= 4 * device_cu_count() &&
+                   !env_flag("NW_NO_PERSISTENT")) {
+            // many tiles per CU: one persistent workgroup per CU walks them (fused_f16p.h).  RS = 8 is
+            // the tallest tile whose persistent build stays under 256 VGPRs (RS = 10 spills: 469 vs
+            // 445 us non-persistent at B=2048 N=50000, against 437 us for RS = 8 persistent).
+            launch_f16p<RS, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, ws.m, ws.den, ws.nrun, ws.lab,
+                                  ws.num, B, N, d, C, n_stiles, n_qtiles, grid, lds_dma, st);
+        } else {
+            NW_LAUNCH(false, MODE_F16, lds_dma);
+        }
     } else if (dma && s_norm2 && KIND != NW_SCORE_DOT) {
         if (scores) NW_LAUNCH(true, MODE_DMA_SN, lds_dma); else NW_LAUNCH(false, MODE_DMA_SN, lds_dma);
     } else if (dma) {
@@ -319,6 +367,24 @@ int launch_fused_kind(const float* q, const float* s, const int64_t* sy, const f
     }
 #undef NW_RS_CASE
 }
+
+}  // namespace nw
+#include "fused_f16p.h"
+namespace nw {
+namespace {
+template <int RS, int KIND>
+void launch_f16p(const float* q, const float* s, const int64_t* sy, const float* s_norm2, const float* s_scale,
+                 const float* q_norm2, const float* q_scale, const float* ls, float* ws_m, float* ws_den,
+                 int* ws_nrun, int* ws_lab, float* ws_num, int B, int N, int d, int C, int n_stiles,
+                 int n_qtiles, int n_tiles, size_t lds, hipStream_t st) {
+    if constexpr (RS > 5) {
+        const int grid = device_cu_count() < n_tiles ? device_cu_count() : n_tiles;
+        hipLaunchKernelGGL((nw_fused_f16p_kernel<RS, KIND>), dim3(grid), dim3(TILE_THREADS), lds, st, q, s, sy,
+                           s_norm2, s_scale, q_norm2, q_scale, ls, ws_m, ws_den, ws_nrun, ws_lab, ws_num, B, N, d,
+                           C, n_stiles, n_qtiles, n_tiles);
+    }
+}
+}  // namespace
 
 #define NW_INSTANTIATE_FUSED_KIND(K)                                                                   \
     template int launch_fused_kind<K>(const float*, const float*, const int64_t*, const float*,        \

@@ -76,24 +76,36 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
 
         tile_barrier();  // stages 0 and 1 have landed
         if (RS > 5) {
-            // one workgroup per CU: fragments double-buffered in registers (the reads of stage kt+1
-            // fly under the MFMAs of stage kt)
+            // one workgroup per CU: fragments double-buffered in registers.  The 2(RS+1) reads of the
+            // next stage are interleaved one-to-one with the first MFMAs of the current stage
+            // (sched_group_barrier): a ds_read_b128 issued between two 16-cycle MFMAs is free, issued
+            // in a block in front of them it is ~8 cycles of idle matrix pipe each.
+            auto interleave = [&]() {
+#pragma unroll
+                for (int x = 0; x < 2 * (RS + 1); ++x) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * RS - 2 * (RS + 1), 0);  // the remaining MFMAs
+            };
             Frag f0, f1;
             load_frags(f0, 0);
             int kt = 0;
-            for (; kt + 1 < nk; kt += 2) {
+            for (; kt + 2 < nk; kt += 2) {
                 load_frags(f1, (kt + 1) & (Cfg::NBUF - 1));
-                __builtin_amdgcn_sched_barrier(0);
                 mfma_stage(f0);
+                interleave();
                 tile_barrier();
-                if (kt + 2 < nk) load_frags(f0, (kt + 2) & (Cfg::NBUF - 1));
-                __builtin_amdgcn_sched_barrier(0);
+                load_frags(f0, (kt + 2) & (Cfg::NBUF - 1));
                 mfma_stage(f1);
+                interleave();
                 tile_barrier();
             }
-            if (kt < nk) {
+            for (; kt < nk; ++kt) {  // tail: one or two stages, nothing further to prefetch
+                if (kt + 1 < nk) load_frags(f1, (kt + 1) & (Cfg::NBUF - 1));
                 mfma_stage(f0);
                 tile_barrier();
+                f0 = f1;
             }
         } else {
             // two workgroups per CU (128 VGPRs): one fragment set; the other three waves of the SIMD
