@@ -29,6 +29,15 @@ NW_EXTERN_FUSED_KIND(NW_SCORE_DOT)
 NW_EXTERN_FUSED_KIND(NW_SCORE_CLIP)
 #undef NW_EXTERN_FUSED_KIND
 
+int persistent_qgroup() {
+    static int v = [] {
+        const char* e = getenv("NW_QG");
+        const int x = e ? atoi(e) : 0;
+        return (x >= 1 && x <= 64) ? x : 8;
+    }();
+    return v;
+}
+
 int device_cu_count() {
     static int n = [] {
         int dev = 0, v = 0;

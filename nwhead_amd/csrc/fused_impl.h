@@ -22,6 +22,7 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
                       int B, int C, int n_stiles, int BS, hipStream_t st);
 int device_cu_count();
 bool env_flag(const char* name);
+int persistent_qgroup();  // query tiles kept L2-resident per XCD by the persistent kernel (NW_QG)
 
 namespace {
 
@@ -378,10 +379,11 @@ void launch_f16p(const float* q, const float* s, const int64_t* sy, const float*
                  int* ws_nrun, int* ws_lab, float* ws_num, int B, int N, int d, int C, int n_stiles,
                  int n_qtiles, int n_tiles, size_t lds, hipStream_t st) {
     if constexpr (RS > 5) {
-        const int grid = device_cu_count() < n_tiles ? device_cu_count() : n_tiles;
+        (void)n_tiles;
+        const int grid = device_cu_count() & ~7;  // one workgroup per CU, the same number on every XCD
         hipLaunchKernelGGL((nw_fused_f16p_kernel<RS, KIND>), dim3(grid), dim3(TILE_THREADS), lds, st, q, s, sy,
                            s_norm2, s_scale, q_norm2, q_scale, ls, ws_m, ws_den, ws_nrun, ws_lab, ws_num, B, N, d,
-                           C, n_stiles, n_qtiles, n_tiles);
+                           C, n_stiles, n_qtiles, persistent_qgroup());
     }
 }
 }  // namespace

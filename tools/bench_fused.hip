@@ -9,11 +9,17 @@ namespace nw {
 size_t fused_layout(int64_t, int64_t, int, char*, FusedWs*) { return 0; }
 int launch_merge_runs(const FusedWs&, float*, float*, float*, float*, float*, int, int, int, int, hipStream_t) { return 0; }
 int pick_rs(int64_t, int64_t, int64_t, bool) { return 10; }
+int device_cu_count() { return 256; }
+bool env_flag(const char*) { return false; }
+int persistent_qgroup() { const char* e = getenv("NW_QG"); return e ? atoi(e) : 8; }
 int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d, hipStream_t st);
 }
 int main(int argc, char** argv) {
     const int B = atoi(argv[1]), N = atoi(argv[2]), d = atoi(argv[3]), C = atoi(argv[4]);
-    constexpr int RS = 10, BS = 160;
+    #ifndef NW_BENCH_RS
+#define NW_BENCH_RS 10
+#endif
+    constexpr int RS = NW_BENCH_RS, BS = 16 * RS;
     std::vector<float> hq((size_t)B * d), hs((size_t)N * d);
     srand(1);
     for (auto& v : hq) v = (rand() / (float)RAND_MAX) * 2 - 1;
@@ -21,7 +27,8 @@ int main(int argc, char** argv) {
     std::vector<int64_t> hy(N);
     for (int j = 0; j < N; ++j) hy[j] = (int64_t)j * C / N;
     const int n_stiles = (N + BS - 1) / BS, n_qtiles = (B + 63) / 64;
-    const bool f16 = argc > 5 && atoi(argv[5]) == 1;
+    const bool f16 = argc > 5 && atoi(argv[5]) >= 1;
+    const bool persistent = argc > 5 && atoi(argv[5]) == 2;
     float *q, *s, *sn, *m, *den, *num, *qsp, *ssp, *qsc, *ssc, *qn; int64_t* sy; int *nrun, *lab; unsigned long long* dbg;
     hipMalloc(&qsp, hq.size() * 4); hipMalloc(&ssp, hs.size() * 4); hipMalloc(&qsc, B * 4); hipMalloc(&ssc, N * 4); hipMalloc(&qn, B * 4);
     hipMalloc(&q, hq.size() * 4); hipMalloc(&s, hs.size() * 4); hipMalloc(&sn, N * 4); hipMalloc(&sy, N * 8);
@@ -34,7 +41,9 @@ int main(int argc, char** argv) {
     const size_t lds = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&] {
-        if (f16)
+        if (persistent)
+            launch_f16p<RS, 0>(qsp, ssp, sy, sn, ssc, qn, qsc, nullptr, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles, grid, lds, 0);
+        else if (f16)
             hipLaunchKernelGGL((nw_fused_kernel<RS, 0, false, MODE_F16>), dim3(grid), dim3(TILE_THREADS), lds, 0, qsp, ssp, sy, sn, ssc, qn, qsc,
                                (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles);
         else
@@ -45,6 +54,15 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 5; ++i) launch();
     hipEventRecord(e0); for (int i = 0; i < 100; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (persistent) {
+        std::vector<unsigned long long> hp(8 * 1024);
+        hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(nw_diag_p), hp.size() * 8);
+        double ph[4] = {0}; int n = 0;
+        for (int b = 0; b < 256; ++b) { ++n; for (int k = 0; k < 4; ++k) ph[k] += (double)hp[8 * b + k]; }
+        printf("persistent kernel %.2f us | per WG (s_memtime ticks): main loops %.0f, header+scan+H %.0f, epilogue %.0f, total %.0f\n",
+               ms * 10, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
+        return 0;
+    }
     std::vector<unsigned long long> h(8 * grid);
     hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
     double ph[6] = {0}; int n = 0;
