@@ -116,6 +116,96 @@ __global__ __launch_bounds__(256) void nw_merge_runs_kernel(
     }
 }
 
+// The same merge for large query batches: one workgroup per MQ = 16 consecutive queries, its 256
+// threads = 16 queries x 16 tile lanes, so every workspace read is a 64-byte run along the query
+// axis (the one-workgroup-per-query kernel above reads 4 bytes per 16 KB stride: 53 us at B = 4096,
+// n_stiles = 391).  Class sums live in LDS as num[class][query].
+constexpr int MQ = 16, ML = 32, MTHREADS = MQ * ML, MU = 4;
+template <bool PARTIAL>
+__global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
+    const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
+    const int* __restrict__ ws_lab, const float* __restrict__ ws_num, float* __restrict__ out,
+    float* __restrict__ lse, float* __restrict__ m_out, float* __restrict__ den_out,
+    float* __restrict__ num_out, int B, int C, int n_stiles, int BS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [ML][MQ]
+    float* inv_s = red + ML * MQ;                 // [MQ]
+    float* num = inv_s + MQ;                      // [C][MQ]
+    const int tid = threadIdx.x, bq = tid & (MQ - 1), sl = tid / MQ;
+    const int b0 = blockIdx.x * MQ;
+    const int b = min(b0 + bq, B - 1);  // rows past the batch repeat the last query and are never written
+    for (int x = tid; x < C * MQ; x += MTHREADS) num[x] = 0.f;
+
+    float M = -INFINITY;
+    for (int t = sl; t < n_stiles; t += ML) M = fmaxf(M, ws_m[(size_t)t * B + b]);
+    red[sl * MQ + bq] = M;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ML; ++k) M = fmaxf(M, red[k * MQ + bq]);
+    __syncthreads();
+
+    // The walk is latency-bound (a tile's run count gates its label and sum reads), so MU tiles are in
+    // flight per thread and the first two runs of each are read before the count is known: rows past
+    // nrun are allocated but never written, so what comes back is selected away, never used in arithmetic.
+    float den = 0.f;
+    for (int t0 = sl; t0 < n_stiles; t0 += ML * MU) {
+        float mm[MU], dd[MU], n0[MU], n1[MU];
+        int nr[MU], y0[MU], y1[MU], tt[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            const int t = t0 + u * ML;
+            const bool ok = t < n_stiles;
+            const int tc = ok ? t : t0;
+            tt[u] = tc;
+            mm[u] = ws_m[(size_t)tc * B + b];
+            dd[u] = ws_den[(size_t)tc * B + b];
+            nr[u] = ok ? ws_nrun[tc] : -1;
+            y0[u] = ws_lab[(size_t)tc * BS];
+            y1[u] = ws_lab[(size_t)tc * BS + 1];
+            n0[u] = ws_num[((size_t)tc * BS) * B + b];
+            n1[u] = ws_num[((size_t)tc * BS + 1) * B + b];
+        }
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            if (nr[u] < 0) continue;
+            const float f = __builtin_amdgcn_exp2f(mm[u] - M);
+            den += dd[u] * f;
+            if (nr[u] > 0 && y0[u] >= 0) atomicAdd(&num[y0[u] * MQ + bq], n0[u] * f);
+            if (nr[u] > 1 && y1[u] >= 0) atomicAdd(&num[y1[u] * MQ + bq], n1[u] * f);
+            for (int r = 2; r < nr[u]; ++r) {
+                const int y = ws_lab[(size_t)tt[u] * BS + r];
+                if (y >= 0) atomicAdd(&num[y * MQ + bq], ws_num[((size_t)tt[u] * BS + r) * B + b] * f);
+            }
+        }
+    }
+    red[sl * MQ + bq] = den;
+    __syncthreads();  // also orders the LDS adds before the reads below
+    den = 0.f;
+#pragma unroll
+    for (int k = 0; k < ML; ++k) den += red[k * MQ + bq];
+    const int nq = min(MQ, B - b0);
+    if (PARTIAL) {
+        if (sl == 0 && bq < nq) {
+            m_out[b] = M * 0.693147180559945309417f;  // back to natural units
+            den_out[b] = den;
+        }
+        for (int x = tid; x < nq * C; x += MTHREADS) {
+            const int qq = x / C, c = x - qq * C;
+            num_out[(size_t)(b0 + qq) * C + c] = num[c * MQ + qq];
+        }
+    } else {
+        if (sl == 0) {
+            inv_s[bq] = 1.f / den;
+            if (lse && bq < nq) lse[b] = M * 0.693147180559945309417f + logf(den);
+        }
+        __syncthreads();
+        for (int x = tid; x < nq * C; x += MTHREADS) {
+            const int qq = x / C, c = x - qq * C;
+            out[(size_t)(b0 + qq) * C + c] = logf(num[c * MQ + qq] * inv_s[qq] + NW_LOG_EPS);
+        }
+    }
+}
+
 int env_rs() {
     static int v = [] {
         const char* e = getenv("NW_TILE_RS");
@@ -128,6 +218,18 @@ int env_rs() {
 
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st) {
+    const size_t blds = ((size_t)ML * MQ + MQ + (size_t)C * MQ) * sizeof(float);
+    if (B >= 512 && blds <= 64 * 1024 && !env_flag("NW_MERGE_PER_QUERY")) {
+        const int grid = (B + MQ - 1) / MQ;
+        if (out)
+            hipLaunchKernelGGL(nw_merge_runs_blk_kernel<false>, dim3(grid), dim3(MTHREADS), blds, st, ws.m, ws.den,
+                               ws.nrun, ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS);
+        else
+            hipLaunchKernelGGL(nw_merge_runs_blk_kernel<true>, dim3(grid), dim3(MTHREADS), blds, st, ws.m, ws.den,
+                               ws.nrun, ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS);
+        NW_CHECK_LAUNCH();
+        return NW_OK;
+    }
     const size_t mlds = (8 + (size_t)C) * sizeof(float);
     if (out)
         hipLaunchKernelGGL(nw_merge_runs_kernel<false>, dim3(B), dim3(256), mlds, st, ws.m, ws.den, ws.nrun,

@@ -200,8 +200,9 @@ def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weig
                            support_cache)
 
 
-def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None):
-    """This rank's (m, den, num) over its shard of the bank; no grad."""
+def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None, support_cache=None):
+    """This rank's (m, den, num) over its shard of the bank; no grad.  ``support_cache``: the
+    shard's SplitBank (split-fp16 fast path)."""
     _need_hip(q, s, sy, logit_scale)
     lib = _lib.load()
     qc, sc = _f32c(q), _f32c(s)
@@ -210,7 +211,7 @@ def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None):
     N = sc.shape[0]
     dev = qc.device
     packed = torch.empty(B, n_classes + 2, dtype=torch.float32, device=dev)
-    return nw_partials_into(packed, qc, sc, syc, n_classes, kind, logit_scale)
+    return nw_partials_into(packed, qc, sc, syc, n_classes, kind, logit_scale, cache=support_cache)
 
 
 def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_scale=None, ws=None, sn2=None,

@@ -316,3 +316,31 @@ def test_class_window_merge(dev, ops):
     rows = torch.stack([ops.nw_partials(q, s[a:b], sy[a:b] - lo, CL).view(-1) for (a, b), lo in zip(bounds, los)])
     out = ops.nw_merge(rows, B, C, class_lo=torch.tensor(los, dtype=torch.int64, device=dev), c_local=CL)
     close(out, ops.nw_head(q, s, sy, C).cpu().numpy(), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,N,d,C,kind,sorted_labels", [
+    (1000, 9000, 64, 37, "euclidean", False),     # nk = 2 < pipeline depth, ragged B and N, ~128 runs per tile
+    (520, 16500, 512, 200, "cosine", True),       # the bench's d, class-sorted bank (1-2 runs per tile)
+    (1030, 8200, 96, 11, "dotproduct", True),
+])
+def test_persistent_many_tiles(dev, ops, O, B, N, d, C, kind, sorted_labels):
+    """>= 4 tiles per CU with a SplitBank: the persistent kernel (fused_f16p.h: XCD-local tile walk, stage
+    pipeline running across tile boundaries) and, from 512 queries up, the blocked merge -- against the
+    fp64 oracle, for the final output and for the (m, den, num) partials."""
+    g = torch.Generator().manual_seed(11)
+    q = (torch.randn(B, d, generator=g) * 0.7).to(dev)
+    s = torch.randn(N, d, generator=g).to(dev)
+    sy = torch.arange(N) % C
+    sy = (sy.sort().values if sorted_labels else sy[torch.randperm(N, generator=g)]).to(dev)
+    cache = ops.SplitBank(s)
+    assert cache.split is not None
+    out = ops.nw_head(q, s, sy, C, kind, support_cache=cache)
+    ref = O.nw_head_f64(q.cpu(), s.cpu(), sy.cpu(), C, kind)
+    smax = O.scores_f64(q[:64].cpu(), s.cpu(), kind, O.CLIP_LOGIT_SCALE_INIT).abs().max().item()
+    atol = max(3e-5, 3e-6 * smax)
+    close(out, ref.numpy(), rtol=RTOL, atol=atol)
+    # partials of two halves of the bank, merged == the whole
+    h = N // 2
+    rows = torch.stack([ops.nw_partials(q, s[:h], sy[:h], C, kind, support_cache=ops.SplitBank(s[:h])).view(-1),
+                        ops.nw_partials(q, s[h:], sy[h:], C, kind, support_cache=ops.SplitBank(s[h:])).view(-1)])
+    close(ops.nw_merge(rows, B, C), ref.numpy(), rtol=RTOL, atol=atol)

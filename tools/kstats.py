@@ -1,4 +1,6 @@
-import csv,glob,re,sys
-import os
-f=sorted(glob.glob(sys.argv[1]+"/trace/*/*_kernel_stats.csv"), key=os.path.getmtime)[-1]
-for r in csv.DictReader(open(f)): print(re.search(r"(nw_[a-z_0-9]+)",r["Name"]).group(1), "%.2f us"%(float(r["AverageNs"])/1e3), r["Calls"])
+import sys, glob, os, csv
+fs = sorted(glob.glob(sys.argv[1] + "/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
+if not fs:
+    sys.exit("no kernel_stats.csv under " + sys.argv[1])
+for r in list(csv.DictReader(open(fs[-1])))[: int(sys.argv[2]) if len(sys.argv) > 2 else 12]:
+    print("%-70s calls %5s avg %10.2f us  %6s %%" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
