@@ -29,6 +29,14 @@ NW_EXTERN_FUSED_KIND(NW_SCORE_DOT)
 NW_EXTERN_FUSED_KIND(NW_SCORE_CLIP)
 #undef NW_EXTERN_FUSED_KIND
 
+bool persistent_two_per_cu() {
+    static int v = [] {
+        const char* e = getenv("NW_P2");
+        return e ? atoi(e) : 1;
+    }();
+    return v != 0;
+}
+
 int persistent_qgroup() {
     static int v = [] {
         const char* e = getenv("NW_QG");
@@ -67,6 +75,7 @@ size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws
     w.nrun = reinterpret_cast<int*>(take((size_t)n_stiles * 4));
     w.lab = reinterpret_cast<int*>(take((size_t)n_stiles * BS * 4));
     w.num = reinterpret_cast<float*>(take((size_t)n_stiles * BS * B * 4));
+    w.runid = reinterpret_cast<int*>(take(((size_t)n_stiles * BS + 64) * 4));
     if (ws) *ws = w;
     return off;
 }
@@ -206,6 +215,45 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
     }
 }
 
+// Runs of equal consecutive labels inside every support tile of BS rows, one wave per tile:
+// runid[st*BS + t] = run of tile row t, lab[st*BS + run] = its class (-1: padding rows / labels outside
+// [0, C)), nrun[st].  The persistent kernel reads these instead of scanning the labels once per
+// (query tile, support tile) pair.
+__global__ __launch_bounds__(64) void nw_run_tables_kernel(const int64_t* __restrict__ sy, int N, int C, int BS,
+                                                           int* __restrict__ runid, int* __restrict__ nrun,
+                                                           int* __restrict__ lab_out) {
+    const int st = blockIdx.x, lane = threadIdx.x, s0 = st * BS;
+    int lab[3], flag[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = 3 * lane + u, j = s0 + t;
+        int64_t y = -1;
+        if (t < BS && j < N) y = sy[j];
+        lab[u] = ((uint64_t)y < (uint64_t)C) ? (int)y : -1;
+    }
+    const int prev_last = __shfl_up(lab[2], 1);
+    flag[0] = (lane == 0) || (lab[0] != prev_last);
+    flag[1] = lab[1] != lab[0];
+    flag[2] = lab[2] != lab[1];
+    int incl = flag[0] + flag[1] + flag[2];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    int id = incl - (flag[0] + flag[1] + flag[2]) - 1;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = 3 * lane + u;
+        id += flag[u];
+        if (t < BS) {
+            runid[(size_t)s0 + t] = id;
+            if (flag[u]) lab_out[(size_t)s0 + id] = lab[u];
+            if (t == BS - 1) nrun[st] = id + 1;
+        }
+    }
+}
+
 int env_rs() {
     static int v = [] {
         const char* e = getenv("NW_TILE_RS");
@@ -215,6 +263,13 @@ int env_rs() {
 }
 
 }  // namespace
+
+int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st) {
+    if (BS > 192) return NW_ERR_UNSUPPORTED;  // three rows per lane
+    hipLaunchKernelGGL(nw_run_tables_kernel, dim3(n_stiles), dim3(64), 0, st, sy, N, C, BS, ws.runid, ws.nrun, ws.lab);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
 
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st) {

@@ -1,18 +1,27 @@
 // fused_f16p.h -- persistent edition of the split-fp16 fused forward (gfx950 / MI355X only).
 //
-// One 512-thread workgroup per CU walks its share of the (query tile, support tile) grid
-// (tile T = blockIdx.x, + gridDim.x, ...), instead of one workgroup per tile.  Measured on the
-// one-workgroup-per-tile kernel (tools/bench_fused.hip, B=2048 N=50000): 21.9 k cycles of stamped
-// work per tile but 27 k cycles per tile of wall time: every new workgroup pays its dispatch (LDS
-// allocation, wave launch), the latency of its label/norm loads and the DMA prologue before the first
-// MFMA.  Here
+// One 512-thread workgroup per CU walks its share of the (query tile, support tile) grid instead of
+// one workgroup per tile.  Measured on the one-workgroup-per-tile kernel (tools/bench_fused.hip,
+// B=2048 N=50000): 21.9 k cycles of stamped work per tile but 27 k cycles per tile of wall time --
+// every new workgroup pays its dispatch (LDS allocation, wave launch), the latency of its label/norm
+// loads, the run scan and the DMA prologue before the first MFMA.  Here
 //   * the loader waves keep ONE stage pipeline running across tile boundaries: while the consumers
 //     run a tile's epilogue the first three stages of the next tile are already landing;
-//   * the consumers issue the loads for a tile's header (labels, norms, scales) when the tile starts
-//     and only touch them after its main loop, so that latency hides behind the MFMAs;
-//   * barriers: one per stage plus one per tile (header visible), executed by both roles.
-// Everything else (tile shape, LDS image, MFMA stream, epilogue, workspace layout) is that of
-// nw_fused_kernel<RS, KIND, false, MODE_F16>.
+//   * the tile header (support norms, row scales, run ids of the support rows; norms and scales of
+//     the query rows) is DMA'd into LDS by the loaders together with the first stage of the tile,
+//     into one of three header buffers (tile index mod 3), so the consumers never wait for a global load;
+//   * the runs of equal labels are found ONCE per launch by nw_run_tables_kernel (fused.hip) instead
+//     of once per (query tile, support tile) workgroup;
+//   * barriers: one per stage, executed by both roles, nothing else.
+// Tile shape, LDS stage image and MFMA stream are those of nw_fused_kernel<RS, KIND, false, MODE_F16>.
+// Requires d / 32 >= 3: the header of tile T+2 is issued 3 stages before tile T+1 ends, i.e. (three
+// stages per tile) possibly while the consumers still run the epilogue of tile T -- hence three header
+// buffers; with fewer stages per tile the issue cursor would run further ahead than that.
+//
+// What bounds it (tools/bench_f16_loop.hip, RS = 8, random operands): the main loop needs 24 MFMAs
+// (384 cycles) and a 24.6 KB LDS fill per stage.  From an L2-resident source the loop runs 495
+// cycles per stage, and the chip holds 1.50 GHz on it (2.37 GHz on zeros): 345 ns per stage = 388
+// TFLOP/s-equivalent is the power-limited pace of this instruction mix, not 833.
 #pragma once
 #include "fused_impl.h"
 
@@ -31,27 +40,157 @@ __device__ unsigned long long nw_diag_p[8 * 1024];
 #define NW_PSTAMP(k)
 #endif
 
+template <int RS>
+struct PCfg {
+    static constexpr int BS = 16 * RS;
+    static constexpr int N64 = (BS + 63) / 64;          // 64-row DMA pieces per support-side header array
+    static constexpr int NH = N64 * 64;                 // entries per support-side array in LDS
+    static constexpr int HDR_F = 3 * NH + 128;          // sn2 | ssc | runid | qn2[64] | qsc[64]
+    static constexpr int NP = 3 * N64 + 2;              // header pieces (256 B each)
+    static constexpr int HPW = (NP + NLOAD - 1) / NLOAD;  // ... per loader wave
+    static constexpr int NHB = 3;                       // header buffers
+    static constexpr size_t HDR_BYTES = NHB * (size_t)HDR_F * 4;
+    static_assert(HDR_BYTES % 16 == 0, "stage buffers must stay 16-byte aligned");
+};
+
+// Epilogue of one tile for the consumer waves: scores -> tile-local softmax statistics -> run sums.
+// Same arithmetic as fused_epilogue<.., MODE_F16> (fused_impl.h); the header comes from LDS only.
 template <int RS, int KIND>
-__global__ __launch_bounds__(TILE_THREADS, 2) void nw_fused_f16p_kernel(
-    const float* __restrict__ q, const float* __restrict__ s, const int64_t* __restrict__ sy,
-    const float* __restrict__ s_norm2, const float* __restrict__ s_scale, const float* __restrict__ q_norm2,
-    const float* __restrict__ q_scale, const float* __restrict__ logit_scale, float* __restrict__ ws_m,
-    float* __restrict__ ws_den, int* __restrict__ ws_nrun, int* __restrict__ ws_lab,
-    float* __restrict__ ws_num, int B, int N, int d, int C, int n_stiles, int n_qtiles, int qg) {
-    using Cfg = DmaCfg<RS>;
-    constexpr int BS = Cfg::BS, TILE_F4 = Cfg::TILE_F4, NI = Cfg::NI, NI_LO = Cfg::NI_LO, NT = Cfg::NT;
-    constexpr int AHEAD = Cfg::NBUF - 1;
+__device__ __forceinline__ void epilogue_p(f32x4 (&acc)[RS], const float* hdr, int nrun,
+                                           const float* __restrict__ logit_scale, float* __restrict__ ws_m,
+                                           float* __restrict__ ws_den, float* __restrict__ ws_num, int B, int N,
+                                           int q0, int s0, int st, int wave, int lane
+#ifdef NW_DIAG_FUSED
+                                           , unsigned long long (&diag_)[8], unsigned long long& last_
+#endif
+                                           ) {
+    using P = PCfg<RS>;
+    constexpr int BS = P::BS;
     constexpr bool NEED_NORM = (KIND != NW_SCORE_DOT);
-    static_assert(RS > 5, "the persistent kernel uses the double-buffered fragment loop");
+    constexpr float L2E = 1.44269504088896340736f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const float* sn2 = hdr;
+    const float* ssc = hdr + P::NH;
+    const int* runid = reinterpret_cast<const int*>(hdr + 2 * P::NH);
+    const float* qn2 = hdr + 3 * P::NH;
+    const float* qsc_s = qn2 + 64;
+    const int i = lane & 15, g = lane >> 4;
+    const int qrow = 16 * wave + i;
+    const int b = q0 + qrow;
+    float scale = 1.f;
+    if (KIND == NW_SCORE_CLIP) scale = expf(*logit_scale);
+    const float qn = NEED_NORM ? qn2[qrow] : 0.f;
+    const float qsc = qsc_s[qrow];
+    // every header vector this lane needs, in one burst of LDS reads
+    float4 n4[RS], s4[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        n4[r] = NEED_NORM ? *reinterpret_cast<const float4*>(sn2 + 16 * r + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s4[r] = *reinterpret_cast<const float4*>(ssc + 16 * r + 4 * g);
+    }
+    float sc[RS][4];
+    if (KIND == NW_SCORE_EUCLIDEAN) {
+        // u = -sqrt(L2E^2 * (qn + sn - 2 dot)), dot = acc * 2^-(e_q + e_s): three packed fp32 ops per pair
+        const f32x2 cq = {-2.f * L2E * L2E * qsc, -2.f * L2E * L2E * qsc};
+        const f32x2 qb = {qn * (L2E * L2E), qn * (L2E * L2E)};
+        const f32x2 l2 = {L2E * L2E, L2E * L2E};
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const f32x2 k01 = f32x2{s4[r].x, s4[r].y} * cq, k23 = f32x2{s4[r].z, s4[r].w} * cq;
+            const f32x2 b01 = __builtin_elementwise_fma(f32x2{n4[r].x, n4[r].y}, l2, qb);
+            const f32x2 b23 = __builtin_elementwise_fma(f32x2{n4[r].z, n4[r].w}, l2, qb);
+            const f32x2 d01 = __builtin_elementwise_fma(f32x2{acc[r][0], acc[r][1]}, k01, b01);
+            const f32x2 d23 = __builtin_elementwise_fma(f32x2{acc[r][2], acc[r][3]}, k23, b23);
+            sc[r][0] = -fast_sqrt_pos(d01.x);
+            sc[r][1] = -fast_sqrt_pos(d01.y);
+            sc[r][2] = -fast_sqrt_pos(d23.x);
+            sc[r][3] = -fast_sqrt_pos(d23.y);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const float nn[4] = {n4[r].x, n4[r].y, n4[r].z, n4[r].w};
+            const float kk[4] = {s4[r].x * qsc, s4[r].y * qsc, s4[r].z * qsc, s4[r].w * qsc};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc[r][e] = score_from_dot<KIND>(acc[r][e] * kk[e], qn, nn[e], scale) * L2E;
+        }
+    }
+    NW_PSTAMP(1);
+    if (s0 + BS > N) {  // only the last support tile has rows past the bank
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (s0 + 16 * r + 4 * g + e >= N) sc[r][e] = -INFINITY;
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) mloc = fmaxf(mloc, fmaxf(fmaxf(sc[r][0], sc[r][1]), fmaxf(sc[r][2], sc[r][3])));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    NW_PSTAMP(2);
+    float dloc = 0.f;
+#pragma unroll
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[r][e] = __builtin_amdgcn_exp2f(sc[r][e] - mloc);  // 2^-inf = 0 for padded rows
+            dloc += sc[r][e];
+        }
+    dloc += __shfl_xor(dloc, 16);
+    dloc += __shfl_xor(dloc, 32);
+    NW_PSTAMP(3);
+    if (nrun == 1) {  // the whole tile is one class: its run sum is the denominator
+        if (g == 0 && b < B) ws_num[((size_t)st * BS) * B + b] = dloc;
+    } else {
+        // run sums on the matrix cores: indicator (A operand) x E (already in B-operand layout)
+        for (int run_base = 0; run_base < nrun; run_base += 16) {
+            f32x4 Pm = {0.f, 0.f, 0.f, 0.f};
+            const int want = run_base + i;
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const int4 rid = *reinterpret_cast<const int4*>(runid + 16 * r + 4 * g);
+                Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.x == want ? 1.f : 0.f, sc[r][0], Pm, 0, 0, 0);
+                Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.y == want ? 1.f : 0.f, sc[r][1], Pm, 0, 0, 0);
+                Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.z == want ? 1.f : 0.f, sc[r][2], Pm, 0, 0, 0);
+                Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.w == want ? 1.f : 0.f, sc[r][3], Pm, 0, 0, 0);
+            }
+            if (b < B) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int run = run_base + 4 * g + j;
+                    if (run < nrun) ws_num[((size_t)st * BS + run) * B + b] = Pm[j];
+                }
+            }
+        }
+    }
+    NW_PSTAMP(4);
+    if (g == 0 && b < B) {
+        ws_m[(size_t)st * B + b] = mloc;
+        ws_den[(size_t)st * B + b] = dloc;
+    }
+    NW_PSTAMP(5);
+}
+
+// TWO = false: one workgroup per CU, 4-buffer ring, double-buffered fragments (<= 256 VGPRs).
+// TWO = true : two workgroups per CU (3-buffer ring: 80 KB of LDS each; single-buffered fragments:
+//              <= 128 VGPRs), so one's epilogue and LDS-read latency run under the other's MFMAs.
+template <int RS, int KIND, bool TWO>
+__global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kernel(
+    const float* __restrict__ q, const float* __restrict__ s, const float* __restrict__ s_norm2,
+    const float* __restrict__ s_scale, const float* __restrict__ q_norm2, const float* __restrict__ q_scale,
+    const float* __restrict__ logit_scale, const int* __restrict__ ws_runid, const int* __restrict__ ws_nrun,
+    float* __restrict__ ws_m, float* __restrict__ ws_den, float* __restrict__ ws_num, int B, int N, int d,
+    int n_stiles, int n_qtiles, int qg) {
+    using Cfg = DmaCfg<RS>;
+    using P = PCfg<RS>;
+    constexpr int BS = Cfg::BS, TILE_F4 = Cfg::TILE_F4, NI = Cfg::NI, NI_LO = Cfg::NI_LO, NT = Cfg::NT;
+    constexpr int NB = TWO ? 3 : 4;  // ring depth
+    constexpr int AHEAD = NB - 1;    // stages in flight per loader wave
+    static_assert(RS > 5, "the persistent kernel is built for the tall tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* qn2 = reinterpret_cast<float*>(smem);
-    float* qsc_s = qn2 + 64;
-    float* sn2 = qsc_s + 64;
-    float* ssc = sn2 + RUN_CAP;
-    int* runid = reinterpret_cast<int*>(ssc + RUN_CAP);
-    int* runlab = runid + RUN_CAP;
-    int* nrun_s = runlab + RUN_CAP;
-    float4* stage = reinterpret_cast<float4*>(smem + FUSED_HDR);
+    float* hdr0 = reinterpret_cast<float*>(smem);  // NHB header buffers of HDR_F floats, by tile index mod NHB
+    float4* stage = reinterpret_cast<float4*>(smem + P::HDR_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,9 +200,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void nw_fused_f16p_kernel(
     // its working set in that L2: XCD x owns the support tiles st = x (mod 8); its list is cut into
     // groups of `qg` query tiles (kept resident: qg * 128 KB), and inside a group runs support-tile
     // major, so the n_cu workgroups of the XCD are on ~n_cu/qg support tiles x qg query tiles at any
-    // time.  (Measured with the old order -- all 32 query tiles of ONE support tile per XCD, 4 MB of
-    // queries cycling through L2 -- the LDS fill ran at 65 GB/s per CU and set the pace of the main
-    // loop; from an L2-resident source the same loop streams 140 GB/s per CU: tools/bench_f16_loop.)
+    // time.
     const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, n_cu = gridDim.x >> 3;
     const int ns_x = (n_stiles - xcd + 7) >> 3;  // support tiles of this XCD
     const int n_local = ns_x * n_qtiles;         // tiles of this XCD
@@ -78,31 +215,61 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void nw_fused_f16p_kernel(
         qt = gi * qg + dec_c;
         st = stl * 8 + xcd;
     };
+
     if (wave >= NCONS) {
         // ================================ LOADER ================================
         const int lw = wave - NCONS;
         const bool long_wave = (NI == NI_LO) || (lw < NT % NLOAD);
         unsigned voff[NI];
-        int iT = cu, ikt = 0, irot = 0;  // issue cursor: (tile of this XCD's list, stage)
-        int gs = 0;                                           // stages issued so far (ring position)
+        int iT = cu, ikt = 0, irot = 0, ipar = 0;  // issue cursor: (tile of this XCD's list, stage), header buffer
+        int iq0 = 0, is0 = 0, ist = 0;
+        int gs = 0;                                // stages issued so far (ring position)
         auto set_tile = [&](int T) {
             int qt, st;
             decode(T, qt, st);
-            const int q0 = qt * BQ, s0 = st * BS;
+            iq0 = qt * BQ;
+            is0 = st * BS;
+            ist = st;
             irot = st % nk;
 #pragma unroll
             for (int m = 0; m < NI; ++m) {
                 const int R = 8 * (lw + NLOAD * m) + (lane >> 3);
                 const int lslot = (lane & 7) ^ ((R >> 1) & 7);
-                const int grow = (8 * NLOAD * m < BQ) ? min(q0 + R, B - 1) : min(s0 + R - BQ, N - 1);
+                const int grow = (8 * NLOAD * m < BQ) ? min(iq0 + R, B - 1) : min(is0 + R - BQ, N - 1);
                 voff[m] = ((unsigned)grow * (unsigned)d + lslot * 4) * 4u;
             }
         };
+        auto dma4 = [&](const void* src, float* dst) {  // one dword per lane -> dst[lane]
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+        };
+        // header pieces of the tile under the issue cursor: HPW per loader wave (piece ids past the
+        // last one repeat the last piece: same bytes to the same place)
+        auto issue_header = [&]() {
+            float* h = hdr0 + ipar * P::HDR_F;
+#pragma unroll
+            for (int k = 0; k < P::HPW; ++k) {
+                const int pc = min(lw + NLOAD * k, P::NP - 1);
+                if (pc < 3 * P::N64) {
+                    const int arr = pc / P::N64, c = pc - arr * P::N64;
+                    const int row = is0 + 64 * c + lane;
+                    float* dst = h + arr * P::NH + 64 * c;
+                    if (arr == 0) dma4(s_norm2 + min(row, N - 1), dst);
+                    else if (arr == 1) dma4(s_scale + min(row, N - 1), dst);
+                    else dma4(ws_runid + (size_t)ist * BS + 64 * c + lane, dst);  // padded by 64 entries
+                } else if (pc == 3 * P::N64) {
+                    dma4(q_norm2 + min(iq0 + lane, B - 1), h + 3 * P::NH);
+                } else {
+                    dma4(q_scale + min(iq0 + lane, B - 1), h + 3 * P::NH + 64);
+                }
+            }
+        };
+        bool young_hdr = false;  // does the youngest issued stage carry header pieces?
         auto issue_next = [&]() {  // returns false once every stage of every tile has been issued
             if (iT >= n_local) return false;
             int kc = ikt + irot;
             if (kc >= nk) kc -= nk;
-            float4* buf = stage + (gs & (Cfg::NBUF - 1)) * TILE_F4;
+            float4* buf = stage + ((unsigned)gs % NB) * TILE_F4;
             const char* qb = reinterpret_cast<const char*>(q) + (size_t)kc * BK * 4;
             const char* sb = reinterpret_cast<const char*>(s) + (size_t)kc * BK * 4;
 #ifndef NW_ABL_NODMA
@@ -119,32 +286,34 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void nw_fused_f16p_kernel(
                 (void)g; (void)buf;
 #endif
             }
+            young_hdr = (ikt == 0);
+            if (young_hdr) issue_header();  // after the stage's own pieces: they are waited for last
             ++gs;
             if (++ikt == nk) {
                 ikt = 0;
+                ipar = (ipar + 1 == P::NHB) ? 0 : ipar + 1;
                 iT += n_cu;
                 if (iT < n_local) set_tile(iT);
             }
             return true;
         };
-        auto wait_landed = [&](bool issued) {  // all but the youngest stage of this wave's DMAs have landed
+        auto wait_landed = [&](bool issued) {  // everything but the youngest stage of this wave has landed
             if (!issued) wait_vmcnt<0>();
-            else if (long_wave) wait_vmcnt<(AHEAD - 2) * NI>();
-            else wait_vmcnt<(AHEAD - 2) * NI_LO>();
+            else if (long_wave) { if (young_hdr) wait_vmcnt<NI + P::HPW>(); else wait_vmcnt<NI>(); }
+            else { if (young_hdr) wait_vmcnt<NI_LO + P::HPW>(); else wait_vmcnt<NI_LO>(); }
         };
         if (iT < n_local) set_tile(iT);
         bool more = true;
 #pragma unroll
         for (int k0 = 0; k0 < AHEAD; ++k0) more = issue_next();
         wait_landed(more);
-        tile_barrier();  // P: stages 0 and 1 of the first tile have landed
+        tile_barrier();  // P: all but the youngest issued stage (and the first tile's header) have landed
         for (int T = cu; T < n_local; T += n_cu) {
             for (int kt = 0; kt < nk; ++kt) {
                 more = issue_next();
                 wait_landed(more);
                 tile_barrier();
             }
-            tile_barrier();  // H: matches the consumers' "header visible" barrier
         }
     } else {
         // ================================ CONSUMER ================================
@@ -156,7 +325,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void nw_fused_f16p_kernel(
         const int qrow = 16 * wave + i;
         const int rsw = (i >> 1) & 7;
         auto load_frags = [&](Frag& f, int buf) {
-            const float4* Qs = stage + (buf & (Cfg::NBUF - 1)) * TILE_F4;
+            const float4* Qs = stage + ((unsigned)buf % NB) * TILE_F4;
             const float4* Ss = Qs + BQ * ROW_F4;
             const int sh = g ^ rsw, sl = (4 + g) ^ rsw;
             f.bh = Qs[qrow * ROW_F4 + sh];
@@ -190,34 +359,19 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void nw_fused_f16p_kernel(
 
         tile_barrier();  // P
         int gi = 0;      // ring position of the current tile's first stage
+        int par = 0;     // header buffer of the current tile
 #ifdef NW_DIAG_FUSED
-        unsigned long long diag_[4] = {0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+        unsigned long long diag_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
         const unsigned long long first_ = last_;
 #endif
         for (int T = cu; T < n_local; T += n_cu) {
             int qt, st;
             decode(T, qt, st);
             const int q0 = qt * BQ, s0 = st * BS;
-            // header loads issued now, consumed behind the main loop: two values per thread + labels
-            const int t0 = tid, t1 = tid + 64 * NCONS;  // 256 consumer threads cover BS <= 192 rows... twice
-            float h_sn0 = 0.f, h_ss0 = 0.f, h_qn = 0.f, h_qs = 1.f;
-            int lab[3] = {-1, -1, -1};
-            if (t0 < BS) {
-                if (NEED_NORM) h_sn0 = s_norm2[min(s0 + t0, N - 1)];
-                h_ss0 = s_scale[min(s0 + t0, N - 1)];
-            }
-            if (t0 < BQ) {
-                if (NEED_NORM) h_qn = q_norm2[min(q0 + t0, B - 1)];
-                h_qs = q_scale[min(q0 + t0, B - 1)];
-            }
-            (void)t1;
-            if (wave == 0) load_tile_labels<BS>(sy, s0, N, C, lane, lab);
+            const int nrun = ws_nrun[st];  // wave-uniform: a scalar load, used after the main loop
 #ifndef NW_ABL_NOPREFETCH
             // L2 prefetch: the support rows of this workgroup's NEXT tile, one 128-B line per load, the
-            // lines dealt round-robin to the workgroups that will share that tile.  First touches of
-            // support rows otherwise pay the HBM / Infinity Cache latency inside the 3-stage LDS
-            // pipeline (74 KB in flight per CU / ~1.1 us = the 65 GB/s per CU measured); touched one
-            // tile ahead, the LDS-DMA stream only ever hits in L2.
+            // lines dealt round-robin to the workgroups that will share that tile.
             if (T + n_cu < n_local) {
                 int nqt, nst;
                 decode(T + n_cu, nqt, nst);
@@ -230,53 +384,53 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void nw_fused_f16p_kernel(
 
 #pragma unroll
             for (int r = 0; r < RS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            Frag f0, f1;
-            load_frags(f0, gi);
-            int kt = 0;
-            for (; kt + 2 < nk; kt += 2) {
-                load_frags(f1, gi + kt + 1);
-                mfma_stage(f0);
-                interleave();
-                tile_barrier();
-                load_frags(f0, gi + kt + 2);
-                mfma_stage(f1);
-                interleave();
-                tile_barrier();
-            }
-            for (; kt < nk; ++kt) {
-                if (kt + 1 < nk) load_frags(f1, gi + kt + 1);
-                mfma_stage(f0);
-                tile_barrier();
-                f0 = f1;
+            if constexpr (TWO) {
+                Frag f0;
+                for (int kt = 0; kt < nk; ++kt) {
+                    load_frags(f0, gi + kt);
+                    mfma_stage(f0);
+                    tile_barrier();
+                }
+            } else {
+                Frag f0, f1;
+                load_frags(f0, gi);
+                int kt = 0;
+                for (; kt + 2 < nk; kt += 2) {
+                    load_frags(f1, gi + kt + 1);
+                    mfma_stage(f0);
+                    interleave();
+                    tile_barrier();
+                    load_frags(f0, gi + kt + 2);
+                    mfma_stage(f1);
+                    interleave();
+                    tile_barrier();
+                }
+                for (; kt < nk; ++kt) {
+                    if (kt + 1 < nk) load_frags(f1, gi + kt + 1);
+                    mfma_stage(f0);
+                    tile_barrier();
+                    f0 = f1;
+                }
             }
             gi += nk;
             NW_PSTAMP(0);
-
-            // header of this tile (the previous tile's epilogue is long over: every wave has passed
-            // this tile's stage barriers since)
-            if (t0 < BS) {
-                if (NEED_NORM) sn2[t0] = h_sn0;
-                ssc[t0] = h_ss0;
-            }
-            if (t0 < BQ) {
-                if (NEED_NORM) qn2[t0] = h_qn;
-                qsc_s[t0] = h_qs;
-            }
-            if (wave == 0) run_scan_wave<BS>(lab, lane, runid, runlab, nrun_s);
-            tile_barrier();  // H
-            NW_PSTAMP(1);
 #ifndef NW_ABL_NOEPI
-            fused_epilogue<RS, KIND, false, MODE_F16>(acc, qn2, sn2, ssc, runid, runlab, nrun_s, qsc_s, logit_scale,
-                                                      nullptr, ws_m, ws_den, ws_nrun, ws_lab, ws_num, B, N, q0, s0, qt, st);
-#else
-            if (acc[0][0] + acc[RS - 1][3] == 12345.678f) ws_m[tid] = acc[1][1];
+            epilogue_p<RS, KIND>(acc, hdr0 + par * P::HDR_F, nrun, logit_scale, ws_m, ws_den, ws_num, B, N, q0, s0, st,
+                                 wave, lane
+#ifdef NW_DIAG_FUSED
+                                 , diag_, last_
 #endif
-            NW_PSTAMP(2);
+                                 );
+#else
+            if (acc[0][0] + acc[RS - 1][3] == 12345.678f) ws_m[tid] = acc[1][1] + nrun;
+#endif
+            par = (par + 1 == P::NHB) ? 0 : par + 1;
+            NW_PSTAMP(6);
         }
 #ifdef NW_DIAG_FUSED
         if (tid == 0 && blockIdx.x < 1024) {
-            for (int k = 0; k < 3; ++k) nw_diag_p[8 * blockIdx.x + k] = diag_[k];
-            nw_diag_p[8 * blockIdx.x + 3] = last_ - first_;
+            for (int k = 0; k < 7; ++k) nw_diag_p[8 * blockIdx.x + k] = diag_[k];
+            nw_diag_p[8 * blockIdx.x + 7] = last_ - first_;
         }
 #endif
     }

@@ -16,13 +16,16 @@ struct FusedWs {  // views into the caller's workspace
     int* nrun;    // [n_stiles]
     int* lab;     // [n_stiles][BS]      label of run r (-1: padding / out-of-range label)
     float* num;   // [n_stiles][BS][B]   run sums, rows >= nrun[st] never touched
+    int* runid;   // [n_stiles][BS] (+64)  run of every support row inside its tile (persistent kernel only)
 };
 size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws);
+int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st);
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st);
 int device_cu_count();
 bool env_flag(const char* name);
 int persistent_qgroup();  // query tiles kept L2-resident per XCD by the persistent kernel (NW_QG)
+bool persistent_two_per_cu();  // two persistent workgroups per CU (NW_P2=0/1)
 
 namespace {
 
@@ -294,10 +297,9 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
 constexpr size_t FUSED_HDR = (128 + 4 * RUN_CAP + 4) * 4;
 
 template <int RS, int KIND>
-void launch_f16p(const float* q, const float* s, const int64_t* sy, const float* s_norm2, const float* s_scale,
-                 const float* q_norm2, const float* q_scale, const float* ls, float* ws_m, float* ws_den,
-                 int* ws_nrun, int* ws_lab, float* ws_num, int B, int N, int d, int C, int n_stiles,
-                 int n_qtiles, int n_tiles, size_t lds, hipStream_t st);
+int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* s_norm2, const float* s_scale,
+                const float* q_norm2, const float* q_scale, const float* ls, const FusedWs& ws, int B, int N,
+                int d, int C, int n_stiles, int n_qtiles, hipStream_t st);
 
 template <int RS, int KIND>
 int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
@@ -327,12 +329,13 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
         if (scores) {
             NW_LAUNCH(true, MODE_F16, lds_dma);
         } else if (RS > 5 && (RS == 8 || env_flag("NW_PERSISTENT_ANY_RS")) && grid >= 4 * device_cu_count() &&
-                   !env_flag("NW_NO_PERSISTENT")) {
+                   d >= 3 * BK && !env_flag("NW_NO_PERSISTENT")) {
             // many tiles per CU: one persistent workgroup per CU walks them (fused_f16p.h).  RS = 8 is
             // the tallest tile whose persistent build stays under 256 VGPRs (RS = 10 spills: 469 vs
             // 445 us non-persistent at B=2048 N=50000, against 437 us for RS = 8 persistent).
-            launch_f16p<RS, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, ws.m, ws.den, ws.nrun, ws.lab,
-                                  ws.num, B, N, d, C, n_stiles, n_qtiles, grid, lds_dma, st);
+            const int rc = launch_f16p<RS, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, ws, B, N, d, C,
+                                                 n_stiles, n_qtiles, st);
+            if (rc != NW_OK) return rc;
         } else {
             NW_LAUNCH(false, MODE_F16, lds_dma);
         }
@@ -374,17 +377,29 @@ int launch_fused_kind(const float* q, const float* s, const int64_t* sy, const f
 namespace nw {
 namespace {
 template <int RS, int KIND>
-void launch_f16p(const float* q, const float* s, const int64_t* sy, const float* s_norm2, const float* s_scale,
-                 const float* q_norm2, const float* q_scale, const float* ls, float* ws_m, float* ws_den,
-                 int* ws_nrun, int* ws_lab, float* ws_num, int B, int N, int d, int C, int n_stiles,
-                 int n_qtiles, int n_tiles, size_t lds, hipStream_t st) {
+int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* s_norm2, const float* s_scale,
+                const float* q_norm2, const float* q_scale, const float* ls, const FusedWs& ws, int B, int N,
+                int d, int C, int n_stiles, int n_qtiles, hipStream_t st) {
     if constexpr (RS > 5) {
-        (void)n_tiles;
-        const int grid = device_cu_count() & ~7;  // one workgroup per CU, the same number on every XCD
-        hipLaunchKernelGGL((nw_fused_f16p_kernel<RS, KIND>), dim3(grid), dim3(TILE_THREADS), lds, st, q, s, sy,
-                           s_norm2, s_scale, q_norm2, q_scale, ls, ws_m, ws_den, ws_nrun, ws_lab, ws_num, B, N, d,
-                           C, n_stiles, n_qtiles, persistent_qgroup());
+        // runs of equal labels per support tile: once per launch (ws.runid / ws.nrun / ws.lab)
+        const int rc = launch_run_tables(ws, sy, N, C, n_stiles, 16 * RS, st);
+        if (rc != NW_OK) return rc;
+        const int cus = device_cu_count() & ~7;  // the same number of workgroups on every XCD
+        const size_t tile_bytes = (size_t)DmaCfg<RS>::TILE_F4 * 16;
+        if (persistent_two_per_cu() && PCfg<RS>::HDR_BYTES + 3 * tile_bytes <= 80 * 1024) {
+            hipLaunchKernelGGL((nw_fused_f16p_kernel<RS, KIND, true>), dim3(2 * cus), dim3(TILE_THREADS),
+                               PCfg<RS>::HDR_BYTES + 3 * tile_bytes, st, q, s, s_norm2, s_scale, q_norm2, q_scale, ls,
+                               ws.runid, ws.nrun, ws.m, ws.den, ws.num, B, N, d, n_stiles, n_qtiles,
+                               persistent_qgroup());
+        } else {
+            hipLaunchKernelGGL((nw_fused_f16p_kernel<RS, KIND, false>), dim3(cus), dim3(TILE_THREADS),
+                               PCfg<RS>::HDR_BYTES + 4 * tile_bytes, st, q, s, s_norm2, s_scale, q_norm2, q_scale, ls,
+                               ws.runid, ws.nrun, ws.m, ws.den, ws.num, B, N, d, n_stiles, n_qtiles,
+                               persistent_qgroup());
+        }
+        NW_CHECK_LAUNCH();
     }
+    return NW_OK;
 }
 }  // namespace
 

@@ -8,9 +8,11 @@ using namespace nw;
 namespace nw {
 size_t fused_layout(int64_t, int64_t, int, char*, FusedWs*) { return 0; }
 int launch_merge_runs(const FusedWs&, float*, float*, float*, float*, float*, int, int, int, int, hipStream_t) { return 0; }
+int launch_run_tables(const FusedWs&, const int64_t*, int, int, int, int, hipStream_t) { return 0; }  // tables are built on the host below
 int pick_rs(int64_t, int64_t, int64_t, bool) { return 10; }
 int device_cu_count() { return 256; }
 bool env_flag(const char*) { return false; }
+bool persistent_two_per_cu() { const char* e = getenv("NW_P2"); return e ? atoi(e) != 0 : true; }
 int persistent_qgroup() { const char* e = getenv("NW_QG"); return e ? atoi(e) : 8; }
 int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d, hipStream_t st);
 }
@@ -37,12 +39,30 @@ int main(int argc, char** argv) {
     hipMemcpy(q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice); hipMemcpy(s, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(sy, hy.data(), N * 8, hipMemcpyHostToDevice); hipMemset(sn, 0, N * 4);
     launch_split_rows(q, qsp, qsc, qn, B, d, 0); launch_split_rows(s, ssp, ssc, sn, N, d, 0);
+    // run tables of the persistent kernel, on the host
+    std::vector<int> h_runid((size_t)n_stiles * BS + 64, 0), h_nrun(n_stiles, 0), h_lab((size_t)n_stiles * BS, -1);
+    for (int stt = 0; stt < n_stiles; ++stt) {
+        int id = -1; long long prev = -2;
+        for (int t = 0; t < BS; ++t) {
+            const int j = stt * BS + t;
+            const long long y = j < N ? hy[j] : -1;
+            if (t == 0 || y != prev) { ++id; h_lab[(size_t)stt * BS + id] = (int)y; }
+            prev = y;
+            h_runid[(size_t)stt * BS + t] = id;
+        }
+        h_nrun[stt] = id + 1;
+    }
+    int* runid; hipMalloc(&runid, h_runid.size() * 4);
+    hipMemcpy(runid, h_runid.data(), h_runid.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(nrun, h_nrun.data(), h_nrun.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(lab, h_lab.data(), h_lab.size() * 4, hipMemcpyHostToDevice);
+    FusedWs wsp; wsp.m = m; wsp.den = den; wsp.nrun = nrun; wsp.lab = lab; wsp.num = num; wsp.runid = runid;
     const int grid = padded_grid(n_stiles, n_qtiles);
     const size_t lds = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&] {
         if (persistent)
-            launch_f16p<RS, 0>(qsp, ssp, sy, sn, ssc, qn, qsc, nullptr, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles, grid, lds, 0);
+            launch_f16p<RS, 0>(qsp, ssp, sy, sn, ssc, qn, qsc, nullptr, wsp, B, N, d, C, n_stiles, n_qtiles, 0);
         else if (f16)
             hipLaunchKernelGGL((nw_fused_kernel<RS, 0, false, MODE_F16>), dim3(grid), dim3(TILE_THREADS), lds, 0, qsp, ssp, sy, sn, ssc, qn, qsc,
                                (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles);
@@ -57,10 +77,11 @@ int main(int argc, char** argv) {
     if (persistent) {
         std::vector<unsigned long long> hp(8 * 1024);
         hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(nw_diag_p), hp.size() * 8);
-        double ph[4] = {0}; int n = 0;
-        for (int b = 0; b < 256; ++b) { ++n; for (int k = 0; k < 4; ++k) ph[k] += (double)hp[8 * b + k]; }
-        printf("persistent kernel %.2f us | per WG (s_memtime ticks): main loops %.0f, header+scan+H %.0f, epilogue %.0f, total %.0f\n",
-               ms * 10, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
+        double ph[8] = {0}; int n = 0;
+        const int nwg = persistent_two_per_cu() ? 512 : 256;
+        for (int b = 0; b < nwg; ++b) { ++n; for (int k = 0; k < 8; ++k) ph[k] += (double)hp[8 * b + k]; }
+        printf("persistent kernel %.2f us | per WG (s_memtime ticks): main loops %.0f | epilogue: header reads+scores %.0f, mask+max %.0f, exp+den %.0f, run sums+stores %.0f, m/den stores %.0f, rest %.0f | total %.0f\n",
+               ms * 10, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, ph[7] / n);
         return 0;
     }
     std::vector<unsigned long long> h(8 * grid);
