@@ -29,12 +29,13 @@ NW_EXTERN_FUSED_KIND(NW_SCORE_DOT)
 NW_EXTERN_FUSED_KIND(NW_SCORE_CLIP)
 #undef NW_EXTERN_FUSED_KIND
 
-bool persistent_two_per_cu() {
+int persistent_variant() {
     static int v = [] {
-        const char* e = getenv("NW_P2");
-        return e ? atoi(e) : 1;
+        const char* e = getenv("NW_PVAR");
+        const int x = e ? atoi(e) : 1;
+        return (x >= 0 && x <= 2) ? x : 1;
     }();
-    return v != 0;
+    return v;
 }
 
 int persistent_qgroup() {
@@ -76,6 +77,7 @@ size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws
     w.lab = reinterpret_cast<int*>(take((size_t)n_stiles * BS * 4));
     w.num = reinterpret_cast<float*>(take((size_t)n_stiles * BS * B * 4));
     w.runid = reinterpret_cast<int*>(take(((size_t)n_stiles * BS + 64) * 4));
+    w.bnd = reinterpret_cast<int*>(take((size_t)n_stiles * 2 * 4));
     if (ws) *ws = w;
     return off;
 }
@@ -221,8 +223,10 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
 // (query tile, support tile) pair.
 __global__ __launch_bounds__(64) void nw_run_tables_kernel(const int64_t* __restrict__ sy, int N, int C, int BS,
                                                            int* __restrict__ runid, int* __restrict__ nrun,
-                                                           int* __restrict__ lab_out) {
+                                                           int* __restrict__ lab_out, int* __restrict__ bnd) {
     const int st = blockIdx.x, lane = threadIdx.x, s0 = st * BS;
+    if (lane < 2) bnd[2 * st + lane] = BS;  // overwritten below when runs 1 / 2 exist (same lane order: see the barrier)
+    __syncthreads();
     int lab[3], flag[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(64) void nw_run_tables_kernel(const int64_t* __rest
         if (t < BS) {
             runid[(size_t)s0 + t] = id;
             if (flag[u]) lab_out[(size_t)s0 + id] = lab[u];
+            if (flag[u] && (id == 1 || id == 2)) bnd[2 * st + id - 1] = t;
             if (t == BS - 1) nrun[st] = id + 1;
         }
     }
@@ -266,7 +271,7 @@ int env_rs() {
 
 int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st) {
     if (BS > 192) return NW_ERR_UNSUPPORTED;  // three rows per lane
-    hipLaunchKernelGGL(nw_run_tables_kernel, dim3(n_stiles), dim3(64), 0, st, sy, N, C, BS, ws.runid, ws.nrun, ws.lab);
+    hipLaunchKernelGGL(nw_run_tables_kernel, dim3(n_stiles), dim3(64), 0, st, sy, N, C, BS, ws.runid, ws.nrun, ws.lab, ws.bnd);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

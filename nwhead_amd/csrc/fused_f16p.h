@@ -30,24 +30,33 @@ namespace {
 
 #ifdef NW_DIAG_FUSED  // diagnostic build only (tools/bench_fused.hip): per-workgroup phase totals
 __device__ unsigned long long nw_diag_p[8 * 1024];
-#define NW_PSTAMP(k)                                              \
-    do {                                                          \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        diag_[k] += now_ - last_;                                 \
-        last_ = now_;                                             \
+#define NW_PSTAMP(k)                                                                         \
+    do {                                                                                     \
+        unsigned long long now_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        diag_[k] += now_ - last_;                                                            \
+        last_ = now_;                                                                        \
     } while (0)
 #else
 #define NW_PSTAMP(k)
 #endif
 
-template <int RS>
+// QB = query blocks (of 16 rows) per consumer wave: the tile is 64*QB queries x 16*RS supports.
+template <int RS, int QB>
 struct PCfg {
     static constexpr int BS = 16 * RS;
+    static constexpr int BQP = 64 * QB;                 // query rows per tile
     static constexpr int N64 = (BS + 63) / 64;          // 64-row DMA pieces per support-side header array
     static constexpr int NH = N64 * 64;                 // entries per support-side array in LDS
-    static constexpr int HDR_F = 3 * NH + 128;          // sn2 | ssc | runid | qn2[64] | qsc[64]
-    static constexpr int NP = 3 * N64 + 2;              // header pieces (256 B each)
+    static constexpr int HDR_F = 3 * NH + 2 * BQP;      // sn2 | ssc | runid | qn2[BQP] | qsc[BQP]
+    static constexpr int NP = 3 * N64 + 2 * QB;         // header pieces (256 B each)
     static constexpr int HPW = (NP + NLOAD - 1) / NLOAD;  // ... per loader wave
+    static constexpr int TILE_F4 = (BQP + BS) * ROW_F4; // one stage: 128 B per row
+    static constexpr int NT = (BQP + BS) / 8;           // stage DMA pieces (1 KB = 8 rows)
+    static constexpr int NI = (NT + NLOAD - 1) / NLOAD; // ... per loader wave (waves lw < NT % NLOAD, or all)
+    static constexpr int NI_LO = NT / NLOAD;
     static constexpr int NHB = 3;                       // header buffers
     static constexpr size_t HDR_BYTES = NHB * (size_t)HDR_F * 4;
     static_assert(HDR_BYTES % 16 == 0, "stage buffers must stay 16-byte aligned");
@@ -55,8 +64,9 @@ struct PCfg {
 
 // Epilogue of one tile for the consumer waves: scores -> tile-local softmax statistics -> run sums.
 // Same arithmetic as fused_epilogue<.., MODE_F16> (fused_impl.h); the header comes from LDS only.
-template <int RS, int KIND>
-__device__ __forceinline__ void epilogue_p(f32x4 (&acc)[RS], const float* hdr, int nrun,
+// A wave owns QB blocks of 16 queries (rows 16*(QB*wave + j) + i of the tile) x all 16*RS supports.
+template <int RS, int KIND, int QB>
+__device__ __forceinline__ void epilogue_p(f32x4 (&acc)[QB][RS], const float* hdr, int nrun, int2 bnd,
                                            const float* __restrict__ logit_scale, float* __restrict__ ws_m,
                                            float* __restrict__ ws_den, float* __restrict__ ws_num, int B, int N,
                                            int q0, int s0, int st, int wave, int lane
@@ -64,7 +74,7 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[RS], const float* hdr, i
                                            , unsigned long long (&diag_)[8], unsigned long long& last_
 #endif
                                            ) {
-    using P = PCfg<RS>;
+    using P = PCfg<RS, QB>;
     constexpr int BS = P::BS;
     constexpr bool NEED_NORM = (KIND != NW_SCORE_DOT);
     constexpr float L2E = 1.44269504088896340736f;
@@ -73,14 +83,10 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[RS], const float* hdr, i
     const float* ssc = hdr + P::NH;
     const int* runid = reinterpret_cast<const int*>(hdr + 2 * P::NH);
     const float* qn2 = hdr + 3 * P::NH;
-    const float* qsc_s = qn2 + 64;
+    const float* qsc_s = qn2 + P::BQP;
     const int i = lane & 15, g = lane >> 4;
-    const int qrow = 16 * wave + i;
-    const int b = q0 + qrow;
     float scale = 1.f;
     if (KIND == NW_SCORE_CLIP) scale = expf(*logit_scale);
-    const float qn = NEED_NORM ? qn2[qrow] : 0.f;
-    const float qsc = qsc_s[qrow];
     // every header vector this lane needs, in one burst of LDS reads
     float4 n4[RS], s4[RS];
 #pragma unroll
@@ -88,103 +94,163 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[RS], const float* hdr, i
         n4[r] = NEED_NORM ? *reinterpret_cast<const float4*>(sn2 + 16 * r + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
         s4[r] = *reinterpret_cast<const float4*>(ssc + 16 * r + 4 * g);
     }
-    float sc[RS][4];
-    if (KIND == NW_SCORE_EUCLIDEAN) {
-        // u = -sqrt(L2E^2 * (qn + sn - 2 dot)), dot = acc * 2^-(e_q + e_s): three packed fp32 ops per pair
-        const f32x2 cq = {-2.f * L2E * L2E * qsc, -2.f * L2E * L2E * qsc};
-        const f32x2 qb = {qn * (L2E * L2E), qn * (L2E * L2E)};
-        const f32x2 l2 = {L2E * L2E, L2E * L2E};
-#pragma unroll
-        for (int r = 0; r < RS; ++r) {
-            const f32x2 k01 = f32x2{s4[r].x, s4[r].y} * cq, k23 = f32x2{s4[r].z, s4[r].w} * cq;
-            const f32x2 b01 = __builtin_elementwise_fma(f32x2{n4[r].x, n4[r].y}, l2, qb);
-            const f32x2 b23 = __builtin_elementwise_fma(f32x2{n4[r].z, n4[r].w}, l2, qb);
-            const f32x2 d01 = __builtin_elementwise_fma(f32x2{acc[r][0], acc[r][1]}, k01, b01);
-            const f32x2 d23 = __builtin_elementwise_fma(f32x2{acc[r][2], acc[r][3]}, k23, b23);
-            sc[r][0] = -fast_sqrt_pos(d01.x);
-            sc[r][1] = -fast_sqrt_pos(d01.y);
-            sc[r][2] = -fast_sqrt_pos(d23.x);
-            sc[r][3] = -fast_sqrt_pos(d23.y);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < RS; ++r) {
-            const float nn[4] = {n4[r].x, n4[r].y, n4[r].z, n4[r].w};
-            const float kk[4] = {s4[r].x * qsc, s4[r].y * qsc, s4[r].z * qsc, s4[r].w * qsc};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sc[r][e] = score_from_dot<KIND>(acc[r][e] * kk[e], qn, nn[e], scale) * L2E;
-        }
-    }
     NW_PSTAMP(1);
-    if (s0 + BS > N) {  // only the last support tile has rows past the bank
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const int qrow = 16 * (QB * wave + j) + i;
+        const int b = q0 + qrow;
+        const float qn = NEED_NORM ? qn2[qrow] : 0.f;
+        const float qsc = qsc_s[qrow];
+        float sc[RS][4];
+        if (KIND == NW_SCORE_EUCLIDEAN) {
+            // u = -sqrt(L2E^2 * (qn + sn - 2 dot)), dot = acc * 2^-(e_q + e_s): three packed fp32 ops per pair
+            const f32x2 cq = {-2.f * L2E * L2E * qsc, -2.f * L2E * L2E * qsc};
+            const f32x2 qb = {qn * (L2E * L2E), qn * (L2E * L2E)};
+            const f32x2 l2 = {L2E * L2E, L2E * L2E};
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const f32x2 k01 = f32x2{s4[r].x, s4[r].y} * cq, k23 = f32x2{s4[r].z, s4[r].w} * cq;
+                const f32x2 b01 = __builtin_elementwise_fma(f32x2{n4[r].x, n4[r].y}, l2, qb);
+                const f32x2 b23 = __builtin_elementwise_fma(f32x2{n4[r].z, n4[r].w}, l2, qb);
+                const f32x2 d01 = __builtin_elementwise_fma(f32x2{acc[j][r][0], acc[j][r][1]}, k01, b01);
+                const f32x2 d23 = __builtin_elementwise_fma(f32x2{acc[j][r][2], acc[j][r][3]}, k23, b23);
+                sc[r][0] = -fast_sqrt_pos(d01.x);
+                sc[r][1] = -fast_sqrt_pos(d01.y);
+                sc[r][2] = -fast_sqrt_pos(d23.x);
+                sc[r][3] = -fast_sqrt_pos(d23.y);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const float nn[4] = {n4[r].x, n4[r].y, n4[r].z, n4[r].w};
+                const float kk[4] = {s4[r].x * qsc, s4[r].y * qsc, s4[r].z * qsc, s4[r].w * qsc};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    sc[r][e] = score_from_dot<KIND>(acc[j][r][e] * kk[e], qn, nn[e], scale) * L2E;
+            }
+        }
+        NW_PSTAMP(2);
+        if (s0 + BS > N) {  // only the last support tile has rows past the bank
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (s0 + 16 * r + 4 * g + e >= N) sc[r][e] = -INFINITY;
+        }
+        // tile-local max: independent chains, then the wave's four lane groups
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int r = 0; r < RS; ++r) mx[r & 3] = fmaxf(mx[r & 3], fmaxf(fmaxf(sc[r][0], sc[r][1]), fmaxf(sc[r][2], sc[r][3])));
+        float mloc = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+        mloc = group4_max(mloc);
 #pragma unroll
         for (int r = 0; r < RS; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (s0 + 16 * r + 4 * g + e >= N) sc[r][e] = -INFINITY;
-    }
-    float mloc = -INFINITY;
+            for (int e = 0; e < 4; ++e) sc[r][e] = __builtin_amdgcn_exp2f(sc[r][e] - mloc);  // 2^-inf = 0 for padded rows
+        NW_PSTAMP(3);
+        // ---- run sums.  A run is a RANGE of tile rows, so with the (wave-uniform) first rows of runs 1
+        // and 2 in hand the membership of row t is a clamped difference: [t < b] = clamp(b - t, 0, 1).
+        // Up to three runs (a class-sorted bank: one or two per tile) that is 2-7 VALU ops per element
+        // and no dependent matrix-core chain; more runs go through the indicator MFMAs.
+        float dloc;
+        auto red4 = [](float x) { return group4_sum(x); };
+        if (nrun <= 3) {
+            float S0[2] = {0.f, 0.f}, S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
+            if (nrun == 1) {
 #pragma unroll
-    for (int r = 0; r < RS; ++r) mloc = fmaxf(mloc, fmaxf(fmaxf(sc[r][0], sc[r][1]), fmaxf(sc[r][2], sc[r][3])));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    NW_PSTAMP(2);
-    float dloc = 0.f;
+                for (int r = 0; r < RS; ++r) {
+                    S0[r & 1] += (sc[r][0] + sc[r][1]) + (sc[r][2] + sc[r][3]);
+                }
+            } else if (nrun == 2) {
+                const float L1 = (float)(bnd.x - 4 * g), M1 = 1.f - L1;
 #pragma unroll
-    for (int r = 0; r < RS; ++r)
+                for (int r = 0; r < RS; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sc[r][e] = __builtin_amdgcn_exp2f(sc[r][e] - mloc);  // 2^-inf = 0 for padded rows
-            dloc += sc[r][e];
-        }
-    dloc += __shfl_xor(dloc, 16);
-    dloc += __shfl_xor(dloc, 32);
-    NW_PSTAMP(3);
-    if (nrun == 1) {  // the whole tile is one class: its run sum is the denominator
-        if (g == 0 && b < B) ws_num[((size_t)st * BS) * B + b] = dloc;
-    } else {
-        // run sums on the matrix cores: indicator (A operand) x E (already in B-operand layout)
-        for (int run_base = 0; run_base < nrun; run_base += 16) {
-            f32x4 Pm = {0.f, 0.f, 0.f, 0.f};
-            const int want = run_base + i;
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = (float)(16 * r + e), ev = sc[r][e];
+                        const float w1 = __builtin_amdgcn_fmed3f(L1 - c, 0.f, 1.f);  // [t <  b1]
+                        const float u1 = __builtin_amdgcn_fmed3f(c + M1, 0.f, 1.f);  // [t >= b1]
+                        S0[e & 1] = __builtin_fmaf(w1, ev, S0[e & 1]);
+                        S1[e & 1] = __builtin_fmaf(u1, ev, S1[e & 1]);
+                    }
+            } else {
+                const float L1 = (float)(bnd.x - 4 * g);
+                const float M2 = 1.f - (float)(bnd.y - 4 * g);
 #pragma unroll
-            for (int r = 0; r < RS; ++r) {
-                const int4 rid = *reinterpret_cast<const int4*>(runid + 16 * r + 4 * g);
-                Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.x == want ? 1.f : 0.f, sc[r][0], Pm, 0, 0, 0);
-                Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.y == want ? 1.f : 0.f, sc[r][1], Pm, 0, 0, 0);
-                Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.z == want ? 1.f : 0.f, sc[r][2], Pm, 0, 0, 0);
-                Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.w == want ? 1.f : 0.f, sc[r][3], Pm, 0, 0, 0);
+                for (int r = 0; r < RS; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = (float)(16 * r + e), ev = sc[r][e];
+                        const float w1 = __builtin_amdgcn_fmed3f(L1 - c, 0.f, 1.f);  // [t <  b1]
+                        const float u2 = __builtin_amdgcn_fmed3f(c + M2, 0.f, 1.f);  // [t >= b2]
+                        S0[e & 1] = __builtin_fmaf(w1, ev, S0[e & 1]);
+                        S2[e & 1] = __builtin_fmaf(u2, ev, S2[e & 1]);
+                        S1[e & 1] = __builtin_fmaf((1.f - w1) - u2, ev, S1[e & 1]);  // exact 0 / 1
+                    }
             }
-            if (b < B) {
+            const float s0v = red4(S0[0] + S0[1]);
+            float s1v = 0.f, s2v = 0.f;
+            if (nrun >= 2) s1v = red4(S1[0] + S1[1]);
+            if (nrun == 3) s2v = red4(S2[0] + S2[1]);
+            dloc = (s0v + s1v) + s2v;
+            if (g == 0 && b < B) {
+                ws_num[((size_t)st * BS) * B + b] = s0v;
+                if (nrun >= 2) ws_num[((size_t)st * BS + 1) * B + b] = s1v;
+                if (nrun == 3) ws_num[((size_t)st * BS + 2) * B + b] = s2v;
+            }
+        } else {
+            float dl[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int run = run_base + 4 * g + j;
-                    if (run < nrun) ws_num[((size_t)st * BS + run) * B + b] = Pm[j];
+            for (int r = 0; r < RS; ++r) dl[r & 3] += (sc[r][0] + sc[r][1]) + (sc[r][2] + sc[r][3]);
+            dloc = red4((dl[0] + dl[1]) + (dl[2] + dl[3]));
+            // run sums on the matrix cores: indicator (A operand) x E (already in B-operand layout)
+            for (int run_base = 0; run_base < nrun; run_base += 16) {
+                f32x4 Pm = {0.f, 0.f, 0.f, 0.f};
+                const int want = run_base + i;
+#pragma unroll
+                for (int r = 0; r < RS; ++r) {
+                    const int4 rid = *reinterpret_cast<const int4*>(runid + 16 * r + 4 * g);
+                    Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.x == want ? 1.f : 0.f, sc[r][0], Pm, 0, 0, 0);
+                    Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.y == want ? 1.f : 0.f, sc[r][1], Pm, 0, 0, 0);
+                    Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.z == want ? 1.f : 0.f, sc[r][2], Pm, 0, 0, 0);
+                    Pm = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.w == want ? 1.f : 0.f, sc[r][3], Pm, 0, 0, 0);
+                }
+                if (b < B) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int run = run_base + 4 * g + jj;
+                        if (run < nrun) ws_num[((size_t)st * BS + run) * B + b] = Pm[jj];
+                    }
                 }
             }
         }
+        NW_PSTAMP(4);
+        if (g == 0 && b < B) {
+            ws_m[(size_t)st * B + b] = mloc;
+            ws_den[(size_t)st * B + b] = dloc;
+        }
+        NW_PSTAMP(5);
     }
-    NW_PSTAMP(4);
-    if (g == 0 && b < B) {
-        ws_m[(size_t)st * B + b] = mloc;
-        ws_den[(size_t)st * B + b] = dloc;
-    }
-    NW_PSTAMP(5);
 }
 
 // TWO = false: one workgroup per CU, 4-buffer ring, double-buffered fragments (<= 256 VGPRs).
 // TWO = true : two workgroups per CU (3-buffer ring: 80 KB of LDS each; single-buffered fragments:
 //              <= 128 VGPRs), so one's epilogue and LDS-read latency run under the other's MFMAs.
-template <int RS, int KIND, bool TWO>
+// QB = 2     : 128-query tiles (one workgroup per CU, single-buffered fragments): per flop 1/3 fewer
+//              bytes through the LDS fill and 44 % fewer LDS read bytes than the 64-query tile -- on
+//              this power-limited loop (header comment) energy per flop is what sets the pace.
+template <int RS, int KIND, bool TWO, int QB>
 __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kernel(
     const float* __restrict__ q, const float* __restrict__ s, const float* __restrict__ s_norm2,
     const float* __restrict__ s_scale, const float* __restrict__ q_norm2, const float* __restrict__ q_scale,
-    const float* __restrict__ logit_scale, const int* __restrict__ ws_runid, const int* __restrict__ ws_nrun,
+    const float* __restrict__ logit_scale, const int* __restrict__ ws_runid, const int* __restrict__ ws_nrun, const int* __restrict__ ws_bnd,
     float* __restrict__ ws_m, float* __restrict__ ws_den, float* __restrict__ ws_num, int B, int N, int d,
     int n_stiles, int n_qtiles, int qg) {
-    using Cfg = DmaCfg<RS>;
-    using P = PCfg<RS>;
-    constexpr int BS = Cfg::BS, TILE_F4 = Cfg::TILE_F4, NI = Cfg::NI, NI_LO = Cfg::NI_LO, NT = Cfg::NT;
+    using P = PCfg<RS, QB>;
+    constexpr int BS = P::BS, BQP = P::BQP, TILE_F4 = P::TILE_F4, NI = P::NI, NI_LO = P::NI_LO, NT = P::NT;
+    constexpr bool SINGLE = TWO || QB > 1;  // single-buffered fragments
+    static_assert(!(TWO && QB > 1), "two 128-query workgroups do not fit the LDS of a CU");
+    static_assert(BQP % (8 * NLOAD) == 0, "query and support pieces must not share a loader round");
     constexpr int NB = TWO ? 3 : 4;  // ring depth
     constexpr int AHEAD = NB - 1;    // stages in flight per loader wave
     static_assert(RS > 5, "the persistent kernel is built for the tall tiles");
@@ -198,7 +264,7 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
     // ---- tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch, one workgroup per CU), and
     // every XCD has its own 4 MiB L2, so each XCD walks its OWN list of tiles in an order that keeps
     // its working set in that L2: XCD x owns the support tiles st = x (mod 8); its list is cut into
-    // groups of `qg` query tiles (kept resident: qg * 128 KB), and inside a group runs support-tile
+    // groups of `qg` query tiles (kept resident: qg * BQP * 2 KB at d = 512), and inside a group runs support-tile
     // major, so the n_cu workgroups of the XCD are on ~n_cu/qg support tiles x qg query tiles at any
     // time.
     const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, n_cu = gridDim.x >> 3;
@@ -227,7 +293,7 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
         auto set_tile = [&](int T) {
             int qt, st;
             decode(T, qt, st);
-            iq0 = qt * BQ;
+            iq0 = qt * BQP;
             is0 = st * BS;
             ist = st;
             irot = st % nk;
@@ -235,7 +301,7 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
             for (int m = 0; m < NI; ++m) {
                 const int R = 8 * (lw + NLOAD * m) + (lane >> 3);
                 const int lslot = (lane & 7) ^ ((R >> 1) & 7);
-                const int grow = (8 * NLOAD * m < BQ) ? min(iq0 + R, B - 1) : min(is0 + R - BQ, N - 1);
+                const int grow = (8 * NLOAD * m < BQP) ? min(iq0 + R, B - 1) : min(is0 + R - BQP, N - 1);
                 voff[m] = ((unsigned)grow * (unsigned)d + lslot * 4) * 4u;
             }
         };
@@ -257,10 +323,10 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
                     if (arr == 0) dma4(s_norm2 + min(row, N - 1), dst);
                     else if (arr == 1) dma4(s_scale + min(row, N - 1), dst);
                     else dma4(ws_runid + (size_t)ist * BS + 64 * c + lane, dst);  // padded by 64 entries
-                } else if (pc == 3 * P::N64) {
-                    dma4(q_norm2 + min(iq0 + lane, B - 1), h + 3 * P::NH);
                 } else {
-                    dma4(q_scale + min(iq0 + lane, B - 1), h + 3 * P::NH + 64);
+                    const int qp = pc - 3 * P::N64, arr = qp / QB, c = qp - arr * QB;  // qn2 pieces, then qsc pieces
+                    const int row = min(iq0 + 64 * c + lane, B - 1);
+                    dma4((arr == 0 ? q_norm2 : q_scale) + row, h + 3 * P::NH + arr * BQP + 64 * c);
                 }
             }
         };
@@ -277,7 +343,7 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
 #endif
             for (int m = 0; m < NI; ++m) {
                 if (NI != NI_LO && m == NI - 1 && lw + NLOAD * m >= NT) break;
-                const char* g = ((8 * NLOAD * m < BQ) ? qb : sb) + voff[m];
+                const char* g = ((8 * NLOAD * m < BQP) ? qb : sb) + voff[m];
 #ifndef NW_ABL_NODMA
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(buf + 64 * (lw + NLOAD * m)),
@@ -319,17 +385,20 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
         // ================================ CONSUMER ================================
         const int i = lane & 15, g = lane >> 4;
         struct Frag {
-            float4 bh, bl;
+            float4 bh[QB], bl[QB];
             float4 ah[RS], al[RS];
         };
-        const int qrow = 16 * wave + i;
         const int rsw = (i >> 1) & 7;
         auto load_frags = [&](Frag& f, int buf) {
             const float4* Qs = stage + ((unsigned)buf % NB) * TILE_F4;
-            const float4* Ss = Qs + BQ * ROW_F4;
+            const float4* Ss = Qs + BQP * ROW_F4;
             const int sh = g ^ rsw, sl = (4 + g) ^ rsw;
-            f.bh = Qs[qrow * ROW_F4 + sh];
-            f.bl = Qs[qrow * ROW_F4 + sl];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                const int qrow = 16 * (QB * wave + j) + i;  // (qrow >> 1) & 7 == rsw: 16-row blocks keep the swizzle
+                f.bh[j] = Qs[qrow * ROW_F4 + sh];
+                f.bl[j] = Qs[qrow * ROW_F4 + sl];
+            }
 #pragma unroll
             for (int r = 0; r < RS; ++r) {
                 f.ah[r] = Ss[(16 * r + i) * ROW_F4 + sh];
@@ -339,16 +408,22 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
         auto mm = [](const float4& a, const float4& b, f32x4 c) {
             return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
         };
-        f32x4 acc[RS];
+        f32x4 acc[QB][RS];
         auto mfma_stage = [&](const Frag& f) {
 #pragma unroll
-            for (int r = 0; r < RS; ++r) acc[r] = mm(f.al[r], f.bh, acc[r]);
+            for (int j = 0; j < QB; ++j)
 #pragma unroll
-            for (int r = 0; r < RS; ++r) acc[r] = mm(f.ah[r], f.bl, acc[r]);
+                for (int r = 0; r < RS; ++r) acc[j][r] = mm(f.al[r], f.bh[j], acc[j][r]);
 #pragma unroll
-            for (int r = 0; r < RS; ++r) acc[r] = mm(f.ah[r], f.bh, acc[r]);
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int r = 0; r < RS; ++r) acc[j][r] = mm(f.ah[r], f.bl[j], acc[j][r]);
+#pragma unroll
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int r = 0; r < RS; ++r) acc[j][r] = mm(f.ah[r], f.bh[j], acc[j][r]);
         };
-        auto interleave = [&]() {
+        auto interleave = [&]() {  // QB == 1 double-buffered loop: MFMA / ds_read alternation
 #pragma unroll
             for (int x = 0; x < 2 * (RS + 1); ++x) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -367,8 +442,9 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
         for (int T = cu; T < n_local; T += n_cu) {
             int qt, st;
             decode(T, qt, st);
-            const int q0 = qt * BQ, s0 = st * BS;
-            const int nrun = ws_nrun[st];  // wave-uniform: a scalar load, used after the main loop
+            const int q0 = qt * BQP, s0 = st * BS;
+            const int nrun = ws_nrun[st];  // wave-uniform: scalar loads, used after the main loop
+            const int2 bnd = *reinterpret_cast<const int2*>(ws_bnd + 2 * (size_t)st);  // first rows of runs 1 and 2
 #ifndef NW_ABL_NOPREFETCH
             // L2 prefetch: the support rows of this workgroup's NEXT tile, one 128-B line per load, the
             // lines dealt round-robin to the workgroups that will share that tile.
@@ -383,8 +459,10 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
 #endif
 
 #pragma unroll
-            for (int r = 0; r < RS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (TWO) {
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int r = 0; r < RS; ++r) acc[j][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SINGLE) {
                 Frag f0;
                 for (int kt = 0; kt < nk; ++kt) {
                     load_frags(f0, gi + kt);
@@ -415,14 +493,14 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
             gi += nk;
             NW_PSTAMP(0);
 #ifndef NW_ABL_NOEPI
-            epilogue_p<RS, KIND>(acc, hdr0 + par * P::HDR_F, nrun, logit_scale, ws_m, ws_den, ws_num, B, N, q0, s0, st,
+            epilogue_p<RS, KIND, QB>(acc, hdr0 + par * P::HDR_F, nrun, bnd, logit_scale, ws_m, ws_den, ws_num, B, N, q0, s0, st,
                                  wave, lane
 #ifdef NW_DIAG_FUSED
                                  , diag_, last_
 #endif
                                  );
 #else
-            if (acc[0][0] + acc[RS - 1][3] == 12345.678f) ws_m[tid] = acc[1][1] + nrun;
+            if (acc[0][0][0] + acc[QB - 1][RS - 1][3] == 12345.678f) ws_m[tid] = acc[0][1][1] + nrun;
 #endif
             par = (par + 1 == P::NHB) ? 0 : par + 1;
             NW_PSTAMP(6);

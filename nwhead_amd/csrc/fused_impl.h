@@ -17,6 +17,7 @@ struct FusedWs {  // views into the caller's workspace
     int* lab;     // [n_stiles][BS]      label of run r (-1: padding / out-of-range label)
     float* num;   // [n_stiles][BS][B]   run sums, rows >= nrun[st] never touched
     int* runid;   // [n_stiles][BS] (+64)  run of every support row inside its tile (persistent kernel only)
+    int* bnd;     // [n_stiles][2]  first tile rows of runs 1 and 2 (BS when there is no such run)
 };
 size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws);
 int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st);
@@ -25,7 +26,7 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
 int device_cu_count();
 bool env_flag(const char* name);
 int persistent_qgroup();  // query tiles kept L2-resident per XCD by the persistent kernel (NW_QG)
-bool persistent_two_per_cu();  // two persistent workgroups per CU (NW_P2=0/1)
+int persistent_variant();  // NW_PVAR = 0: 64-query tiles, one workgroup per CU; 1: two per CU; 2: 128-query tiles
 
 namespace {
 
@@ -153,8 +154,7 @@ __device__ __forceinline__ void fused_epilogue(
             }
         }
         // tile-local max over the wave's 16 query columns: lanes i, i+16, i+32, i+48 hold one query
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        mloc = group4_max(mloc);
     }
 
     // ---- 2^(u - mu) and its sums over the runs of equal labels, on the matrix cores:
@@ -172,8 +172,7 @@ __device__ __forceinline__ void fused_epilogue(
                 sc[r][e] = __builtin_amdgcn_exp2f(sc[r][e] - mloc);  // 2^-inf = 0 for padded rows
                 dloc += sc[r][e];
             }
-        dloc += __shfl_xor(dloc, 16);
-        dloc += __shfl_xor(dloc, 32);
+        dloc = group4_sum(dloc);
         const int nrun = *nrun_s;
         if (nrun == 1) {  // the whole tile is one class: its run sum is the denominator
             if (g == 0 && b < B) ws_num[((size_t)st * BS) * B + b] = dloc;
@@ -385,18 +384,26 @@ int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* 
         const int rc = launch_run_tables(ws, sy, N, C, n_stiles, 16 * RS, st);
         if (rc != NW_OK) return rc;
         const int cus = device_cu_count() & ~7;  // the same number of workgroups on every XCD
-        const size_t tile_bytes = (size_t)DmaCfg<RS>::TILE_F4 * 16;
-        if (persistent_two_per_cu() && PCfg<RS>::HDR_BYTES + 3 * tile_bytes <= 80 * 1024) {
-            hipLaunchKernelGGL((nw_fused_f16p_kernel<RS, KIND, true>), dim3(2 * cus), dim3(TILE_THREADS),
-                               PCfg<RS>::HDR_BYTES + 3 * tile_bytes, st, q, s, s_norm2, s_scale, q_norm2, q_scale, ls,
-                               ws.runid, ws.nrun, ws.m, ws.den, ws.num, B, N, d, n_stiles, n_qtiles,
-                               persistent_qgroup());
+        const int variant = persistent_variant();  // 0: 64-query tiles, 1 workgroup per CU; 1: two per CU; 2: 128-query tiles
+        (void)n_qtiles;
+#define NW_LAUNCH_P(TWO_, QB_, GRID_, NBUF_)                                                                      \
+    do {                                                                                                          \
+        using PC_ = PCfg<RS, QB_>;                                                                                \
+        const size_t lds_ = PC_::HDR_BYTES + (size_t)(NBUF_) * PC_::TILE_F4 * 16;                                 \
+        hipLaunchKernelGGL((nw_fused_f16p_kernel<RS, KIND, TWO_, QB_>), dim3(GRID_), dim3(TILE_THREADS), lds_, st, \
+                           q, s, s_norm2, s_scale, q_norm2, q_scale, ls, ws.runid, ws.nrun, ws.bnd, ws.m, ws.den, ws.num,  \
+                           B, N, d, n_stiles, (B + 64 * (QB_) - 1) / (64 * (QB_)), persistent_qgroup());          \
+    } while (0)
+        constexpr size_t lds_q2 = PCfg<RS, 2>::HDR_BYTES + (size_t)4 * PCfg<RS, 2>::TILE_F4 * 16;
+        constexpr size_t lds_two = PCfg<RS, 1>::HDR_BYTES + (size_t)3 * PCfg<RS, 1>::TILE_F4 * 16;
+        if (variant == 2 && lds_q2 <= 160 * 1024) {
+            NW_LAUNCH_P(false, 2, cus, 4);
+        } else if (variant == 1 && lds_two <= 80 * 1024) {
+            NW_LAUNCH_P(true, 1, 2 * cus, 3);
         } else {
-            hipLaunchKernelGGL((nw_fused_f16p_kernel<RS, KIND, false>), dim3(cus), dim3(TILE_THREADS),
-                               PCfg<RS>::HDR_BYTES + 4 * tile_bytes, st, q, s, s_norm2, s_scale, q_norm2, q_scale, ls,
-                               ws.runid, ws.nrun, ws.m, ws.den, ws.num, B, N, d, n_stiles, n_qtiles,
-                               persistent_qgroup());
+            NW_LAUNCH_P(false, 1, cus, 4);
         }
+#undef NW_LAUNCH_P
         NW_CHECK_LAUNCH();
     }
     return NW_OK;

@@ -95,6 +95,25 @@ __device__ __forceinline__ float fast_exp_neg(float x) {
 // reference's own result has.
 __device__ __forceinline__ float fast_sqrt_pos(float x) { return __builtin_amdgcn_sqrtf(fmaxf(x, 0.f)); }
 
+// Reductions over the four lanes {i, i+16, i+32, i+48} of a wave (the four k-groups of a 16x16 MFMA
+// accumulator column), result in all four.  gfx950's v_permlane{32,16}_swap are plain VALU ops
+// (mov + swap + op = 3 issue slots per step); __shfl_xor goes through ds_bpermute and its LDS round
+// trip (~120 cycles per step, exposed when one wave per SIMD runs an epilogue).
+__device__ __forceinline__ float group4_sum(float x) {
+    typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+    u2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float group4_max(float x) {
+    typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+    u2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // score from (dot, |q|^2, |s|^2); shared by the MFMA and the generic kernels
 template <int KIND>
 __device__ __forceinline__ float score_from_dot(float dot, float qn2, float sn2, float scale) {

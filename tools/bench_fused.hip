@@ -12,7 +12,7 @@ int launch_run_tables(const FusedWs&, const int64_t*, int, int, int, int, hipStr
 int pick_rs(int64_t, int64_t, int64_t, bool) { return 10; }
 int device_cu_count() { return 256; }
 bool env_flag(const char*) { return false; }
-bool persistent_two_per_cu() { const char* e = getenv("NW_P2"); return e ? atoi(e) != 0 : true; }
+int persistent_variant() { const char* e = getenv("NW_PVAR"); return e ? atoi(e) : 1; }
 int persistent_qgroup() { const char* e = getenv("NW_QG"); return e ? atoi(e) : 8; }
 int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d, hipStream_t st);
 }
@@ -40,23 +40,24 @@ int main(int argc, char** argv) {
     hipMemcpy(sy, hy.data(), N * 8, hipMemcpyHostToDevice); hipMemset(sn, 0, N * 4);
     launch_split_rows(q, qsp, qsc, qn, B, d, 0); launch_split_rows(s, ssp, ssc, sn, N, d, 0);
     // run tables of the persistent kernel, on the host
-    std::vector<int> h_runid((size_t)n_stiles * BS + 64, 0), h_nrun(n_stiles, 0), h_lab((size_t)n_stiles * BS, -1);
+    std::vector<int> h_runid((size_t)n_stiles * BS + 64, 0), h_nrun(n_stiles, 0), h_lab((size_t)n_stiles * BS, -1), h_bnd((size_t)n_stiles * 2, BS);
     for (int stt = 0; stt < n_stiles; ++stt) {
         int id = -1; long long prev = -2;
         for (int t = 0; t < BS; ++t) {
             const int j = stt * BS + t;
             const long long y = j < N ? hy[j] : -1;
-            if (t == 0 || y != prev) { ++id; h_lab[(size_t)stt * BS + id] = (int)y; }
+            if (t == 0 || y != prev) { ++id; h_lab[(size_t)stt * BS + id] = (int)y; if (id == 1 || id == 2) h_bnd[2 * stt + id - 1] = t; }
             prev = y;
             h_runid[(size_t)stt * BS + t] = id;
         }
         h_nrun[stt] = id + 1;
     }
     int* runid; hipMalloc(&runid, h_runid.size() * 4);
+    int* bndp; hipMalloc(&bndp, h_bnd.size() * 4); hipMemcpy(bndp, h_bnd.data(), h_bnd.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(runid, h_runid.data(), h_runid.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(nrun, h_nrun.data(), h_nrun.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(lab, h_lab.data(), h_lab.size() * 4, hipMemcpyHostToDevice);
-    FusedWs wsp; wsp.m = m; wsp.den = den; wsp.nrun = nrun; wsp.lab = lab; wsp.num = num; wsp.runid = runid;
+    FusedWs wsp; wsp.m = m; wsp.den = den; wsp.nrun = nrun; wsp.lab = lab; wsp.num = num; wsp.runid = runid; wsp.bnd = bndp;
     const int grid = padded_grid(n_stiles, n_qtiles);
     const size_t lds = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -78,9 +79,9 @@ int main(int argc, char** argv) {
         std::vector<unsigned long long> hp(8 * 1024);
         hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(nw_diag_p), hp.size() * 8);
         double ph[8] = {0}; int n = 0;
-        const int nwg = persistent_two_per_cu() ? 512 : 256;
+        const int nwg = persistent_variant() == 1 ? 512 : 256;
         for (int b = 0; b < nwg; ++b) { ++n; for (int k = 0; k < 8; ++k) ph[k] += (double)hp[8 * b + k]; }
-        printf("persistent kernel %.2f us | per WG (s_memtime ticks): main loops %.0f | epilogue: header reads+scores %.0f, mask+max %.0f, exp+den %.0f, run sums+stores %.0f, m/den stores %.0f, rest %.0f | total %.0f\n",
+        printf("persistent kernel %.2f us | per WG (s_memtime ticks): main loops %.0f | epilogue: header reads %.0f, scores %.0f, mask+max+exp+den %.0f, run sums+stores %.0f, m/den stores %.0f, rest %.0f | total %.0f\n",
                ms * 10, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, ph[7] / n);
         return 0;
     }
