@@ -32,8 +32,8 @@ NW_EXTERN_FUSED_KIND(NW_SCORE_CLIP)
 int persistent_variant() {
     static int v = [] {
         const char* e = getenv("NW_PVAR");
-        const int x = e ? atoi(e) : 1;
-        return (x >= 0 && x <= 2) ? x : 1;
+        const int x = e ? atoi(e) : -1;
+        return (x >= 0 && x <= 2) ? x : -1;  // -1: chosen per launch
     }();
     return v;
 }

@@ -26,7 +26,7 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
 int device_cu_count();
 bool env_flag(const char* name);
 int persistent_qgroup();  // query tiles kept L2-resident per XCD by the persistent kernel (NW_QG)
-int persistent_variant();  // NW_PVAR = 0: 64-query tiles, one workgroup per CU; 1: two per CU; 2: 128-query tiles
+int persistent_variant();  // NW_PVAR = 0: 64-query tiles, one workgroup per CU; 1: two per CU; 2: 128-query tiles; unset: -1
 
 namespace {
 
@@ -384,7 +384,11 @@ int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* 
         const int rc = launch_run_tables(ws, sy, N, C, n_stiles, 16 * RS, st);
         if (rc != NW_OK) return rc;
         const int cus = device_cu_count() & ~7;  // the same number of workgroups on every XCD
-        const int variant = persistent_variant();  // 0: 64-query tiles, 1 workgroup per CU; 1: two per CU; 2: 128-query tiles
+        // 0: 64-query tiles, one workgroup per CU; 1: two per CU; 2: 128-query tiles.  Measured at B = 2048,
+        // N = 50000, d = 512 (tools/bench_fused.hip, same device): 387 / 353 / 337 us.  128-query tiles
+        // unless their padding costs more than 15 % of the rows (then two 64-query workgroups per CU).
+        int variant = persistent_variant();
+        if (variant < 0) variant = ((B + 127) / 128 * 128 <= 1.15 * ((B + 63) / 64 * 64)) ? 2 : 1;
         (void)n_qtiles;
 #define NW_LAUNCH_P(TWO_, QB_, GRID_, NBUF_)                                                                      \
     do {                                                                                                          \

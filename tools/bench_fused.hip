@@ -12,7 +12,7 @@ int launch_run_tables(const FusedWs&, const int64_t*, int, int, int, int, hipStr
 int pick_rs(int64_t, int64_t, int64_t, bool) { return 10; }
 int device_cu_count() { return 256; }
 bool env_flag(const char*) { return false; }
-int persistent_variant() { const char* e = getenv("NW_PVAR"); return e ? atoi(e) : 1; }
+int persistent_variant() { const char* e = getenv("NW_PVAR"); return e ? atoi(e) : 2; }
 int persistent_qgroup() { const char* e = getenv("NW_QG"); return e ? atoi(e) : 8; }
 int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d, hipStream_t st);
 }
