@@ -1,4 +1,5 @@
 // capi.hip -- the extern "C" surface declared in include/nwhead_hip.h (gfx950 / MI355X only).
+#include <cstdlib>
 #include <string.h>
 #include "nw_internal.h"
 
@@ -6,6 +7,14 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool bad_kind(int kind) { return kind < NW_SCORE_EUCLIDEAN || kind > NW_SCORE_CLIP; }
 }  // namespace
+
+// The split-fp16 path adds a launch (splitting the query rows) in front of the tile kernel; below
+// ~2e8 multiply-adds the fp32-MFMA path with cached norms is the shorter one (measured: B=64 N=1000
+// d=512 19.7 vs 29.8 us; B=256 N=10000 d=512 36.1 vs 23.9 us).  NW_SPLIT_ALWAYS=1 forces the split path.
+static bool split_pays(int64_t B, int64_t N, int64_t d) {
+    static const bool always = [] { const char* e = getenv("NW_SPLIT_ALWAYS"); return e && e[0] == '1'; }();
+    return always || (double)B * (double)N * (double)d >= 2.0e8;
+}
 
 extern "C" int nw_abi_version(void) { return NW_ABI_VERSION; }
 
@@ -96,7 +105,7 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, con
     if (N > 0 && C > 0 && !sup_batched && !weights_out && nw::fused_eligible(q, s, B, N, d, C) &&
         (!scores_out || (reinterpret_cast<uintptr_t>(scores_out) & 15) == 0)) {
         if (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C)) return NW_ERR_WORKSPACE;
-        if (s_split && s_scale && s_norm2 && d % 32 == 0 &&
+        if (s_split && s_scale && s_norm2 && d % 32 == 0 && split_pays(B, N, d) &&
             ((reinterpret_cast<uintptr_t>(s_split) | reinterpret_cast<uintptr_t>(q)) & 15) == 0) {
             QSplit qs;
             const int rc = split_queries(q, workspace, workspace_bytes, B, N, d, C, &qs, st);
@@ -134,7 +143,7 @@ extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t*
     float* scores = static_cast<float*>(workspace);
     if (N > 0 && (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C))) return NW_ERR_WORKSPACE;
     if (N > 0 && C > 0 && nw::fused_eligible(q, s, B, N, d, C)) {
-        if (s_split && s_scale && s_norm2 && d % 32 == 0 &&
+        if (s_split && s_scale && s_norm2 && d % 32 == 0 && split_pays(B, N, d) &&
             ((reinterpret_cast<uintptr_t>(s_split) | reinterpret_cast<uintptr_t>(q)) & 15) == 0) {
             QSplit qs;
             const int rc = split_queries(q, workspace, workspace_bytes, B, N, d, C, &qs, st);

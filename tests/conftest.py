@@ -11,6 +11,12 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# The C ABI routes small problems to the fp32 path even when a SplitBank is supplied (capi.hip,
+# split_pays); the parity tests want the split-fp16 kernels on their small shapes, so pin the choice
+# before the library is loaded (it reads the variable once).
+os.environ.setdefault("NW_SPLIT_ALWAYS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
