@@ -168,6 +168,16 @@ int nw_support_influence_f32(const float *probs, const int64_t *qy, const float 
                              const int64_t *sy, float *infl,
                              int64_t B, int64_t N, int64_t C, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics (no reference counterpart): device time of the TILE kernel alone -- the kernel the
+ * roofline is quoted on (nw_fused_kernel / nw_fused_f16p_kernel), without the small kernels around
+ * it (query split, run tables, merge).  While enabled, every forward brackets its tile-kernel launch
+ * with two HIP events on the launch stream; nw_debug_tile_timing_read waits for them, returns their
+ * summed elapsed time and the number of launches since the last read, and clears both.
+ * ------------------------------------------------------------------------------------------- */
+int nw_debug_tile_timing(int enable);
+int nw_debug_tile_timing_read(double *total_us, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

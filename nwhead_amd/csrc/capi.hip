@@ -171,3 +171,9 @@ extern "C" int nw_merge_finalize_f32(const float* m, const float* den, const flo
     return nw::launch_merge(m, den, num, out, G, B, C, stride_m, stride_den, stride_num, class_lo,
                             class_lo ? C_local : C, static_cast<hipStream_t>(stream));
 }
+
+extern "C" int nw_debug_tile_timing(int enable) { return nw::tile_timer_enable(enable != 0); }
+
+extern "C" int nw_debug_tile_timing_read(double* total_us, int64_t* launches) {
+    return nw::tile_timer_read(total_us, launches);
+}

@@ -12,6 +12,9 @@
 //   nw_merge_runs_kernel  per query: rescale every tile to the global max, add run sums into the
 //                     per-class accumulator, write log(num/den + 1e-12) (or the (m, den, num)
 //                     partials of a shard).
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "fused_impl.h"
 
 namespace nw {
@@ -28,6 +31,56 @@ NW_EXTERN_FUSED_KIND(NW_SCORE_COSINE)
 NW_EXTERN_FUSED_KIND(NW_SCORE_DOT)
 NW_EXTERN_FUSED_KIND(NW_SCORE_CLIP)
 #undef NW_EXTERN_FUSED_KIND
+
+// ---- diagnostics: device time of the tile kernel alone (nw_debug_tile_timing*, include/nwhead_hip.h)
+namespace {
+struct TileTimer {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // pairs recorded since the last read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    std::mutex mu;
+} g_tt;
+}  // namespace
+
+int tile_timer_start(hipStream_t st) {
+    if (!g_tt.on) return -1;
+    std::lock_guard<std::mutex> lk(g_tt.mu);
+    std::pair<hipEvent_t, hipEvent_t> p;
+    if (!g_tt.pool.empty()) {
+        p = g_tt.pool.back();
+        g_tt.pool.pop_back();
+    } else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) {
+        return -1;
+    }
+    (void)hipEventRecord(p.first, st);
+    g_tt.ev.push_back(p);
+    return (int)g_tt.ev.size() - 1;
+}
+void tile_timer_stop(int slot, hipStream_t st) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_tt.mu);
+    if (slot < (int)g_tt.ev.size()) (void)hipEventRecord(g_tt.ev[slot].second, st);
+}
+int tile_timer_enable(bool on) {
+    std::lock_guard<std::mutex> lk(g_tt.mu);
+    g_tt.on = on;
+    return NW_OK;
+}
+int tile_timer_read(double* total_us, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_tt.mu);
+    double tot = 0;
+    for (auto& p : g_tt.ev) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.second) != hipSuccess || hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess)
+            return NW_ERR_LAUNCH;
+        tot += (double)ms * 1e3;
+        g_tt.pool.push_back(p);
+    }
+    if (total_us) *total_us = tot;
+    if (launches) *launches = (int64_t)g_tt.ev.size();
+    g_tt.ev.clear();
+    return NW_OK;
+}
 
 int persistent_variant() {
     static int v = [] {

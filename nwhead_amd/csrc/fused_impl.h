@@ -25,6 +25,8 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
                       int B, int C, int n_stiles, int BS, hipStream_t st);
 int device_cu_count();
 bool env_flag(const char* name);
+int tile_timer_start(hipStream_t st);          // diagnostics (nw_debug_tile_timing): -1 when disabled
+void tile_timer_stop(int slot, hipStream_t st);
 int persistent_qgroup();  // query tiles kept L2-resident per XCD by the persistent kernel (NW_QG)
 int persistent_variant();  // NW_PVAR = 0: 64-query tiles, one workgroup per CU; 1: two per CU; 2: 128-query tiles; unset: -1
 
@@ -323,15 +325,20 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
                        q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, scores, ws.m, ws.den, ws.nrun, ws.lab, \
                        ws.num, B, N, d, C,                                                                  \
                        n_stiles, n_qtiles)
+    // many tiles per CU on split operands: the persistent kernel (fused_f16p.h).  RS = 8 is the tallest
+    // tile whose build stays under 256 VGPRs.
+    const bool persistent = s_scale && !scores && RS > 5 && (RS == 8 || env_flag("NW_PERSISTENT_ANY_RS")) &&
+                            grid >= 4 * device_cu_count() && d >= 3 * BK && !env_flag("NW_NO_PERSISTENT");
+    if (persistent) {  // runs of equal labels per support tile: once per launch (ws.runid / nrun / lab / bnd)
+        const int rc = launch_run_tables(ws, sy, N, C, n_stiles, 16 * RS, st);
+        if (rc != NW_OK) return rc;
+    }
+    const int timer_slot = tile_timer_start(st);
     if (s_scale) {  // split-fp16 operands (the caller has checked d % 32 == 0 and supplied everything)
         if (!dma || !s_norm2 || !q_norm2 || !q_scale) return NW_ERR_INVALID_ARG;
         if (scores) {
             NW_LAUNCH(true, MODE_F16, lds_dma);
-        } else if (RS > 5 && (RS == 8 || env_flag("NW_PERSISTENT_ANY_RS")) && grid >= 4 * device_cu_count() &&
-                   d >= 3 * BK && !env_flag("NW_NO_PERSISTENT")) {
-            // many tiles per CU: one persistent workgroup per CU walks them (fused_f16p.h).  RS = 8 is
-            // the tallest tile whose persistent build stays under 256 VGPRs (RS = 10 spills: 469 vs
-            // 445 us non-persistent at B=2048 N=50000, against 437 us for RS = 8 persistent).
+        } else if (persistent) {
             const int rc = launch_f16p<RS, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, ws, B, N, d, C,
                                                  n_stiles, n_qtiles, st);
             if (rc != NW_OK) return rc;
@@ -346,6 +353,7 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
         if (scores) NW_LAUNCH(true, MODE_REG, lds_reg); else NW_LAUNCH(false, MODE_REG, lds_reg);
     }
 #undef NW_LAUNCH
+    tile_timer_stop(timer_slot, st);
     NW_CHECK_LAUNCH();
     return launch_merge_runs(ws, out, lse, m, den, num, B, C, n_stiles, BS, st);
 }
@@ -380,9 +388,7 @@ int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* 
                 const float* q_norm2, const float* q_scale, const float* ls, const FusedWs& ws, int B, int N,
                 int d, int C, int n_stiles, int n_qtiles, hipStream_t st) {
     if constexpr (RS > 5) {
-        // runs of equal labels per support tile: once per launch (ws.runid / ws.nrun / ws.lab)
-        const int rc = launch_run_tables(ws, sy, N, C, n_stiles, 16 * RS, st);
-        if (rc != NW_OK) return rc;
+        (void)sy; (void)C;  // the run tables (launch_run_tables) are the caller's job
         const int cus = device_cu_count() & ~7;  // the same number of workgroups on every XCD
         // 0: 64-query tiles, one workgroup per CU; 1: two per CU; 2: 128-query tiles.  Measured at B = 2048,
         // N = 50000, d = 512 (tools/bench_fused.hip, same device): 387 / 353 / 337 us.  128-query tiles

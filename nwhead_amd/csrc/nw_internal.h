@@ -33,6 +33,8 @@ int launch_merge(const float* m, const float* den, const float* num, float* out,
 int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStream_t st);
 
 // fused forward (fused.hip)
+int tile_timer_enable(bool on);
+int tile_timer_read(double* total_us, int64_t* launches);
 int pick_rs(int64_t B, int64_t N, int64_t d, bool f16 = false);
 bool fused_eligible(const float* q, const float* s, int64_t B, int64_t N, int64_t d, int64_t C);
 size_t fused_workspace_bytes(int64_t B, int64_t N, int64_t d);
