@@ -114,6 +114,55 @@ def measure_influence(B, N, C, dev, iters=100):
             "frac_hbm": nbytes / t / 1e9 / PEAK_HBM_GBS}
 
 
+def measure_backbone_configs(dev):
+    """BASELINE configs[1] and [3] end to end (backbones are torch/MIOpen fp32: plumbing around the head):
+    K2 = ResNet-18 + head, predict over 64 images @224 against a 1000-row bank; K4 = DenseNet-121 training
+    step (joint forward of 32 queries + 10 supports @224, NLL loss, backward through the HIP head, SGD)."""
+    import torch.nn.functional as F
+    from nwhead_amd.model import load_model
+    from nwhead_amd.nwhead.kernel import get_kernel
+    from nwhead_amd.nwhead.nw import NWHead
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    try:
+        net = load_model("resnet18").to(dev).eval()
+        x = torch.randn(64, 3, 224, 224, generator=g).to(dev)
+        s = torch.randn(1000, 512, generator=g).to(dev)
+        sy = (torch.arange(1000) % 200).sort().values.to(dev)
+        head = NWHead(get_kernel("euclidean"), 200)
+
+        def k2():
+            with torch.no_grad():
+                return head(net(x), s, sy)
+        t = time_kernel_events(k2, 10)
+        out["config_K2_resnet18_plus_head"] = {"images": 64, "N": 1000, "ms_per_call": t * 1e3,
+                                               "images_per_s": 64 / t, "backbone": "torch/MIOpen fp32"}
+        del net
+    except Exception as e:                                    # never lose the JSON line to an extra
+        out["config_K2_resnet18_plus_head"] = {"error": repr(e)[:200]}
+    try:
+        dn = load_model("densenet121").to(dev).train()
+        opt = torch.optim.SGD(dn.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4)
+        xq = torch.randn(32, 3, 224, 224, generator=g).to(dev)
+        yq = torch.randint(0, 10, (32,), generator=g).to(dev)
+        xs = torch.randn(10, 3, 224, 224, generator=g).to(dev)
+        ys = torch.arange(10).to(dev)
+        head = NWHead(get_kernel("euclidean"), 10)
+
+        def k4():
+            opt.zero_grad(set_to_none=True)
+            feats = dn(torch.cat((xq, xs)))
+            loss = F.nll_loss(head(feats[:32], feats[32:], ys), yq)
+            loss.backward()
+            opt.step()
+        t = time_kernel_events(k4, 5, warmup=2)
+        out["config_K4_densenet121_train_step"] = {"B": 32, "n_way": 10, "n_shot": 1, "ms_per_step": t * 1e3,
+                                                   "backbone": "torch/MIOpen fp32"}
+    except Exception as e:
+        out["config_K4_densenet121_train_step"] = {"error": repr(e)[:200]}
+    return out
+
+
 def cpu_baseline(B_sample, N, d, C, budget_s=20.0):
     """The reference's op sequence (oracle port) on this host's cores, bounded sample."""
     from oracle import nw_oracle as O
@@ -264,6 +313,7 @@ def main():
             line["north_star_T"] = measure_shape(256, 10000, 512, 200, dev, 100)
             line["config_K2_head"] = measure_shape(64, 1000, 512, 200, dev, 100)
             line["config_K5_support_influence"] = measure_influence(256, 10000, 200, dev)
+            line.update(measure_backbone_configs(dev))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(32, N, d, C)
     if use_dist:
