@@ -169,6 +169,17 @@ int nw_support_influence_f32(const float *probs, const int64_t *qy, const float 
                              int64_t B, int64_t N, int64_t C, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The k best supports per query.  Replaces the full descending argsort that the reference cuts to
+ * its first k columns (KNN.__call__, nwhead/utils.py:185-193; 'knn' / 'hnsw' support modes):
+ *   idx_out[b][0..k) = argsort(scores[b], descending, stable)[0..k)      (ties: lower index first)
+ *   scores   (B,N) fp32 (e.g. from nw_scores_f32)
+ *   idx_out  (B,k) int64;  val_out optional (B,k) fp32: the selected scores, best first
+ * 1 <= k <= min(N, 1024); larger k returns NW_ERR_UNSUPPORTED (callers sort the whole row then).
+ * ------------------------------------------------------------------------------------------- */
+int nw_topk_f32(const float *scores, int64_t *idx_out, float *val_out,
+                int64_t B, int64_t N, int64_t k, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): device time of the TILE kernel alone -- the kernel the
  * roofline is quoted on (nw_fused_kernel / nw_fused_f16p_kernel), without the small kernels around
  * it (query split, run tables, merge).  While enabled, every forward brackets its tile-kernel launch

@@ -172,6 +172,12 @@ extern "C" int nw_merge_finalize_f32(const float* m, const float* den, const flo
                             class_lo ? C_local : C, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int nw_topk_f32(const float* scores, int64_t* idx_out, float* val_out, int64_t B, int64_t N, int64_t k,
+                           void* stream) {
+    if (B < 0 || N < 0 || (B > 0 && (!scores || !idx_out))) return NW_ERR_INVALID_ARG;
+    return nw::launch_topk(scores, idx_out, val_out, B, N, k, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int nw_debug_tile_timing(int enable) { return nw::tile_timer_enable(enable != 0); }
 
 extern "C" int nw_debug_tile_timing_read(double* total_us, int64_t* launches) {

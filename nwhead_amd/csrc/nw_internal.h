@@ -33,6 +33,7 @@ int launch_merge(const float* m, const float* den, const float* num, float* out,
 int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStream_t st);
 
 // fused forward (fused.hip)
+int launch_topk(const float* scores, int64_t* idx, float* vals, int64_t B, int64_t N, int64_t k, hipStream_t st);  // topk.hip
 int tile_timer_enable(bool on);
 int tile_timer_read(double* total_us, int64_t* launches);
 int pick_rs(int64_t B, int64_t N, int64_t d, bool f16 = false);

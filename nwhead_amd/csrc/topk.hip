@@ -1,0 +1,187 @@
+// topk.hip -- the k best supports of every query from a (B,N) score matrix (gfx950 / MI355X only).
+//
+// Replaces the full descending argsort the reference runs for its neighbour modes and then cuts to k
+// columns (KNN.__call__, nwhead/utils.py:185-193; NWNet.get_neighbors, nwhead/nw.py:245-249):
+//   idx[b][0..k) = the first k columns of argsort(scores[b], descending, stable)
+// i.e. best score first, equal scores in ascending index order -- bit-exact, not approximate.
+//
+// One 1024-thread workgroup per row (four independent loads in flight per thread in the histogram passes):
+//   1. radix select on the order-preserving uint image of the floats, four 8-bit digits from the top:
+//      an LDS histogram of the digit among the elements that match the prefix found so far gives the
+//      digit of the k-th largest; lanes of a wave that hit the same bin are merged before the LDS
+//      atomic (the top byte of a score row is almost constant: one hot bin);
+//   2. ordered compaction: every thread owns a CONTIGUOUS index range, counts its elements above the
+//      threshold T and equal to it, a block scan turns the counts into output slots, so the ties that
+//      make it are the lowest-indexed ones;
+//   3. bitonic sort of the (at most 1024) survivors in LDS by (value desc, index asc).
+// A row is read five times (200 KB at N = 50000: L2-resident after the first).
+#include "nw_internal.h"
+
+namespace nw {
+namespace {
+
+constexpr int TK_THREADS = 1024;
+constexpr int TK_MAXK = 1024;
+
+__device__ __forceinline__ unsigned ordered_bits(float f) {  // larger float <=> larger uint; NaN on top
+    unsigned b = __float_as_uint(f);
+    if ((b << 1) == 0) b = 0;  // -0.0 == +0.0: one image, so that their order is the index order
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __restrict__ scores,
+                                                             int64_t* __restrict__ idx_out,
+                                                             float* __restrict__ val_out, int N, int k) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_need;  // prefix of the k-th largest so far; how many of its bin are still needed
+    __shared__ unsigned scan_gt[TK_THREADS], scan_eq[TK_THREADS];
+    __shared__ unsigned cand_u[TK_MAXK];
+    __shared__ int cand_i[TK_MAXK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float* row = scores + (size_t)blockIdx.x * N;
+
+    // ---- 1. radix select of the k-th largest
+    if (tid == 0) {
+        sel_prefix = 0;
+        sel_need = (unsigned)k;
+    }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = sel_prefix;
+        for (int i0 = 0; i0 < N; i0 += 4 * TK_THREADS) {
+            unsigned u4[4];
+            bool ok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // coalesced, independent: four loads in flight
+                const int i = i0 + e * TK_THREADS + tid;
+                ok[e] = i < N;
+                u4[e] = ok[e] ? ordered_bits(row[i]) : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool live = ok[e] && ((pass == 0) || ((u4[e] >> (shift + 8)) == (prefix >> (shift + 8))));
+                const unsigned bin = (u4[e] >> shift) & 255u;
+                // merge the lanes that hit the same bin (two rounds take care of a hot bin), then plain atomics
+                for (int round = 0; round < 2; ++round) {
+                    const unsigned long long act = __ballot(live);
+                    if (!act) break;
+                    const unsigned b0 = __builtin_amdgcn_readlane(bin, __builtin_ctzll(act));
+                    const unsigned long long same = __ballot(live && bin == b0);
+                    if (live && bin == b0) {
+                        if (lane == __builtin_ctzll(same)) atomicAdd(&hist[b0], (unsigned)__builtin_popcountll(same));
+                        live = false;
+                    }
+                }
+                if (live) atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {  // one wave walks the 256 bins from the top: 4 bins per lane
+            unsigned c[4], tot = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                c[j] = hist[255 - (4 * tid + j)];
+                tot += c[j];
+            }
+            unsigned incl = tot;  // inclusive scan over lanes (lane 0 = top bins)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            unsigned before = incl - tot;  // elements in bins above this lane's four
+            const unsigned need = sel_need;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (before < need && before + c[j] >= need) {  // exactly one (lane, j) satisfies this
+                    sel_prefix = prefix | ((unsigned)(255 - (4 * tid + j)) << shift);
+                    sel_need = need - before;
+                }
+                before += c[j];
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned T = sel_prefix;       // ordered bits of the k-th largest element
+    const unsigned n_eq = sel_need;      // how many elements equal to T make it (the lowest-indexed ones)
+    const unsigned n_gt = (unsigned)k - n_eq;
+
+    // ---- 2. ordered compaction over contiguous per-thread index ranges
+    const int per = (N + TK_THREADS - 1) / TK_THREADS;
+    const int lo = min(tid * per, N), hi = min(lo + per, N);
+    unsigned cg = 0, ce = 0;
+    for (int i = lo; i < hi; ++i) {
+        const unsigned u = ordered_bits(row[i]);
+        cg += u > T;
+        ce += u == T;
+    }
+    scan_gt[tid] = cg;
+    scan_eq[tid] = ce;
+    __syncthreads();
+    for (int o = 1; o < TK_THREADS; o <<= 1) {  // inclusive Hillis-Steele scans
+        const unsigned a = tid >= o ? scan_gt[tid - o] : 0, b = tid >= o ? scan_eq[tid - o] : 0;
+        __syncthreads();
+        scan_gt[tid] += a;
+        scan_eq[tid] += b;
+        __syncthreads();
+    }
+    unsigned og = scan_gt[tid] - cg, oe = scan_eq[tid] - ce;  // exclusive offsets
+    for (int i = lo; i < hi; ++i) {
+        const unsigned u = ordered_bits(row[i]);
+        if (u > T) {
+            cand_u[og] = u;
+            cand_i[og] = i;
+            ++og;
+        } else if (u == T) {
+            if (oe < n_eq) {
+                cand_u[n_gt + oe] = u;
+                cand_i[n_gt + oe] = i;
+            }
+            ++oe;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. bitonic sort of the k survivors: value descending, index ascending
+    int P = 1;
+    while (P < k) P <<= 1;
+    for (int x = k + tid; x < P; x += TK_THREADS) {  // padding sorts last
+        cand_u[x] = 0;
+        cand_i[x] = 0x7fffffff;
+    }
+    __syncthreads();
+    auto before = [](unsigned ua, int ia, unsigned ub, int ib) { return ua > ub || (ua == ub && ia < ib); };
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int x = tid; x < P / 2; x += TK_THREADS) {
+                const int a = 2 * x - (x & (stride - 1)), b = a + stride;
+                const bool up = ((a & size) == 0);  // this pair's run is sorted "best first"
+                const unsigned ua = cand_u[a], ub = cand_u[b];
+                const int ia = cand_i[a], ib = cand_i[b];
+                if (before(ub, ib, ua, ia) == up) {
+                    cand_u[a] = ub; cand_i[a] = ib;
+                    cand_u[b] = ua; cand_i[b] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int x = tid; x < k; x += TK_THREADS) {
+        idx_out[(size_t)blockIdx.x * k + x] = cand_i[x];
+        if (val_out) val_out[(size_t)blockIdx.x * k + x] = row[cand_i[x]];
+    }
+}
+
+}  // namespace
+
+int launch_topk(const float* scores, int64_t* idx, float* vals, int64_t B, int64_t N, int64_t k, hipStream_t st) {
+    if (k < 1 || k > N || k > TK_MAXK || N >= (1ll << 31) || B >= (1ll << 31)) return NW_ERR_UNSUPPORTED;
+    if (B == 0) return NW_OK;
+    hipLaunchKernelGGL(nw_topk_kernel, dim3((unsigned)B), dim3(TK_THREADS), 0, st, scores, idx, vals, (int)N, (int)k);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+}  // namespace nw

@@ -115,7 +115,9 @@ class KNN:
     def indices(self, x):
         scores = ops.nw_scores(x, self.data.to(x.device), "euclidean")
         k = min(self.n_neighbors, scores.shape[1])
-        # descending score == ascending distance; stable so ties resolve like argsort would
+        # descending score == ascending distance; ties resolve like a stable argsort would
+        if k <= 1024:
+            return ops.nw_topk(scores, k)                    # radix select: the other N-k are never sorted
         return torch.argsort(scores, dim=-1, descending=True, stable=True)[:, :k]
 
     def __call__(self, x):

@@ -73,6 +73,22 @@ def nw_scores(q, s, kind="euclidean", logit_scale=None):
     return out
 
 
+def nw_topk(scores, k, return_values=False):
+    """scores (B,N) fp32 HIP tensor -> (B,k) int64 column indices, best score first, ties by ascending
+    index: the first k columns of argsort(scores, descending=True, stable=True) (nwhead/utils.py:185-193),
+    without sorting the other N-k.  k <= min(N, 1024)."""
+    _need_hip(scores)
+    lib = _lib.load()
+    sc = _f32c(scores)
+    B, N = sc.shape
+    k = int(k)
+    idx = torch.empty(B, k, dtype=torch.int64, device=sc.device)
+    vals = torch.empty(B, k, dtype=torch.float32, device=sc.device) if return_values else None
+    with torch.cuda.device(sc.device):
+        _lib.check(lib.nw_topk_f32(_ptr(sc), _ptr(idx), _ptr(vals), B, N, k, _stream(sc)), "nw_topk_f32")
+    return (idx, vals) if return_values else idx
+
+
 def row_norm2(x):
     """Squared L2 norm of every row of a (rows,d) fp32 HIP tensor -> (rows,).  Cache this for a support
     bank that does not change between calls and pass it as ``support_norm2``."""

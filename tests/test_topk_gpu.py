@@ -1,0 +1,81 @@
+"""nw_topk_f32 (topk.hip): the first k columns of the reference's full descending argsort
+(KNN.__call__, nwhead/utils.py:185-193), bit-exact, ties in ascending index order."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nwhead_amd import ops
+    return ops
+
+
+def _ref(scores, k):
+    return torch.argsort(scores.cpu(), dim=-1, descending=True, stable=True)[:, :k]
+
+
+@pytest.mark.parametrize("B,N,k", [(1, 1, 1), (3, 5, 5), (7, 64, 10), (16, 1000, 20), (5, 1000, 257),
+                                   (4, 4097, 1024), (32, 50000, 10), (2, 50000, 1000), (9, 333, 1)])
+def test_topk_matches_stable_argsort(dev, ops, B, N, k):
+    g = torch.Generator().manual_seed(B * 131 + N)
+    s = (torch.randn(B, N, generator=g) * 3 - 30).to(dev)          # like -distance: one sign, one exponent
+    idx, vals = ops.nw_topk(s, k, return_values=True)
+    ref = _ref(s, k)
+    assert torch.equal(idx.cpu(), ref)
+    assert torch.equal(vals.cpu(), torch.gather(s.cpu(), 1, ref))
+
+
+def test_topk_ties_and_specials(dev, ops):
+    g = torch.Generator().manual_seed(2)
+    # heavy ties: scores drawn from 7 distinct values; the threshold value is shared by many columns
+    s = torch.randint(-3, 4, (6, 2000), generator=g).float()
+    s[0, :] = 1.5                                                   # a constant row: the first k indices
+    s[1, ::3] = float("inf")
+    s[2, 5] = float("nan")                                          # NaN sorts first, like torch
+    s[3, :] = -s[3, :].abs()
+    s[4, :] = -s[4, :].abs() - 1.0
+    s[4, 40:90:2] = -0.0                                            # -0.0 and +0.0 are equal for torch:
+    s[4, 41:91:2] = 0.0                                             # the zeros come out in index order
+    s = s.to(dev)
+    for k in (1, 8, 100, 777):
+        assert torch.equal(ops.nw_topk(s, k).cpu(), _ref(s, k)), k
+
+
+def test_topk_mixed_signs_and_wide_range(dev, ops):
+    g = torch.Generator().manual_seed(3)
+    s = (torch.randn(8, 30000, generator=g) * torch.logspace(-20, 20, 30000)).to(dev)
+    assert torch.equal(ops.nw_topk(s, 64).cpu(), _ref(s, 64))
+
+
+def test_topk_rejects_large_k(dev, ops):
+    from nwhead_amd._lib import NWHipError
+    with pytest.raises(NWHipError):
+        ops.nw_topk(torch.randn(2, 5000, device=dev), 1025)
+    with pytest.raises(NWHipError):
+        ops.nw_topk(torch.randn(2, 8, device=dev), 9)
+
+
+def test_knn_support_uses_topk(dev, ops):
+    """KNN (the 'knn' / 'hnsw' support modes): same rows as the reference's argsort-and-slice."""
+    from nwhead_amd.nwhead.utils import KNN
+    g = torch.Generator().manual_seed(4)
+    bank = torch.randn(3000, 64, generator=g).to(dev)
+    bank[100] = bank[7]                                            # duplicate rows: exact score ties
+    labels = (torch.arange(3000) % 10).to(dev)
+    q = torch.cat([bank[7:8] + 0.0, torch.randn(5, 64, generator=g).to(dev)])
+    knn = KNN(bank, labels, n_neighbors=20)
+    idx = knn.indices(q)
+    scores = ops.nw_scores(q, bank, "euclidean")
+    assert torch.equal(idx.cpu(), _ref(scores, 20))
+    sx, sy = knn(q)
+    assert sx.shape == (6 * 20, 64) and torch.equal(sy.cpu(), labels.cpu()[idx.cpu().reshape(-1)])
