@@ -86,8 +86,43 @@ class NWNet(nn.Module):
         self.full_norm2 = self.full_cache.norm2
         self.support_eval.build_infer_iters(*info)
 
+    @torch.no_grad()
+    def precompute_sharded(self, group=None, partial_fn=None, merge_fn=None):
+        """'full' inference over a bank sharded across the ranks of `group`: this
+        rank featurises ONLY rows [lo, hi) of the balanced, class-sorted bank -- the row order of
+        precompute() (environments in order, support.py loader order inside) -- and keeps them resident
+        as a ShardedBank; the bank is never gathered.  predict(x, 'full') then exchanges one packed
+        partial per query batch.  The other inference modes still need precompute().
+        partial_fn / merge_fn: compute hooks for the CPU tests (see sharded.ShardedBank)."""
+        import torch.distributed as dist
+        from torch.utils.data import DataLoader, Subset
+        from ..sharded import ShardedBank, shard_bounds
+        assert not self.featurizer.training
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        datasets = self.support_eval.full_datasets
+        lo, hi = shard_bounds(sum(len(ds) for ds in datasets), world, rank)
+        feats, labels, start = [], [], 0
+        for ds in datasets:                                   # this rank's rows of every environment
+            a, b = max(lo, start) - start, min(hi, start + len(ds)) - start
+            start += len(ds)
+            if a >= b:
+                continue
+            for img, label, _meta in DataLoader(Subset(ds, range(a, b)), batch_size=128, shuffle=False):
+                feats.append(self.featurizer(img.to(self.device)).detach())
+                labels.append(label.to(self.device))
+        d = feats[0].shape[1] if feats else self.featurizer(ds[0][0][None].to(self.device)).shape[1]
+        feat = torch.cat(feats) if feats else torch.empty(0, d, device=self.device)
+        y = torch.cat(labels) if labels else torch.empty(0, dtype=torch.int64, device=self.device)
+        self.sharded_bank = ShardedBank(feat, y, self.n_classes, self.kernel.kind, self.kernel._logit_scale(),
+                                        group=group, partial_fn=partial_fn, merge_fn=merge_fn)
+        return self.sharded_bank
+
     def predict(self, x, mode='random'):
         qfeat = self.featurizer(x)
+        if mode == 'full' and getattr(self, 'sharded_bank', None) is not None:
+            out = self.sharded_bank.predict(qfeat.detach())
+            return (out, torch.full((len(x),), True)) if self.return_mask else out
         sfeat, sy = self.support_eval.get_support(mode, x=qfeat)
         if self.debug_mode:
             print('qx shape:', x.shape)

@@ -322,6 +322,9 @@ def test_class_window_merge(dev, ops):
     (1000, 9000, 64, 37, "euclidean", False),     # nk = 2 < pipeline depth, ragged B and N, ~128 runs per tile
     (520, 16500, 512, 200, "cosine", True),       # the bench's d, class-sorted bank (1-2 runs per tile)
     (1030, 8200, 96, 11, "dotproduct", True),
+    (640, 14000, 128, 150, "euclidean", True),    # ~93 rows per class: 2-3 runs per 128-row tile (VALU run sums)
+    (530, 9000, 160, 9, "hypersphere_euclidean", True),
+    (515, 8300, 128, 40, "clip", False),
 ])
 def test_persistent_many_tiles(dev, ops, O, B, N, d, C, kind, sorted_labels):
     """>= 4 tiles per CU with a SplitBank: the persistent kernel (fused_f16p.h: XCD-local tile walk, stage
@@ -334,13 +337,14 @@ def test_persistent_many_tiles(dev, ops, O, B, N, d, C, kind, sorted_labels):
     sy = (sy.sort().values if sorted_labels else sy[torch.randperm(N, generator=g)]).to(dev)
     cache = ops.SplitBank(s)
     assert cache.split is not None
-    out = ops.nw_head(q, s, sy, C, kind, support_cache=cache)
+    ls = _ls(dev) if kind == "clip" else None
+    out = ops.nw_head(q, s, sy, C, kind, ls, support_cache=cache)
     ref = O.nw_head_f64(q.cpu(), s.cpu(), sy.cpu(), C, kind)
     smax = O.scores_f64(q[:64].cpu(), s.cpu(), kind, O.CLIP_LOGIT_SCALE_INIT).abs().max().item()
     atol = max(3e-5, 3e-6 * smax)
     close(out, ref.numpy(), rtol=RTOL, atol=atol)
     # partials of two halves of the bank, merged == the whole
     h = N // 2
-    rows = torch.stack([ops.nw_partials(q, s[:h], sy[:h], C, kind, support_cache=ops.SplitBank(s[:h])).view(-1),
-                        ops.nw_partials(q, s[h:], sy[h:], C, kind, support_cache=ops.SplitBank(s[h:])).view(-1)])
+    rows = torch.stack([ops.nw_partials(q, s[:h], sy[:h], C, kind, ls, support_cache=ops.SplitBank(s[:h])).view(-1),
+                        ops.nw_partials(q, s[h:], sy[h:], C, kind, ls, support_cache=ops.SplitBank(s[h:])).view(-1)])
     close(ops.nw_merge(rows, B, C), ref.numpy(), rtol=RTOL, atol=atol)
