@@ -249,7 +249,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
+    # untimed warm-up: at least W steps, and at least one bucket of every launch shape the timed region
+    # will use (a full bucket, and the shorter last one), so that workspace growth, the packed/gathered
+    # ring buffers and RCCL's first collective of each size stay outside the timed region
+    run(max(args.warmup, args.bucket))
+    if args.steps % args.bucket:
+        run(args.steps % args.bucket)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
