@@ -252,7 +252,7 @@ def main():
     # untimed warm-up: at least W steps, and at least one bucket of every launch shape the timed region
     # will use (a full bucket, and the shorter last one), so that workspace growth, the packed/gathered
     # ring buffers and RCCL's first collective of each size stay outside the timed region
-    run(max(args.warmup, args.bucket))
+    run(max(args.warmup, (3 if use_dist else 1) * args.bucket))   # 3: predict_stream's ring of exchange buffers
     if args.steps % args.bucket:
         run(args.steps % args.bucket)
     barrier()
