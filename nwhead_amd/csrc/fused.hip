@@ -180,11 +180,15 @@ __global__ __launch_bounds__(256) void nw_merge_runs_kernel(
     }
 }
 
+// (Merging inside the tile kernel -- the last workgroup of a query tile does it -- was tried and dropped:
+//  one CU's ~450 dependent-latency loads take 25 us where this kernel's 256 workgroups take 6, and
+//  agent-scope release/acquire fences cost ~40 us per launch on the 8-XCD part.)
 // The same merge for large query batches: one workgroup per MQ = 16 consecutive queries, its 256
 // threads = 16 queries x 16 tile lanes, so every workspace read is a 64-byte run along the query
 // axis (the one-workgroup-per-query kernel above reads 4 bytes per 16 KB stride: 53 us at B = 4096,
 // n_stiles = 391).  Class sums live in LDS as num[class][query].
 constexpr int MQ = 16, ML = 32, MTHREADS = MQ * ML, MU = 4;
+constexpr int MNS = MQ + 1;  // row stride of num[class][query] in LDS: odd, the output phase reads columns
 template <bool PARTIAL>
 __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
     const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
     const int tid = threadIdx.x, bq = tid & (MQ - 1), sl = tid / MQ;
     const int b0 = blockIdx.x * MQ;
     const int b = min(b0 + bq, B - 1);  // rows past the batch repeat the last query and are never written
-    for (int x = tid; x < C * MQ; x += MTHREADS) num[x] = 0.f;
+    for (int x = tid; x < C * MNS; x += MTHREADS) num[x] = 0.f;
 
     float M = -INFINITY;
     for (int t = sl; t < n_stiles; t += ML) M = fmaxf(M, ws_m[(size_t)t * B + b]);
@@ -234,11 +238,11 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
             if (nr[u] < 0) continue;
             const float f = __builtin_amdgcn_exp2f(mm[u] - M);
             den += dd[u] * f;
-            if (nr[u] > 0 && y0[u] >= 0) atomicAdd(&num[y0[u] * MQ + bq], n0[u] * f);
-            if (nr[u] > 1 && y1[u] >= 0) atomicAdd(&num[y1[u] * MQ + bq], n1[u] * f);
+            if (nr[u] > 0 && y0[u] >= 0) atomicAdd(&num[y0[u] * MNS + bq], n0[u] * f);
+            if (nr[u] > 1 && y1[u] >= 0) atomicAdd(&num[y1[u] * MNS + bq], n1[u] * f);
             for (int r = 2; r < nr[u]; ++r) {
                 const int y = ws_lab[(size_t)tt[u] * BS + r];
-                if (y >= 0) atomicAdd(&num[y * MQ + bq], ws_num[((size_t)tt[u] * BS + r) * B + b] * f);
+                if (y >= 0) atomicAdd(&num[y * MNS + bq], ws_num[((size_t)tt[u] * BS + r) * B + b] * f);
             }
         }
     }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
         }
         for (int x = tid; x < nq * C; x += MTHREADS) {
             const int qq = x / C, c = x - qq * C;
-            num_out[(size_t)(b0 + qq) * C + c] = num[c * MQ + qq];
+            num_out[(size_t)(b0 + qq) * C + c] = num[c * MNS + qq];
         }
     } else {
         if (sl == 0) {
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
         __syncthreads();
         for (int x = tid; x < nq * C; x += MTHREADS) {
             const int qq = x / C, c = x - qq * C;
-            out[(size_t)(b0 + qq) * C + c] = logf(num[c * MQ + qq] * inv_s[qq] + NW_LOG_EPS);
+            out[(size_t)(b0 + qq) * C + c] = logf(num[c * MNS + qq] * inv_s[qq] + NW_LOG_EPS);
         }
     }
 }
@@ -331,7 +335,7 @@ int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_
 
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st) {
-    const size_t blds = ((size_t)ML * MQ + MQ + (size_t)C * MQ) * sizeof(float);
+    const size_t blds = ((size_t)ML * MQ + MQ + (size_t)C * MNS) * sizeof(float);
     if (B >= 512 && blds <= 64 * 1024 && !env_flag("NW_MERGE_PER_QUERY")) {
         const int grid = (B + MQ - 1) / MQ;
         if (out)

@@ -41,15 +41,21 @@ struct DmaCfg {
     static constexpr int NT = (BQ + BS) / 8;                 // DMA instructions per stage (1 KB each)
     static constexpr int NI = (NT + NLOAD - 1) / NLOAD;      // ... per loader wave (waves lw < NT % NLOAD, or all)
     static constexpr int NI_LO = NT / NLOAD;                 // ... for the other loader waves
-#ifndef NW_NBUF
-#define NW_NBUF 4
+    // Ring depth: as many stage buffers as the CU's LDS holds next to the header (one workgroup per CU
+    // for the tall tiles, two for RS <= 5), at most 8: NBUF-1 stages are in flight per loader wave, and at
+    // small grids (one tile per CU, e.g. T) the loop is bound by bytes in flight / fill latency.
+    static constexpr size_t STAGE_ONE = (size_t)TILE_F4 * 16;
+    static constexpr size_t LDS_BUDGET = ((RS <= 5) ? 80 : 160) * 1024 - 4096;  // 4 KB: header of the fused kernels
+    static constexpr int NBUF_FIT = (int)(LDS_BUDGET / STAGE_ONE);
+#ifdef NW_NBUF
+    static constexpr int NBUF = NW_NBUF;
+#else
+    static constexpr int NBUF = NBUF_FIT > 8 ? 8 : (NBUF_FIT < 4 ? 4 : NBUF_FIT);
 #endif
-    static constexpr int NBUF = NW_NBUF;                     // ring depth: NBUF-1 stages in flight
-    static constexpr size_t STAGE_BYTES = (size_t)NBUF * TILE_F4 * 16;
+    static constexpr size_t STAGE_BYTES = (size_t)NBUF * STAGE_ONE;
     static constexpr int WAVES_PER_SIMD = (RS <= 5) ? 4 : 2; // launch bound: 128 or 256 VGPRs
+    static_assert((NBUF - 3) * NI < 64, "vmcnt is a 6-bit field");
 };
-constexpr int NBUF_DMA = 4;
-static_assert(NW_NBUF == 4, "ring indexing uses kt & (NBUF-1)");
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -88,7 +94,7 @@ __device__ __forceinline__ void dma_loader_run(const float* __restrict__ q, cons
         auto issue = [&](int kt) {
             int kc = kt + rot;
             if (kc >= nk) kc -= nk;
-            float4* buf = stage + (kt & (NBUF_DMA - 1)) * TILE_F4;
+            float4* buf = stage + ((unsigned)kt % Cfg::NBUF) * TILE_F4;
             const char* qb = reinterpret_cast<const char*>(q) + (size_t)kc * BK * 4;
             const char* sb = reinterpret_cast<const char*>(s) + (size_t)kc * BK * 4;
 #pragma unroll
@@ -193,7 +199,7 @@ __device__ __forceinline__ void tile_dots_dma(const float* __restrict__ q, const
         Frag f0, f1;
         load_frags(f0, 0, 0);
         for (int kt = 0; kt < nk; ++kt) {
-            const int b0 = kt & (NBUF_DMA - 1), b1 = (kt + 1) & (NBUF_DMA - 1);
+            const int b0 = (unsigned)kt % Cfg::NBUF, b1 = (unsigned)(kt + 1) % Cfg::NBUF;
             // sched_barrier(0): keep the fragment reads of the NEXT step in front of this step's MFMAs
             // (hipcc otherwise sinks them behind most of the MFMAs they are meant to hide under)
             load_frags(f1, b0, 1);

@@ -92,17 +92,17 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
             load_frags(f0, 0);
             int kt = 0;
             for (; kt + 2 < nk; kt += 2) {
-                load_frags(f1, (kt + 1) & (Cfg::NBUF - 1));
+                load_frags(f1, (unsigned)(kt + 1) % Cfg::NBUF);
                 mfma_stage(f0);
                 interleave();
                 tile_barrier();
-                load_frags(f0, (kt + 2) & (Cfg::NBUF - 1));
+                load_frags(f0, (unsigned)(kt + 2) % Cfg::NBUF);
                 mfma_stage(f1);
                 interleave();
                 tile_barrier();
             }
             for (; kt < nk; ++kt) {  // tail: one or two stages, nothing further to prefetch
-                if (kt + 1 < nk) load_frags(f1, (kt + 1) & (Cfg::NBUF - 1));
+                if (kt + 1 < nk) load_frags(f1, (unsigned)(kt + 1) % Cfg::NBUF);
                 mfma_stage(f0);
                 tile_barrier();
                 f0 = f1;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
             // cover the LDS latency
             Frag f;
             for (int kt = 0; kt < nk; ++kt) {
-                load_frags(f, kt & (Cfg::NBUF - 1));
+                load_frags(f, (unsigned)kt % Cfg::NBUF);
                 mfma_stage(f);
                 tile_barrier();
             }
