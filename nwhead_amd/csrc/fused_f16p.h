@@ -271,14 +271,11 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
     const int ns_x = (n_stiles - xcd + 7) >> 3;  // support tiles of this XCD
     const int n_local = ns_x * n_qtiles;         // tiles of this XCD
     const int grp_tiles = qg * ns_x;
-    int dec_g = 1, dec_c = 0;  // of the last decode: workgroups sharing the support tile, and this one's rank
     auto decode = [&](int L, int& qt, int& st) {
         const int gi = L / grp_tiles, r = L - gi * grp_tiles;
         const int g = min(qg, n_qtiles - gi * qg);
         const int stl = r / g;
-        dec_g = g;
-        dec_c = r - stl * g;
-        qt = gi * qg + dec_c;
+        qt = gi * qg + (r - stl * g);
         st = stl * 8 + xcd;
     };
 
@@ -445,20 +442,8 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
             const int q0 = qt * BQP, s0 = st * BS;
             const int nrun = ws_nrun[st];  // wave-uniform: scalar loads, used after the main loop
             const int2 bnd = *reinterpret_cast<const int2*>(ws_bnd + 2 * (size_t)st);  // first rows of runs 1 and 2
-#ifdef NW_L2_PREFETCH
-            // (off: measured 342 us with, 329 us without at B=2048 N=50000 d=512 on 128-query tiles -- the
-            //  three-stage LDS pipeline already covers the first touch, the extra requests only cost)
-            // L2 prefetch: the support rows of this workgroup's NEXT tile, one 128-B line per load, the
-            // lines dealt round-robin to the workgroups that will share that tile.
-            if (T + n_cu < n_local) {
-                int nqt, nst;
-                decode(T + n_cu, nqt, nst);
-                const char* nb = reinterpret_cast<const char*>(s) + (size_t)nst * BS * d * 4;
-                const int n_lines = min(BS, N - nst * BS) * nk;
-                for (int x = tid * dec_g + dec_c; x < n_lines; x += 64 * NCONS * dec_g)
-                    (void)*reinterpret_cast<const volatile float*>(nb + (size_t)x * 128);
-            }
-#endif
+            // (an L2 prefetch of the next tile's support rows was measured and dropped: 342 us with, 329 us
+            //  without at B=2048 N=50000 d=512 -- the three-stage LDS pipeline already covers the first touch)
 
 #pragma unroll
             for (int j = 0; j < QB; ++j)
