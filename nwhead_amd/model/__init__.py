@@ -8,3 +8,9 @@ def load_model(name, pretrained=False, **kwargs):
     except AttributeError:
         raise KeyError(name)
     return factory(pretrained=pretrained, **kwargs)
+
+
+def fold_batchnorm(model):
+    """Inference copy of a backbone with conv -> BatchNorm pairs folded (backbones.fold_batchnorm)."""
+    from . import backbones
+    return backbones.fold_batchnorm(model)

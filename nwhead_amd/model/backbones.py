@@ -347,3 +347,40 @@ def densenet201(pretrained=False, progress=True, **kw):
 
 def CIFAR_DenseNet121(pretrained=False, num_classes=10, bias=True, **kw):
     return CIFAR_DenseNet(CifarBottleneck, [6, 12, 24, 16], growth_rate=32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Eval-mode BatchNorm folding.  In ResNet / Bottleneck blocks and the ResNet stem a
+# BatchNorm directly follows a bias-free convolution, so at inference (running statistics) the pair is
+# one convolution: w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps).
+# The pre-activation nets (CIFAR_ResNet blocks, DenseNets) apply BN -> ReLU -> conv and cannot fold.
+# ---------------------------------------------------------------------------------------------
+def _fold_pair(conv, bn):
+    scale = bn.weight.detach() * torch.rsqrt(bn.running_var.detach() + bn.eps)
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                      conv.dilation, conv.groups, bias=True).to(conv.weight.device, conv.weight.dtype)
+    fused.weight.data.copy_(conv.weight.detach() * scale.view(-1, 1, 1, 1))
+    bias = conv.bias.detach() if conv.bias is not None else torch.zeros_like(scale)
+    fused.bias.data.copy_(bn.bias.detach() + (bias - bn.running_mean.detach()) * scale)
+    return fused
+
+
+def fold_batchnorm(model):
+    """A deep copy of `model` (eval mode) in which every conv -> BatchNorm pair of the ResNet family is one
+    convolution; other architectures come back unchanged.  For inference only: the copy shares nothing with
+    the original and must be re-made after the weights change."""
+    import copy
+    m = copy.deepcopy(model).eval()
+    for mod in m.modules():
+        if isinstance(mod, (BasicBlock, Bottleneck, ResNet)) or (isinstance(mod, CIFAR_ResNet) and hasattr(mod, "bn1")):
+            k = 1
+            while hasattr(mod, f"conv{k}") and hasattr(mod, f"bn{k}"):
+                conv, bn = getattr(mod, f"conv{k}"), getattr(mod, f"bn{k}")
+                if isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d):
+                    setattr(mod, f"conv{k}", _fold_pair(conv, bn))
+                    setattr(mod, f"bn{k}", nn.Identity())
+                k += 1
+        ds = getattr(mod, "downsample", None)
+        if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and isinstance(ds[1], nn.BatchNorm2d):
+            mod.downsample = nn.Sequential(_fold_pair(ds[0], ds[1]), nn.Identity())
+    return m

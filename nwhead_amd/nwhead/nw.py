@@ -57,6 +57,27 @@ class NWNet(nn.Module):
                                                  n_way=n_way, env_array=env_array)
             self.process_support_eval(support_dataset)
 
+    # ------------------------------------------------------------------ eval-mode BatchNorm folding
+    def enable_bn_folding(self, on=True):
+        """Inference (precompute / predict / get_neighbors, featurizer in eval mode) then runs a copy of the
+        featurizer whose conv -> BatchNorm pairs are single convolutions (model.fold_batchnorm, SURVEY 8f
+        N1).  The copy is rebuilt by precompute() and dropped by train(); it is not part of state_dict()."""
+        object.__setattr__(self, '_fold_bn', bool(on))
+        object.__setattr__(self, '_folded', None)
+
+    def _eval_featurizer(self, rebuild=False):
+        if not getattr(self, '_fold_bn', False) or self.featurizer.training:
+            return self.featurizer
+        if rebuild or getattr(self, '_folded', None) is None:
+            from ..model import fold_batchnorm
+            object.__setattr__(self, '_folded', fold_batchnorm(self.featurizer))
+        return self._folded
+
+    def train(self, mode=True):
+        if mode and getattr(self, '_fold_bn', False):
+            object.__setattr__(self, '_folded', None)   # the weights are about to change
+        return super().train(mode)
+
     # ------------------------------------------------------------------ evaluation bank
     def process_support_eval(self, support_dataset):
         self.support_eval = SupportSetEval(support_dataset, self.n_classes, self.n_shot_random,
@@ -67,10 +88,11 @@ class NWNet(nn.Module):
     def _compute_all_support_feats(self):
         """Featurise every environment's balanced bank in loader order; rows stay on self.device."""
         per_env = []
+        featurizer = self._eval_featurizer(rebuild=True)
         for loader in self.support_eval.support_loaders:
             f, y, m = [], [], []
             for img, label, meta in loader:
-                f.append(self.featurizer(img.to(self.device)).detach())
+                f.append(featurizer(img.to(self.device)).detach())
                 y.append(label.to(self.device))
                 m.append(meta.to(self.device))
             per_env.append((torch.cat(f), torch.cat(y), torch.cat(m)))
@@ -102,6 +124,7 @@ class NWNet(nn.Module):
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         datasets = self.support_eval.full_datasets
         lo, hi = shard_bounds(sum(len(ds) for ds in datasets), world, rank)
+        featurizer = self._eval_featurizer(rebuild=True)
         feats, labels, start = [], [], 0
         for ds in datasets:                                   # this rank's rows of every environment
             a, b = max(lo, start) - start, min(hi, start + len(ds)) - start
@@ -109,9 +132,9 @@ class NWNet(nn.Module):
             if a >= b:
                 continue
             for img, label, _meta in DataLoader(Subset(ds, range(a, b)), batch_size=128, shuffle=False):
-                feats.append(self.featurizer(img.to(self.device)).detach())
+                feats.append(featurizer(img.to(self.device)).detach())
                 labels.append(label.to(self.device))
-        d = feats[0].shape[1] if feats else self.featurizer(ds[0][0][None].to(self.device)).shape[1]
+        d = feats[0].shape[1] if feats else featurizer(ds[0][0][None].to(self.device)).shape[1]
         feat = torch.cat(feats) if feats else torch.empty(0, d, device=self.device)
         y = torch.cat(labels) if labels else torch.empty(0, dtype=torch.int64, device=self.device)
         self.sharded_bank = ShardedBank(feat, y, self.n_classes, self.kernel.kind, self.kernel._logit_scale(),
@@ -119,7 +142,7 @@ class NWNet(nn.Module):
         return self.sharded_bank
 
     def predict(self, x, mode='random'):
-        qfeat = self.featurizer(x)
+        qfeat = self._eval_featurizer()(x)
         if mode == 'full' and getattr(self, 'sharded_bank', None) is not None:
             out = self.sharded_bank.predict(qfeat.detach())
             return (out, torch.full((len(x),), True)) if self.return_mask else out
@@ -141,7 +164,7 @@ class NWNet(nn.Module):
 
     def get_neighbors(self, x):
         """Support indices ordered from nearest to farthest under the configured kernel."""
-        qfeat = self.featurizer(x).detach()
+        qfeat = self._eval_featurizer()(x).detach()
         scores = self.kernel(qfeat, self.full_feat.to(qfeat.device))
         return torch.argsort(scores, dim=-1, descending=True)
 

@@ -39,3 +39,35 @@ def test_load_model_contract():
     with pytest.raises(KeyError):
         load_model("no_such_net")
     assert load_model("resnet18")(torch.zeros(1, 3, 64, 64)).shape == (1, 512)
+
+
+def test_fold_batchnorm_matches_eval_mode():
+    """model.fold_batchnorm (SURVEY 8f N1): conv -> BN pairs of the ResNet family become one convolution;
+    same eval-mode features up to fp32 re-association; pre-activation nets come back unchanged."""
+    import torch.nn as nn
+    from nwhead_amd.model import fold_batchnorm, load_model
+    from tests.procedural import fill_procedural
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    for name in ("resnet18", "resnet50"):
+        net = load_model(name)
+        fill_procedural(net)
+        net.train()
+        with torch.no_grad():
+            net(torch.randn(4, 3, 64, 64, generator=g))          # move the running statistics off their init
+        net.eval()
+        folded = fold_batchnorm(net)
+        assert not any(isinstance(m, nn.BatchNorm2d) for m in folded.modules())
+        with torch.no_grad():
+            a, b = net(x), folded(x)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * a.abs().max().item()), (a - b).abs().max()
+        assert any(isinstance(m, nn.BatchNorm2d) for m in net.modules())   # the original is untouched
+    x32 = torch.randn(2, 3, 32, 32, generator=g)
+    for name in ("CIFAR_ResNet18", "CIFAR_DenseNet121"):
+        net = load_model(name)
+        fill_procedural(net)
+        net.eval()
+        folded = fold_batchnorm(net)
+        with torch.no_grad():
+            a, b = net(x32), folded(x32)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * a.abs().max().item())

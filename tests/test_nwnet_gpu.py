@@ -88,3 +88,30 @@ def test_errors(net_and_g):
         get_kernel("relationnet")
     with pytest.raises(NotImplementedError):
         net.support_eval.get_support("nope")
+
+
+def test_bn_folding_through_nwnet():
+    """enable_bn_folding(): precompute() / predict() run the folded copy in eval mode, train() drops it, the
+    state_dict is unchanged, and the predictions agree with the unfolded network."""
+    from nwhead_amd.data import SyntheticImages
+    from nwhead_amd.model import load_model
+    from nwhead_amd.nwhead.nw import NWNet
+    from tests.procedural import fill_procedural
+    ds = SyntheticImages(6, 5, 32, seed=2)
+    feat = load_model("CIFAR_ResNet18")
+    fill_procedural(feat)
+    net = NWNet(feat, 5, support_dataset=ds, n_shot_full=6, device="cuda:0").to("cuda:0").eval()
+    x = torch.stack([ds[i][0] for i in range(0, 30, 3)]).to("cuda:0")
+    keys = list(net.state_dict().keys())
+    with torch.no_grad():
+        net.precompute()
+        ref = net.predict(x, "full")
+        net.enable_bn_folding()
+        net.precompute()
+        assert net._folded is not None and not any(isinstance(m, nn.BatchNorm2d) for m in [net._folded.bn1])
+        out = net.predict(x, "full")
+    assert torch.allclose(out, ref, rtol=1e-3, atol=1e-3), (out - ref).abs().max()
+    assert list(net.state_dict().keys()) == keys
+    net.train()
+    assert net._folded is None
+    net.eval()
