@@ -87,7 +87,9 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[QB][RS], const float* hd
     const int i = lane & 15, g = lane >> 4;
     float scale = 1.f;
     if (KIND == NW_SCORE_CLIP) scale = expf(*logit_scale);
-    // every header vector this lane needs, in one burst of LDS reads
+    // every header vector this lane needs, in one burst of LDS reads; then the per-support-row score
+    // factors (nw_internal.h, ScoreFactors), shared by the QB query blocks
+    using SF = ScoreFactors<KIND>;
     float4 n4[RS], s4[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
@@ -95,39 +97,32 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[QB][RS], const float* hd
         s4[r] = *reinterpret_cast<const float4*>(ssc + 16 * r + 4 * g);
     }
     NW_PSTAMP(1);
+    float4 K4[RS], B4[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        SF::support(n4[r].x, s4[r].x, K4[r].x, B4[r].x);
+        SF::support(n4[r].y, s4[r].y, K4[r].y, B4[r].y);
+        SF::support(n4[r].z, s4[r].z, K4[r].z, B4[r].z);
+        SF::support(n4[r].w, s4[r].w, K4[r].w, B4[r].w);
+    }
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         const int qrow = 16 * (QB * wave + j) + i;
         const int b = q0 + qrow;
-        const float qn = NEED_NORM ? qn2[qrow] : 0.f;
-        const float qsc = qsc_s[qrow];
+        float Cq, Bq;
+        SF::query(NEED_NORM ? qn2[qrow] : 0.f, qsc_s[qrow], scale, Cq, Bq);
+        const f32x2 cq = {Cq, Cq}, bq = {Bq, Bq};
         float sc[RS][4];
-        if (KIND == NW_SCORE_EUCLIDEAN) {
-            // u = -sqrt(L2E^2 * (qn + sn - 2 dot)), dot = acc * 2^-(e_q + e_s): three packed fp32 ops per pair
-            const f32x2 cq = {-2.f * L2E * L2E * qsc, -2.f * L2E * L2E * qsc};
-            const f32x2 qb = {qn * (L2E * L2E), qn * (L2E * L2E)};
-            const f32x2 l2 = {L2E * L2E, L2E * L2E};
 #pragma unroll
-            for (int r = 0; r < RS; ++r) {
-                const f32x2 k01 = f32x2{s4[r].x, s4[r].y} * cq, k23 = f32x2{s4[r].z, s4[r].w} * cq;
-                const f32x2 b01 = __builtin_elementwise_fma(f32x2{n4[r].x, n4[r].y}, l2, qb);
-                const f32x2 b23 = __builtin_elementwise_fma(f32x2{n4[r].z, n4[r].w}, l2, qb);
-                const f32x2 d01 = __builtin_elementwise_fma(f32x2{acc[j][r][0], acc[j][r][1]}, k01, b01);
-                const f32x2 d23 = __builtin_elementwise_fma(f32x2{acc[j][r][2], acc[j][r][3]}, k23, b23);
-                sc[r][0] = -fast_sqrt_pos(d01.x);
-                sc[r][1] = -fast_sqrt_pos(d01.y);
-                sc[r][2] = -fast_sqrt_pos(d23.x);
-                sc[r][3] = -fast_sqrt_pos(d23.y);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < RS; ++r) {
-                const float nn[4] = {n4[r].x, n4[r].y, n4[r].z, n4[r].w};
-                const float kk[4] = {s4[r].x * qsc, s4[r].y * qsc, s4[r].z * qsc, s4[r].w * qsc};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    sc[r][e] = score_from_dot<KIND>(acc[j][r][e] * kk[e], qn, nn[e], scale) * L2E;
-            }
+        for (int r = 0; r < RS; ++r) {  // x = acc * (K * Cq) + (Base + Bq): three packed fp32 ops per pair
+            const f32x2 d01 = __builtin_elementwise_fma(f32x2{acc[j][r][0], acc[j][r][1]}, f32x2{K4[r].x, K4[r].y} * cq,
+                                                        f32x2{B4[r].x, B4[r].y} + bq);
+            const f32x2 d23 = __builtin_elementwise_fma(f32x2{acc[j][r][2], acc[j][r][3]}, f32x2{K4[r].z, K4[r].w} * cq,
+                                                        f32x2{B4[r].z, B4[r].w} + bq);
+            sc[r][0] = SF::finish(d01.x);
+            sc[r][1] = SF::finish(d01.y);
+            sc[r][2] = SF::finish(d23.x);
+            sc[r][3] = SF::finish(d23.y);
         }
         NW_PSTAMP(2);
         if (s0 + BS > N) {  // only the last support tile has rows past the bank

@@ -109,24 +109,21 @@ __device__ __forceinline__ void fused_epilogue(
     float sc[RS][4];
     float mloc = -INFINITY;
     if (consumer) {
+        // per-row score factors (nw_internal.h, ScoreFactors): x = acc * K * Cq + (Base + Bq)
+        using SF = ScoreFactors<KIND>;
+        float Cq, Bq;
+        SF::query(qn, qsc, scale, Cq, Bq);
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
-            float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
             if (NEED_NORM) n2 = *reinterpret_cast<const float4*>(sn2 + 16 * r + 4 * g);
-            const float nn[4] = {n2.x, n2.y, n2.z, n2.w};
-            float kk[4] = {1.f, 1.f, 1.f, 1.f};  // MODE_F16: dot = acc * 2^-(e_q + e_s)
-            if (MODE == MODE_F16) {
-                const float4 s4 = *reinterpret_cast<const float4*>(ssc + 16 * r + 4 * g);
-                kk[0] = s4.x * qsc; kk[1] = s4.y * qsc; kk[2] = s4.z * qsc; kk[3] = s4.w * qsc;
-            }
+            if (MODE == MODE_F16) s4 = *reinterpret_cast<const float4*>(ssc + 16 * r + 4 * g);  // 2^-e of the support rows
+            const float nn[4] = {n2.x, n2.y, n2.z, n2.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (KIND == NW_SCORE_EUCLIDEAN) {
-                    const float base = __builtin_fmaf(nn[e], L2E * L2E, qn * (L2E * L2E));
-                    sc[r][e] = -fast_sqrt_pos(__builtin_fmaf(acc[r][e], (-2.f * L2E * L2E) * kk[e], base));
-                } else {
-                    sc[r][e] = score_from_dot<KIND>(acc[r][e] * kk[e], qn, nn[e], scale) * L2E;
-                }
+                float K, Base;
+                SF::support(nn[e], ss[e], K, Base);
+                sc[r][e] = SF::finish(__builtin_fmaf(acc[r][e], K * Cq, Base + Bq));
             }
         }
         if (partial_tile) {

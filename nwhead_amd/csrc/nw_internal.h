@@ -131,4 +131,32 @@ __device__ __forceinline__ float score_from_dot(float dot, float qn2, float sn2,
     return -fast_sqrt_pos(a + b - 2.f * c);
 }
 
+
+// The same scores, factored for the tile epilogues: with per-support-row factors (K, Base), per-query
+// factors (Cq, Bq) and x = acc * K * Cq + (Base + Bq), the score in BASE-2 units (u = score * log2 e) is
+// finish(x).  `acc` is the raw accumulator (for split-fp16 operands the dot product times 2^(e_q + e_s);
+// sscale / qscale = 2^-e of the row, 1 for fp32 operands).  Everything that depends on one row only --
+// square roots, reciprocals, the normalisation of the cosine-type kernels -- is done once per row here
+// instead of once per (query, support) pair; 1/x is v_rcp_f32 (1 ulp), well inside the 1e-5 bar.
+template <int KIND>
+struct ScoreFactors {
+    static constexpr float L2E = 1.44269504088896340736f;
+    static constexpr bool DIST = (KIND == NW_SCORE_EUCLIDEAN || KIND == NW_SCORE_HYPERSPHERE);
+    static constexpr bool NORMALISED = (KIND == NW_SCORE_HYPERSPHERE || KIND == NW_SCORE_COSINE || KIND == NW_SCORE_CLIP);
+    static __device__ __forceinline__ float inv_norm(float n2) {  // 1 / max(|x|, eps), F.normalize's eps
+        return __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(n2), NW_NORM_EPS));
+    }
+    static __device__ __forceinline__ void support(float n2, float sscale, float& K, float& Base) {
+        const float in = NORMALISED ? inv_norm(n2) : 1.f;
+        K = sscale * in * (DIST ? -2.f * L2E * L2E : L2E);
+        Base = DIST ? (NORMALISED ? n2 * in * in : n2) * (L2E * L2E) : 0.f;
+    }
+    static __device__ __forceinline__ void query(float n2, float qscale, float clip_scale, float& Cq, float& Bq) {
+        const float in = NORMALISED ? inv_norm(n2) : 1.f;
+        Cq = qscale * in * (KIND == NW_SCORE_CLIP ? clip_scale : 1.f);
+        Bq = DIST ? (NORMALISED ? n2 * in * in : n2) * (L2E * L2E) : 0.f;
+    }
+    static __device__ __forceinline__ float finish(float x) { return DIST ? -fast_sqrt_pos(x) : x; }
+};
+
 }  // namespace nw
