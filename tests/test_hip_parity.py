@@ -325,6 +325,8 @@ def test_class_window_merge(dev, ops):
     (640, 14000, 128, 150, "euclidean", True),    # ~93 rows per class: 2-3 runs per 128-row tile (VALU run sums)
     (530, 9000, 160, 9, "hypersphere_euclidean", True),
     (515, 8300, 128, 40, "clip", False),
+    (70, 140003, 96, 7, "euclidean", True),       # one (padded) 128-query tile, 1094 support tiles
+    (129, 70001, 128, 3, "cosine", True),         # 129 queries: a 128-query tile plus a 1-row one
 ])
 def test_persistent_many_tiles(dev, ops, O, B, N, d, C, kind, sorted_labels):
     """>= 4 tiles per CU with a SplitBank: the persistent kernel (fused_f16p.h: XCD-local tile walk, stage
