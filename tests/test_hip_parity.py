@@ -350,3 +350,20 @@ def test_persistent_many_tiles(dev, ops, O, B, N, d, C, kind, sorted_labels):
     rows = torch.stack([ops.nw_partials(q, s[:h], sy[:h], C, kind, ls, support_cache=ops.SplitBank(s[:h])).view(-1),
                         ops.nw_partials(q, s[h:], sy[h:], C, kind, ls, support_cache=ops.SplitBank(s[h:])).view(-1)])
     close(ops.nw_merge(rows, B, C), ref.numpy(), rtol=RTOL, atol=atol)
+
+
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_persistent_other_variants(dev, variant):
+    """The library picks the persistent kernel's tile variant once per process (NW_PVAR unset: per launch);
+    the variants that are not the default choice (0: 64-query tiles, one workgroup per CU; 1: two per CU) get
+    a process of their own."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NW_PVAR=variant)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "persistent_many_tiles and (cosine or dotproduct or 640)"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
