@@ -367,3 +367,33 @@ def test_persistent_other_variants(dev, variant):
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_zero_rows_and_tiny_norms(dev, ops, O, kind):
+    """All-zero query / support rows (F.normalize's eps branch for the cosine-type kernels, zero distance
+    for the Euclidean ones) and rows of tiny norm, on the fp32 path and on the split-fp16 path."""
+    g = torch.Generator().manual_seed(9)
+    B, N, d, C = 40, 300, 64, 6
+    q = torch.randn(B, d, generator=g)
+    s = torch.randn(N, d, generator=g)
+    q[3] = 0.0
+    s[7] = 0.0
+    s[8] *= 1e-20
+    q[5] *= 1e-18
+    s[100] = q[9]                                   # an exact duplicate: zero Euclidean distance
+    sy = (torch.arange(N) % C).sort().values
+    ls = _ls(dev) if kind == "clip" else None
+    ref = O.nw_head_f64(q, s, sy, C, kind)
+    qd, sd, syd = q.to(dev), s.to(dev), sy.to(dev)
+    slow = ops.nw_head(qd, sd, syd, C, kind, ls)
+    fast = ops.nw_head(qd, sd, syd, C, kind, ls, support_cache=ops.SplitBank(sd))
+    assert torch.isfinite(slow).all() and torch.isfinite(fast).all()
+    # the duplicate makes one Euclidean distance a difference of equal numbers (noise ~1e-3 in the matmul
+    # form, as in torch's own cdist for N > 25): that query row gets the loose bar
+    loose = np.zeros(B, dtype=bool)
+    loose[9] = kind in ("euclidean", "hypersphere_euclidean")
+    for out in (slow, fast):
+        o = out.cpu().numpy()
+        np.testing.assert_allclose(o[~loose], ref.numpy()[~loose], rtol=RTOL, atol=5e-5)
+        np.testing.assert_allclose(o[loose], ref.numpy()[loose], rtol=1e-2, atol=5e-2)
