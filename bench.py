@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--bucket", type=int, default=0,
                     help="query batches coalesced per launch (and per RCCL all-gather); 0 = 16 x min(gpus, 4): "
                          "a rank's shard shrinks with the rank count, the per-launch fixed costs do not")
+    ap.add_argument("--min-warmup-ms", type=float, default=40.0,
+                    help="the untimed warm-up lasts at least this long (device time): post-idle clock ramp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="only the timed workload (for profiling)")
     args = ap.parse_args()
@@ -252,9 +254,29 @@ def main():
     # untimed warm-up: at least W steps, and at least one bucket of every launch shape the timed region
     # will use (a full bucket, and the shorter last one), so that workspace growth, the packed/gathered
     # ring buffers and RCCL's first collective of each size stay outside the timed region
-    run(max(args.warmup, (3 if use_dist else 1) * args.bucket))   # 3: predict_stream's ring of exchange buffers
+    warm_steps = max(args.warmup, (3 if use_dist else 1) * args.bucket)   # 3: predict_stream's ring of exchange buffers
+    run(warm_steps)
     if args.steps % args.bucket:
         run(args.steps % args.bucket)
+        warm_steps += args.steps % args.bucket
+    # ... and until the device has left its post-idle ramp: measured on MI355X (tools/bucket_times.py),
+    # back-to-back launches of this workload take 886, 684, ... 775 ... 680 (12th) ... 650 (25th) ... 625 us
+    # (40th and on) after an idle period; a serving process sits in the steady state, so the untimed
+    # warm-up runs for at least --min-warmup-ms of device time (the same number of steps on every rank)
+    if args.min_warmup_ms > 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(8 * args.bucket)
+        e1.record()
+        torch.cuda.synchronize()
+        per_step_ms = max(e0.elapsed_time(e1) / (8 * args.bucket), 1e-6)
+        extra = int(max(0.0, args.min_warmup_ms - e0.elapsed_time(e1)) / per_step_ms / args.bucket + 1) * args.bucket
+        if use_dist:                                   # one count for all ranks (collectives inside)
+            cnt = torch.tensor([extra], dtype=torch.int64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+            extra = int(cnt.item())
+        run(extra)
+        warm_steps += 8 * args.bucket + extra
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -306,7 +328,7 @@ def main():
                 "alg_bytes_per_launch": alg_bytes(Bl, n_shard, d, C),
                 "alg_GBps": alg_bytes(Bl, n_shard, d, C) / t_all / 1e9}
         line = {"metric": "query-predictions/sec", "value": args.steps * B / dt, "unit": "query-predictions/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"K3 predict('full'): B={B} queries/step vs bank N={N} d={d} C={C}, "
