@@ -60,12 +60,23 @@ def pmc_traffic():
     return None if best is None else best[1]
 
 
-def time_kernel_events(fn, iters, warmup=3):
-    """Average device time of fn() over `iters` launches on the current stream (HIP events)."""
+def time_kernel_events(fn, iters, warmup=3, min_warm_ms=30.0):
+    """Average device time of fn() over `iters` launches on the current stream (HIP events), taken after
+    `warmup` calls and at least `min_warm_ms` of back-to-back device time (the post-idle clock ramp:
+    see the warm-up comment in main())."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if min_warm_ms > 0:
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        one = max(e0.elapsed_time(e1), 1e-3)
+        for _ in range(min(int(min_warm_ms / one), 200) * iters):   # bounded: host-bound callers stay short
+            fn()
     e0.record()
     for _ in range(iters):
         fn()
@@ -301,8 +312,9 @@ def main():
         import ctypes
         from nwhead_amd import _lib
         lib = _lib.load()
+        time_kernel_events(lambda: bank._partial(pk, qcat), 10)            # (device stays in its steady state)
         lib.nw_debug_tile_timing(1)
-        t_all = time_kernel_events(lambda: bank._partial(pk, qcat), 20)
+        t_all = time_kernel_events(lambda: bank._partial(pk, qcat), 20, warmup=0, min_warm_ms=0)
         tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
         _lib.check(lib.nw_debug_tile_timing_read(ctypes.byref(tot), ctypes.byref(cnt)), "nw_debug_tile_timing_read")
         lib.nw_debug_tile_timing(0)
