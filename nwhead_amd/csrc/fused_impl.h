@@ -40,11 +40,13 @@ namespace {
 enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2, MODE_F16 = 3 };
 
 // Runs of equal consecutive labels inside one support tile, by ONE wave (3 rows per lane): fills
-// runid[t] (run of tile row t), runlab[run] (its class, -1 = padding / out-of-range label) and *nrun.
+// runid[t] (run of tile row t), runlab[run] (its class, -1 = padding / out-of-range label), nrun_s[0] =
+// number of runs and nrun_s[1], nrun_s[2] = first tile rows of runs 1 and 2 (BS when there is none).
 // `lab` = this lane's three labels (tile rows 3*lane .. 3*lane+2), already mapped to -1 when invalid.
 template <int BS>
 __device__ __forceinline__ void run_scan_wave(const int (&lab)[3], int lane, int* runid, int* runlab, int* nrun_s) {
     int flag[3];
+    if (lane < 2) nrun_s[1 + lane] = BS;  // overwritten below by the lane that starts run 1 / run 2 (same wave: in order)
     const int prev_last = __shfl_up(lab[2], 1);
     flag[0] = (lane == 0) || (lab[0] != prev_last);
     flag[1] = lab[1] != lab[0];
@@ -62,6 +64,7 @@ __device__ __forceinline__ void run_scan_wave(const int (&lab)[3], int lane, int
         id += flag[u];
         if (t < BS) {
             runid[t] = id;
+            if (flag[u] && (id == 1 || id == 2)) nrun_s[id] = t;
             if (flag[u]) runlab[id] = lab[u];
             if (t == BS - 1) *nrun_s = id + 1;
         }
@@ -167,32 +170,75 @@ __device__ __forceinline__ void fused_epilogue(
 #pragma unroll
         for (int r = 0; r < RS; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sc[r][e] = __builtin_amdgcn_exp2f(sc[r][e] - mloc);  // 2^-inf = 0 for padded rows
-                dloc += sc[r][e];
-            }
-        dloc = group4_sum(dloc);
-        const int nrun = *nrun_s;
-        if (nrun == 1) {  // the whole tile is one class: its run sum is the denominator
-            if (g == 0 && b < B) ws_num[((size_t)st * BS) * B + b] = dloc;
-        } else
-        for (int run_base = 0; run_base < nrun; run_base += 16) {
-            f32x4 P = {0.f, 0.f, 0.f, 0.f};
-            const int want = run_base + i;
+            for (int e = 0; e < 4; ++e) sc[r][e] = __builtin_amdgcn_exp2f(sc[r][e] - mloc);  // 2^-inf = 0 for padded rows
+        // Run sums.  A run is a RANGE of tile rows: with the first rows b1, b2 of runs 1 and 2 the
+        // membership of row t is a clamped difference, [t < b] = clamp(b - t, 0, 1) -- for up to three
+        // runs (a class-sorted bank has one or two per tile) 2-7 VALU ops per element instead of a
+        // dependent chain of 4*RS fp32 MFMAs; more runs go through the indicator MFMAs.
+        const int nrun = nrun_s[0];
+        if (nrun <= 3) {
+            float S0[2] = {0.f, 0.f}, S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
+            if (nrun == 1) {
 #pragma unroll
-            for (int r = 0; r < RS; ++r) {
-                const int4 rid = *reinterpret_cast<const int4*>(runid + 16 * r + 4 * g);
-                P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.x == want ? 1.f : 0.f, sc[r][0], P, 0, 0, 0);
-                P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.y == want ? 1.f : 0.f, sc[r][1], P, 0, 0, 0);
-                P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.z == want ? 1.f : 0.f, sc[r][2], P, 0, 0, 0);
-                P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.w == want ? 1.f : 0.f, sc[r][3], P, 0, 0, 0);
-            }
-            // P[j] = sum of run (run_base + 4g + j) for query column i
-            if (b < B) {
+                for (int r = 0; r < RS; ++r) S0[r & 1] += (sc[r][0] + sc[r][1]) + (sc[r][2] + sc[r][3]);
+            } else if (nrun == 2) {
+                const float L1 = (float)(nrun_s[1] - 4 * g), M1 = 1.f - L1;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int run = run_base + 4 * g + j;
-                    if (run < nrun) ws_num[((size_t)st * BS + run) * B + b] = P[j];
+                for (int r = 0; r < RS; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = (float)(16 * r + e), ev = sc[r][e];
+                        S0[e & 1] = __builtin_fmaf(__builtin_amdgcn_fmed3f(L1 - c, 0.f, 1.f), ev, S0[e & 1]);  // [t <  b1]
+                        S1[e & 1] = __builtin_fmaf(__builtin_amdgcn_fmed3f(c + M1, 0.f, 1.f), ev, S1[e & 1]);  // [t >= b1]
+                    }
+            } else {
+                const float L1 = (float)(nrun_s[1] - 4 * g);
+                const float M2 = 1.f - (float)(nrun_s[2] - 4 * g);
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = (float)(16 * r + e), ev = sc[r][e];
+                        const float w1 = __builtin_amdgcn_fmed3f(L1 - c, 0.f, 1.f);  // [t <  b1]
+                        const float u2 = __builtin_amdgcn_fmed3f(c + M2, 0.f, 1.f);  // [t >= b2]
+                        S0[e & 1] = __builtin_fmaf(w1, ev, S0[e & 1]);
+                        S2[e & 1] = __builtin_fmaf(u2, ev, S2[e & 1]);
+                        S1[e & 1] = __builtin_fmaf((1.f - w1) - u2, ev, S1[e & 1]);  // exact 0 / 1
+                    }
+            }
+            const float s0v = group4_sum(S0[0] + S0[1]);
+            float s1v = 0.f, s2v = 0.f;
+            if (nrun >= 2) s1v = group4_sum(S1[0] + S1[1]);
+            if (nrun == 3) s2v = group4_sum(S2[0] + S2[1]);
+            dloc = (s0v + s1v) + s2v;
+            if (g == 0 && b < B) {
+                ws_num[((size_t)st * BS) * B + b] = s0v;
+                if (nrun >= 2) ws_num[((size_t)st * BS + 1) * B + b] = s1v;
+                if (nrun == 3) ws_num[((size_t)st * BS + 2) * B + b] = s2v;
+            }
+        } else {
+            float dl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < RS; ++r) dl[r & 3] += (sc[r][0] + sc[r][1]) + (sc[r][2] + sc[r][3]);
+            dloc = group4_sum((dl[0] + dl[1]) + (dl[2] + dl[3]));
+            for (int run_base = 0; run_base < nrun; run_base += 16) {
+                f32x4 P = {0.f, 0.f, 0.f, 0.f};
+                const int want = run_base + i;
+#pragma unroll
+                for (int r = 0; r < RS; ++r) {
+                    const int4 rid = *reinterpret_cast<const int4*>(runid + 16 * r + 4 * g);
+                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.x == want ? 1.f : 0.f, sc[r][0], P, 0, 0, 0);
+                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.y == want ? 1.f : 0.f, sc[r][1], P, 0, 0, 0);
+                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.z == want ? 1.f : 0.f, sc[r][2], P, 0, 0, 0);
+                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.w == want ? 1.f : 0.f, sc[r][3], P, 0, 0, 0);
+                }
+                // P[j] = sum of run (run_base + 4g + j) for query column i
+                if (b < B) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int run = run_base + 4 * g + j;
+                        if (run < nrun) ws_num[((size_t)st * BS + run) * B + b] = P[j];
+                    }
                 }
             }
         }
