@@ -104,7 +104,7 @@ class NWNet(nn.Module):
         assert not self.featurizer.training
         info = self._compute_all_support_feats()
         self.full_feat, self.full_y = info[0], info[1]
-        self.full_cache = ops.SplitBank(self.full_feat)   # norms + split-fp16 rows for predict('full')
+        self.full_cache = ops.SplitBank(self.full_feat, labels=self.full_y)   # norms + split-fp16 rows for predict('full')
         self.full_norm2 = self.full_cache.norm2
         self.support_eval.build_infer_iters(*info)
 

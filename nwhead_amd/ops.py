@@ -104,12 +104,26 @@ def row_norm2(x):
 class SplitBank:
     """A support matrix prepared once for repeated 'full' inference: split-fp16 rows, row scales and
     squared norms (nw_split_rows_f16x2).  Pass it as ``support_cache`` to nw_head / nw_partials.
-    Falls back to norms only (fp32 matrix cores) when d % 32 != 0."""
+    Falls back to norms only (fp32 matrix cores) when d % 32 != 0.
 
-    def __init__(self, s):
-        _need_hip(s)
+    ``labels``: the (N,) labels that will be used with this bank.  The tile kernels sum softmax weights
+    per RUN of equal consecutive labels, so a class-sorted bank (what precompute() builds) costs 1-2 sums
+    per tile and an unsorted one a sum per row (measured 1862 vs 322 us at B=2048, N=50000).  The output
+    does not depend on the order of the supports, so when unsorted labels are given the bank keeps a
+    class-sorted copy (``sorted_rows`` / ``sorted_labels``, stable order) and nw_head runs on that."""
+
+    def __init__(self, s, labels=None):
+        _need_hip(s, labels)
         lib = _lib.load()
         sc = _f32c(s)
+        self.sorted_rows = self.sorted_labels = None
+        if labels is not None and sc.dim() == 2 and labels.dim() == 1 and labels.numel() > 1:
+            lab = labels.detach().to(torch.int64)
+            if bool((lab[1:] < lab[:-1]).any()):
+                perm = torch.argsort(lab, stable=True)
+                self.sorted_rows, self.sorted_labels = sc[perm].contiguous(), lab[perm].contiguous()
+                self._labels_ref = labels          # the label tensor this bank was sorted for (identity check only)
+                sc = self.sorted_rows
         N, d = sc.shape
         self.shape = (N, d)
         self.split = self.scale = None
@@ -122,6 +136,19 @@ class SplitBank:
                                                    N, d, _stream(sc)), "nw_split_rows_f16x2")
         else:
             self.norm2 = row_norm2(sc)
+
+
+def _resolve_sorted_bank(s, sy, cache, per_position_outputs=False):
+    """A SplitBank built from UNSORTED labels holds the split form of its class-sorted copy: run on that
+    copy (same output: the order of the supports does not matter) when the caller passes the very label
+    tensor the bank was built with and wants nothing indexed by support position; otherwise drop the cache
+    (correct, slower) rather than pair split rows with labels in another order."""
+    if cache is None or cache.sorted_rows is None:
+        return s, sy, cache
+    same = sy is cache._labels_ref or (sy.data_ptr() == cache._labels_ref.data_ptr() and sy.shape == cache._labels_ref.shape)
+    if per_position_outputs or not same:
+        return s, sy, None
+    return cache.sorted_rows, cache.sorted_labels, cache
 
 
 class _NoCtx:
@@ -207,6 +234,8 @@ def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weig
         support_norm2 = _f32c(support_norm2)
     if support_cache is not None and (s.dim() != 2 or tuple(s.shape) != support_cache.shape):
         raise ValueError("support_cache was built for a different support")
+    s, sy, support_cache = _resolve_sorted_bank(s, sy, support_cache,
+                                                return_weights or (torch.is_grad_enabled() and s.requires_grad))
     needs_grad = torch.is_grad_enabled() and (q.requires_grad or s.requires_grad or
                                               (logit_scale is not None and logit_scale.requires_grad))
     if not needs_grad:   # inference: skip the autograd node (its bookkeeping costs more than the kernels at small sizes)
@@ -227,6 +256,9 @@ def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None, support
     N = sc.shape[0]
     dev = qc.device
     packed = torch.empty(B, n_classes + 2, dtype=torch.float32, device=dev)
+    sc, syc2, support_cache = _resolve_sorted_bank(sc, sy, support_cache)
+    if syc2 is not sy:
+        syc = syc2
     return nw_partials_into(packed, qc, sc, syc, n_classes, kind, logit_scale, cache=support_cache)
 
 
@@ -246,6 +278,9 @@ def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_sca
     ls = None if logit_scale is None else _f32c(logit_scale)
     ssplit = sscale = None
     if cache is not None:
+        if cache.sorted_rows is not None and sc.data_ptr() != cache.sorted_rows.data_ptr():
+            raise ValueError("this SplitBank holds a class-sorted copy of its support: pass cache.sorted_rows / "
+                             "cache.sorted_labels (or call nw_partials, which does)")
         sn2, ssplit, sscale = cache.norm2, cache.split, cache.scale
     with torch.cuda.device(qc.device):
         _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale),

@@ -397,3 +397,27 @@ def test_zero_rows_and_tiny_norms(dev, ops, O, kind):
         o = out.cpu().numpy()
         np.testing.assert_allclose(o[~loose], ref.numpy()[~loose], rtol=RTOL, atol=5e-5)
         np.testing.assert_allclose(o[loose], ref.numpy()[loose], rtol=1e-2, atol=5e-2)
+
+
+def test_split_bank_sorts_unsorted_labels(dev, ops, O):
+    """SplitBank(s, labels=...) with shuffled labels keeps a class-sorted copy and nw_head runs on it (same
+    output); another label tensor, or a request for per-position weights, falls back to the plain path."""
+    g = torch.Generator().manual_seed(13)
+    B, N, d, C = 48, 3000, 64, 11
+    q = torch.randn(B, d, generator=g).to(dev)
+    s = torch.randn(N, d, generator=g).to(dev)
+    sy = torch.randint(0, C, (N,), generator=g).to(dev)
+    bank = ops.SplitBank(s, labels=sy)
+    assert bank.sorted_rows is not None and bool((bank.sorted_labels[1:] >= bank.sorted_labels[:-1]).all())
+    ref = O.nw_head_f64(q.cpu(), s.cpu(), sy.cpu(), C)
+    close(ops.nw_head(q, s, sy, C, support_cache=bank), ref.numpy(), rtol=RTOL, atol=3e-5)
+    other = sy.roll(1)                                            # a different label tensor: cache not applicable
+    close(ops.nw_head(q, s, other, C, support_cache=bank), O.nw_head_f64(q.cpu(), s.cpu(), other.cpu(), C).numpy(),
+          rtol=RTOL, atol=3e-5)
+    out, w = ops.nw_head(q, s, sy, C, return_weights=True, support_cache=bank)
+    close(out, ref.numpy(), rtol=RTOL, atol=3e-5)
+    assert w.shape == (B, N) and torch.allclose(w.sum(-1).cpu(), torch.ones(B), atol=1e-5)
+    rows = ops.nw_partials(q, s, sy, C, support_cache=bank).view(1, -1)
+    close(ops.nw_merge(rows, B, C), ref.numpy(), rtol=RTOL, atol=3e-5)
+    sorted_bank = ops.SplitBank(s, labels=sy.sort().values)      # already sorted: no copy
+    assert sorted_bank.sorted_rows is None
