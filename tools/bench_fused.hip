@@ -72,7 +72,8 @@ int main(int argc, char** argv) {
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C,
                                n_stiles, n_qtiles);
     };
-    for (int i = 0; i < 5; ++i) launch();
+    const int warm = argc > 6 ? atoi(argv[6]) : 5;   // e.g. 300: past the post-idle clock ramp (~40 ms)
+    for (int i = 0; i < warm; ++i) launch();
     hipEventRecord(e0); for (int i = 0; i < 100; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (persistent) {
