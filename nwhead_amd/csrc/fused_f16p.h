@@ -119,29 +119,34 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[QB][RS], const float* hd
                                                         f32x2{B4[r].x, B4[r].y} + bq);
             const f32x2 d23 = __builtin_elementwise_fma(f32x2{acc[j][r][2], acc[j][r][3]}, f32x2{K4[r].z, K4[r].w} * cq,
                                                         f32x2{B4[r].z, B4[r].w} + bq);
-            sc[r][0] = SF::finish(d01.x);
-            sc[r][1] = SF::finish(d01.y);
-            sc[r][2] = SF::finish(d23.x);
-            sc[r][3] = SF::finish(d23.y);
+            // distance kernels: sc = +distance (u = -sc), extremum = minimum; the others: sc = u, maximum
+            sc[r][0] = SF::finish_abs(d01.x);
+            sc[r][1] = SF::finish_abs(d01.y);
+            sc[r][2] = SF::finish_abs(d23.x);
+            sc[r][3] = SF::finish_abs(d23.y);
         }
         NW_PSTAMP(2);
+        constexpr float WORST = SF::DIST ? INFINITY : -INFINITY;
         if (s0 + BS > N) {  // only the last support tile has rows past the bank
 #pragma unroll
             for (int r = 0; r < RS; ++r)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (s0 + 16 * r + 4 * g + e >= N) sc[r][e] = -INFINITY;
+                    if (s0 + 16 * r + 4 * g + e >= N) sc[r][e] = WORST;
         }
-        // tile-local max: independent chains, then the wave's four lane groups
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        // tile-local extremum: independent chains, then the wave's four lane groups
+        auto best = [](float a, float b) { return SF::DIST ? fminf(a, b) : fmaxf(a, b); };
+        float mx[4] = {WORST, WORST, WORST, WORST};
 #pragma unroll
-        for (int r = 0; r < RS; ++r) mx[r & 3] = fmaxf(mx[r & 3], fmaxf(fmaxf(sc[r][0], sc[r][1]), fmaxf(sc[r][2], sc[r][3])));
-        float mloc = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-        mloc = group4_max(mloc);
+        for (int r = 0; r < RS; ++r) mx[r & 3] = best(mx[r & 3], best(best(sc[r][0], sc[r][1]), best(sc[r][2], sc[r][3])));
+        float ext = best(best(mx[0], mx[1]), best(mx[2], mx[3]));
+        ext = SF::DIST ? group4_min(ext) : group4_max(ext);
+        const float mloc = SF::DIST ? -ext : ext;  // the tile maximum of u
 #pragma unroll
         for (int r = 0; r < RS; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sc[r][e] = __builtin_amdgcn_exp2f(sc[r][e] - mloc);  // 2^-inf = 0 for padded rows
+            for (int e = 0; e < 4; ++e)  // 2^(u - max); 2^-inf = 0 for padded rows
+                sc[r][e] = __builtin_amdgcn_exp2f(SF::DIST ? ext - sc[r][e] : sc[r][e] - ext);
         NW_PSTAMP(3);
         // ---- run sums.  A run is a RANGE of tile rows, so with the (wave-uniform) first rows of runs 1
         // and 2 in hand the membership of row t is a clamped difference: [t < b] = clamp(b - t, 0, 1).

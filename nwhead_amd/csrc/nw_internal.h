@@ -109,12 +109,21 @@ __device__ __forceinline__ float group4_sum(float x) {
     r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float group4_min(float x);
 __device__ __forceinline__ float group4_max(float x) {
     typedef unsigned u2_ __attribute__((ext_vector_type(2)));
     u2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ float group4_min(float x) {
+    typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+    u2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 // score from (dot, |q|^2, |s|^2); shared by the MFMA and the generic kernels
@@ -157,6 +166,9 @@ struct ScoreFactors {
         Bq = DIST ? (NORMALISED ? n2 * in * in : n2) * (L2E * L2E) : 0.f;
     }
     static __device__ __forceinline__ float finish(float x) { return DIST ? -fast_sqrt_pos(x) : x; }
+    // the same without the sign for the distance kernels (u = -finish_abs(x)): the persistent epilogue
+    // carries distances and takes their MINIMUM, which saves one negation per pair
+    static __device__ __forceinline__ float finish_abs(float x) { return DIST ? fast_sqrt_pos(x) : x; }
 };
 
 }  // namespace nw
