@@ -232,6 +232,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # Rehearsal knobs for a one-GPU box (never set by the driver): NW_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and NW_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so that the
+    # multi-rank code path -- shards, class windows, all-gather, merge of G partials -- runs the real kernels.
+    if os.environ.get("NW_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # NW_FORCE_DIST=1 rehearses the RCCL code path on a single rank (the 1-GPU box cannot host two)
@@ -239,7 +244,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("NW_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from nwhead_amd import ops
     from nwhead_amd.sharded import ShardedBank, shard_bounds
