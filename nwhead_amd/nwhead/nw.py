@@ -58,11 +58,14 @@ class NWNet(nn.Module):
             self.process_support_eval(support_dataset)
 
     # ------------------------------------------------------------------ eval-mode BatchNorm folding
-    def enable_bn_folding(self, on=True):
+    def enable_bn_folding(self, on=True, channels_last=True):
         """Inference (precompute / predict / get_neighbors, featurizer in eval mode) then runs a copy of the
         featurizer whose conv -> BatchNorm pairs are single convolutions (model.fold_batchnorm, SURVEY 8f
-        N1).  The copy is rebuilt by precompute() and dropped by train(); it is not part of state_dict()."""
+        N1), kept in channels_last layout (MIOpen's faster fp32 path: ResNet-18 over 64 images @224
+        3.81 -> 3.55 ms folded -> 3.22 ms folded + channels_last, features equal to 3e-7 relative).  The copy
+        is rebuilt by precompute() and dropped by train(); it is not part of state_dict()."""
         object.__setattr__(self, '_fold_bn', bool(on))
+        object.__setattr__(self, '_fold_cl', bool(channels_last))
         object.__setattr__(self, '_folded', None)
 
     def _eval_featurizer(self, rebuild=False):
@@ -70,7 +73,14 @@ class NWNet(nn.Module):
             return self.featurizer
         if rebuild or getattr(self, '_folded', None) is None:
             from ..model import fold_batchnorm
-            object.__setattr__(self, '_folded', fold_batchnorm(self.featurizer))
+            folded = fold_batchnorm(self.featurizer)
+            if getattr(self, '_fold_cl', False):
+                inner = folded.to(memory_format=torch.channels_last)
+
+                def folded(x, _m=inner):
+                    return _m(x.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x)
+                folded.bn1 = getattr(inner, 'bn1', None)
+            object.__setattr__(self, '_folded', folded)
         return self._folded
 
     def train(self, mode=True):
