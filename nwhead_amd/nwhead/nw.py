@@ -15,6 +15,17 @@ from .kernel import _ScoreModule, get_kernel
 from .support import SupportSetEval, SupportSetTrain
 
 
+class _ChannelsLast(nn.Module):
+    """An inference copy of a backbone kept in channels_last layout; 4-D inputs are converted on the way in."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner.to(memory_format=torch.channels_last)
+
+    def forward(self, x):
+        return self.inner(x.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x)
+
+
 class NWHead(nn.Module):
     """forward(x:(B,d), sx:(N,d)|(B,N,d), sy:(N,)|(B,N)) -> (B, n_classes) log-probabilities."""
 
@@ -75,11 +86,7 @@ class NWNet(nn.Module):
             from ..model import fold_batchnorm
             folded = fold_batchnorm(self.featurizer)
             if getattr(self, '_fold_cl', False):
-                inner = folded.to(memory_format=torch.channels_last)
-
-                def folded(x, _m=inner):
-                    return _m(x.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x)
-                folded.bn1 = getattr(inner, 'bn1', None)
+                folded = _ChannelsLast(folded)
             object.__setattr__(self, '_folded', folded)
         return self._folded
 

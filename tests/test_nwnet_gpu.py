@@ -108,7 +108,8 @@ def test_bn_folding_through_nwnet():
         ref = net.predict(x, "full")
         net.enable_bn_folding()
         net.precompute()
-        assert net._folded is not None and not any(isinstance(m, nn.BatchNorm2d) for m in [net._folded.bn1])
+        assert net._folded is not None
+        assert not any(isinstance(m, nn.BatchNorm2d) and m is not None for m in [getattr(net._folded.inner, 'bn1', None)])
         out = net.predict(x, "full")
     assert torch.allclose(out, ref, rtol=1e-3, atol=1e-3), (out - ref).abs().max()
     assert list(net.state_dict().keys()) == keys
