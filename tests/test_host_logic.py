@@ -79,3 +79,20 @@ def test_kernel_factory_contract():
     assert abs(float(get_kernel("clip").logit_scale) - np.log(1 / 0.07)) < 1e-6
     with pytest.raises(NotImplementedError):
         get_kernel("relationnet")
+
+
+def test_dropin_import_paths():
+    """The reference's import lines (train.py:13-19, README usage) resolve to this implementation when
+    dropin/ is ahead of everything else on the path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from nwhead.nw import NWNet, NWHead; from nwhead.kernel import get_kernel; from model import load_model; "
+            "from util.metric import support_influence, Metric, ECELoss; from util.utils import save_checkpoint, load_checkpoint; "
+            "import nwhead_amd.nwhead.nw as a; assert NWNet is a.NWNet; "
+            "m = load_model('resnet18'); print(type(m).__name__, type(get_kernel('euclidean')).__name__)")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "dropin"), root]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp", timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert r.stdout.split()[0] == "ResNet"
