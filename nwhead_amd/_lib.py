@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnwhead_hip.so")
+# NW_HIP_LIB: another build of the same library (A/B timing of kernel variants on one device)
+LIB_PATH = os.environ.get("NW_HIP_LIB") or os.path.join(_HERE, "csrc", "libnwhead_hip.so")
 
 SCORE_KINDS = {"euclidean": 0, "hypersphere_euclidean": 1, "cosine": 2, "dotproduct": 3, "clip": 4}
 

@@ -473,21 +473,32 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
 #pragma unroll
                     for (int r = 0; r < RS; ++r) f.ah[r] = Ss[(16 * r + i) * ROW_F4 + sh];
                 };
+                // MFMA order: a boustrophedon walk over the (support block, query block) grid, so that
+                // consecutive MFMAs share one of their two operand registers
                 auto group1 = [&](const F1& a) {
 #pragma unroll
-                    for (int j = 0; j < QB; ++j)
+                    for (int r = 0; r < RS; ++r)
 #pragma unroll
-                        for (int r = 0; r < RS; ++r) acc[j][r] = mm(a.al[r], a.bh[j], acc[j][r]);
+                        for (int jx = 0; jx < QB; ++jx) {
+                            const int j = (r & 1) ? QB - 1 - jx : jx;
+                            acc[j][r] = mm(a.al[r], a.bh[j], acc[j][r]);
+                        }
                 };
                 auto group23 = [&](const F1& a, const F2& b) {
 #pragma unroll
-                    for (int j = 0; j < QB; ++j)
+                    for (int r = 0; r < RS; ++r)
 #pragma unroll
-                        for (int r = 0; r < RS; ++r) acc[j][r] = mm(b.ah[r], b.bl[j], acc[j][r]);
+                        for (int jx = 0; jx < QB; ++jx) {
+                            const int j = (r & 1) ? QB - 1 - jx : jx;
+                            acc[j][r] = mm(b.ah[r], b.bl[j], acc[j][r]);
+                        }
 #pragma unroll
-                    for (int j = 0; j < QB; ++j)
+                    for (int r = RS - 1; r >= 0; --r)
 #pragma unroll
-                        for (int r = 0; r < RS; ++r) acc[j][r] = mm(b.ah[r], a.bh[j], acc[j][r]);
+                        for (int jx = 0; jx < QB; ++jx) {
+                            const int j = (r & 1) ? jx : QB - 1 - jx;
+                            acc[j][r] = mm(b.ah[r], a.bh[j], acc[j][r]);
+                        }
                 };
                 F1 a0, a1;
                 F2 b0;
