@@ -263,8 +263,14 @@ def main():
     qs = [torch.randn(B, d, generator=gq).to(dev) for _ in range(4)]
 
     def run(nsteps):
-        # same code path at every N: buckets of query batches coalesced per launch (sharded.py)
-        return bank.predict_stream([qs[i % 4] for i in range(nsteps)], bucket=args.bucket)[-1]
+        # same code path at every N: buckets of query batches coalesced per launch (sharded.py); long
+        # (warm-up) runs go in chunks of 32 buckets so that the list of outputs stays small
+        chunk = 32 * args.bucket
+        out = None
+        for i0 in range(0, nsteps, chunk):
+            n = min(chunk, nsteps - i0)
+            out = bank.predict_stream([qs[i % 4] for i in range(n)], bucket=args.bucket)[-1]
+        return out
 
     def barrier():
         if use_dist:
