@@ -206,8 +206,8 @@ def cpu_baseline(B_sample, N, d, C, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--bank", type=int, default=50000)
     ap.add_argument("--dim", type=int, default=512)
