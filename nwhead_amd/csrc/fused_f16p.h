@@ -298,8 +298,9 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
             for (int m = 0; m < NI; ++m) {
                 const int R = 8 * (lw + NLOAD * m) + (lane >> 3);
                 const int lslot = (lane & 7) ^ ((R >> 1) & 7);
-                const int grow = (8 * NLOAD * m < BQP) ? min(iq0 + R, B - 1) : min(is0 + R - BQP, N - 1);
-                voff[m] = ((unsigned)grow * (unsigned)d + lslot * 4) * 4u;
+                // relative to the tile's first rows (64-bit bases in issue_next): no 4 GB limit on the bank
+                const int rel = (8 * NLOAD * m < BQP) ? min(iq0 + R, B - 1) - iq0 : min(is0 + R - BQP, N - 1) - is0;
+                voff[m] = ((unsigned)rel * (unsigned)d + lslot * 4) * 4u;
             }
         };
         auto dma4 = [&](const void* src, float* dst) {  // one dword per lane -> dst[lane]
@@ -333,8 +334,8 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
             int kc = ikt + irot;
             if (kc >= nk) kc -= nk;
             float4* buf = stage + ((unsigned)gs % NB) * TILE_F4;
-            const char* qb = reinterpret_cast<const char*>(q) + (size_t)kc * BK * 4;
-            const char* sb = reinterpret_cast<const char*>(s) + (size_t)kc * BK * 4;
+            const char* qb = reinterpret_cast<const char*>(q + (size_t)iq0 * d) + (size_t)kc * BK * 4;
+            const char* sb = reinterpret_cast<const char*>(s + (size_t)is0 * d) + (size_t)kc * BK * 4;
 #ifndef NW_ABL_NODMA
 #pragma unroll
 #endif

@@ -360,7 +360,7 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
     const int grid = padded_grid(n_stiles, n_qtiles);
     // RS = 5 exists for the LDS-DMA modes only (two workgroups per CU); the register-staged loaders
     // need an even split of the tile rows
-    const bool dma = (d % BK) == 0 && (uint64_t)N * d * 4 < 0xffffffffull && (uint64_t)B * d * 4 < 0xffffffffull;
+    const bool dma = (d % BK) == 0 && (uint64_t)(BQ + BS) * 2 * d * 4 < 0xffffffffull;  // per-lane offsets are tile-relative
     if (!dma && (RS & 1)) return NW_ERR_UNSUPPORTED;
     const size_t lds_reg = FUSED_HDR + TileCfg<RS>::STAGE_BYTES, lds_dma = FUSED_HDR + DmaCfg<RS>::STAGE_BYTES;
 #define NW_LAUNCH(WS_, MODE_, LDS_)                                                                      \

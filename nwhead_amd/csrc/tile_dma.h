@@ -88,15 +88,17 @@ __device__ __forceinline__ void dma_loader_run(const float* __restrict__ q, cons
         for (int m = 0; m < NI; ++m) {
             const int R = 8 * (lw + NLOAD * m) + (lane >> 3);
             const int lslot = (lane & 7) ^ ((R >> 1) & 7);  // source-side swizzle
-            const int grow = (8 * NLOAD * m < BQ) ? min(q0 + R, B - 1) : min(s0 + R - BQ, N - 1);
-            voff[m] = ((unsigned)grow * (unsigned)d + lslot * 4) * 4u;
+            // offsets are relative to the tile's first row (the bases below carry q0 / s0 in 64 bits): banks
+            // beyond 4 GB are fine, a tile never spans more than (BQ + BS) * d * 4 bytes
+            const int rel = (8 * NLOAD * m < BQ) ? min(q0 + R, B - 1) - q0 : min(s0 + R - BQ, N - 1) - s0;
+            voff[m] = ((unsigned)rel * (unsigned)d + lslot * 4) * 4u;
         }
         auto issue = [&](int kt) {
             int kc = kt + rot;
             if (kc >= nk) kc -= nk;
             float4* buf = stage + ((unsigned)kt % Cfg::NBUF) * TILE_F4;
-            const char* qb = reinterpret_cast<const char*>(q) + (size_t)kc * BK * 4;
-            const char* sb = reinterpret_cast<const char*>(s) + (size_t)kc * BK * 4;
+            const char* qb = reinterpret_cast<const char*>(q + (size_t)q0 * d) + (size_t)kc * BK * 4;
+            const char* sb = reinterpret_cast<const char*>(s + (size_t)s0 * d) + (size_t)kc * BK * 4;
 #pragma unroll
             for (int m = 0; m < NI; ++m) {
                 if (NI != NI_LO && m == NI - 1 && lw + NLOAD * m >= NT) break;  // uneven split: last slot of the short waves

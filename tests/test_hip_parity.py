@@ -421,3 +421,38 @@ def test_split_bank_sorts_unsorted_labels(dev, ops, O):
     close(ops.nw_merge(rows, B, C), ref.numpy(), rtol=RTOL, atol=3e-5)
     sorted_bank = ops.SplitBank(s, labels=sy.sort().values)      # already sorted: no copy
     assert sorted_bank.sorted_rows is None
+
+
+def test_bank_beyond_4gb(dev, ops):
+    """A bank of 4.5 GB (N = 2.2 M rows of 512 floats): the LDS-DMA loaders address rows relative to their
+    tile, so nothing in the path is limited to 32-bit byte offsets.  Checked against an fp64 evaluation on
+    the device in chunks (the CPU oracle would need the 9 GB fp64 bank)."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip("needs ~20 GB of free HBM")
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, N, d, C = 136, 2_150_000, 512, 50
+    q = torch.randn(B, d, generator=g, device=dev)
+    s = torch.randn(N, d, generator=g, device=dev)
+    s[-3:] = q[:3] + 0.5 * torch.randn(3, d, generator=g, device=dev)   # the nearest neighbours sit in the LAST rows (beyond 4 GB)
+    sy = (torch.arange(N, device=dev) * C // N)
+    bank = ops.SplitBank(s, labels=sy)
+    out = ops.nw_head(q, s, sy, C, support_cache=bank)            # 128-query tiles
+    out16 = ops.nw_head(q[:16], s, sy, C, support_cache=bank)     # 64-query tiles, two workgroups per CU
+    # fp64 reference for the first 16 queries, streamed over the bank
+    nr = 16
+    m = torch.full((nr,), -float("inf"), dtype=torch.float64, device=dev)
+    num = torch.zeros(nr, C, dtype=torch.float64, device=dev)
+    qd = q[:nr].double()
+    for a0 in range(0, N, 430_000):
+        sc = -torch.cdist(qd, s[a0:a0 + 430_000].double())
+        mn = torch.maximum(m, sc.max(1).values)
+        num *= torch.exp(m - mn)[:, None]
+        num.index_add_(1, sy[a0:a0 + 430_000], torch.exp(sc - mn[:, None]))
+        m = mn
+    ref = torch.log(num / num.sum(1, keepdim=True) + 1e-12).cpu().numpy()
+    close(out[:nr], ref, rtol=RTOL, atol=3e-5)
+    close(out16, ref, rtol=RTOL, atol=3e-5)
+    assert torch.isfinite(out).all() and (out.exp().sum(1) - 1).abs().max().item() < 1e-4
+    del bank, s
+    torch.cuda.empty_cache()
