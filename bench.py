@@ -258,9 +258,12 @@ def main():
     lo, hi = shard_bounds(N, world, rank)
     bank = ShardedBank(s[lo:hi].clone(), sy[lo:hi].clone(), C)
     del s
-    # a few distinct query batches so that nothing is cached across steps
+    # one bucket of distinct query batches, back to back in one staging buffer (predict_stream then hands the
+    # bucket to the kernels as a view instead of concatenating it)
     gq = torch.Generator().manual_seed(123)
-    qs = [torch.randn(B, d, generator=gq).to(dev) for _ in range(4)]
+    nq = max(args.bucket, 4)
+    qbuf = torch.randn(nq * B, d, generator=gq).to(dev)
+    qs = [qbuf[k * B:(k + 1) * B] for k in range(nq)]
 
     def run(nsteps):
         # same code path at every N: buckets of query batches coalesced per launch (sharded.py); long
@@ -269,7 +272,7 @@ def main():
         out = None
         for i0 in range(0, nsteps, chunk):
             n = min(chunk, nsteps - i0)
-            out = bank.predict_stream([qs[i % 4] for i in range(n)], bucket=args.bucket)[-1]
+            out = bank.predict_stream([qs[i % nq] for i in range(n)], bucket=args.bucket)[-1]
         return out
 
     def barrier():
@@ -320,7 +323,7 @@ def main():
         # one launch = the partial forward of one bucket (bucket*B queries) over this rank's shard:
         # nw_fused_kernel + nw_merge_runs_kernel
         Bl = B * args.bucket
-        qcat = torch.cat([qs[i % 4] for i in range(args.bucket)], dim=0)
+        qcat = torch.cat([qs[i % nq] for i in range(args.bucket)], dim=0)
         pk = torch.empty(bank.row_len(Bl), dtype=torch.float32, device=dev)
         # the tile kernel alone, bracketed by HIP events on its own launch stream inside the library
         # (nw_debug_tile_timing, include/nwhead_hip.h), and the whole partial forward around it

@@ -24,6 +24,20 @@ def shard_bounds(n_rows: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _coalesce(chunk):
+    """One (nb*B, d) tensor for a bucket of (B, d) query batches: a VIEW when the batches already sit back to
+    back in one storage (slices of a staging buffer, the usual case in a serving loop), else a copy."""
+    first = chunk[0]
+    if first.is_contiguous() and first.dim() == 2:
+        base = first.untyped_storage().data_ptr()
+        step = first.numel() * first.element_size()
+        if all(c.dtype == first.dtype and c.shape == first.shape and c.is_contiguous() and
+               c.untyped_storage().data_ptr() == base and c.data_ptr() == first.data_ptr() + k * step
+               for k, c in enumerate(chunk)):
+            return first.as_strided((len(chunk) * first.shape[0], first.shape[1]), (first.shape[1], 1))
+    return torch.cat(chunk, dim=0)
+
+
 class ShardedBank:
     def __init__(self, feat_shard, y_shard, n_classes, kind="euclidean", logit_scale=None, group=None,
                  partial_fn=None, merge_fn=None):
@@ -106,7 +120,7 @@ class ShardedBank:
                 ring[key] = (torch.empty(L, dtype=torch.float32, device=dev),
                              torch.empty(G, L, dtype=torch.float32, device=dev))
             packed, gathered = ring[key]
-            qcat = chunk[0] if nb == 1 else torch.cat(chunk, dim=0)
+            qcat = chunk[0] if nb == 1 else _coalesce(chunk)
             if G == 1 and self._partial == self._hip_partial:
                 # one rank: nothing to exchange, the forward finalises in place
                 out = ops.nw_head(qcat, self.feat, self.y, self.C, self.kind, self.logit_scale, support_cache=self.cache)

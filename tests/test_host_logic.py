@@ -96,3 +96,19 @@ def test_dropin_import_paths():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp", timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
     assert r.stdout.split()[0] == "ResNet"
+
+
+def test_bucket_coalescing_views():
+    """predict_stream hands a bucket of query batches to the kernels as ONE tensor: a view when the batches
+    are consecutive slices of one buffer, a copy otherwise."""
+    import torch
+    from nwhead_amd.sharded import _coalesce
+    buf = torch.arange(6 * 4 * 3, dtype=torch.float32).reshape(24, 3)
+    parts = [buf[k * 4:(k + 1) * 4] for k in range(6)]
+    v = _coalesce(parts[1:5])
+    assert v.shape == (16, 3) and v.data_ptr() == parts[1].data_ptr() and torch.equal(v, buf[4:20])
+    c = _coalesce([parts[0], parts[2]])                        # a gap: copy
+    assert c.data_ptr() != parts[0].data_ptr() and torch.equal(c, torch.cat([parts[0], parts[2]]))
+    other = [torch.ones(4, 3), torch.zeros(4, 3)]              # different storages: copy
+    assert torch.equal(_coalesce(other), torch.cat(other))
+    assert torch.equal(_coalesce([parts[3], parts[2]]), torch.cat([parts[3], parts[2]]))   # wrong order: copy
