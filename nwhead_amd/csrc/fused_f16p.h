@@ -267,11 +267,23 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
     // groups of `qg` query tiles (kept resident: qg * BQP * 2 KB at d = 512), and inside a group runs support-tile
     // major, so the n_cu workgroups of the XCD are on ~n_cu/qg support tiles x qg query tiles at any
     // time.
+    // The support tiles beyond the last full round of 8 (n_stiles % 8 of them) are dealt by QUERY tile
+    // (qt = x mod 8) instead, so every XCD gets the same number of tiles to within n_stiles % 8: with 49
+    // support tiles (a shard of the K3 bank at 8 ranks) one XCD would otherwise walk 7 and seven XCDs 6.
     const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, n_cu = gridDim.x >> 3;
-    const int ns_x = (n_stiles - xcd + 7) >> 3;  // support tiles of this XCD
-    const int n_local = ns_x * n_qtiles;         // tiles of this XCD
+    const int ns_x = n_stiles >> 3;              // full rounds: support tiles st = stl * 8 + x
+    const int n_full = ns_x * n_qtiles;
+    const int rem = n_stiles & 7;                // leftover support tiles 8 * ns_x .. n_stiles - 1
+    const int nq_x = (n_qtiles - xcd + 7) >> 3;  // query tiles of this XCD in the leftover part
+    const int n_local = n_full + rem * nq_x;     // tiles of this XCD
     const int grp_tiles = qg * ns_x;
     auto decode = [&](int L, int& qt, int& st) {
+        if (L >= n_full) {                       // leftover part, support-tile major
+            const int r = L - n_full, j = r / nq_x;
+            st = 8 * ns_x + j;
+            qt = xcd + 8 * (r - j * nq_x);
+            return;
+        }
         const int gi = L / grp_tiles, r = L - gi * grp_tiles;
         const int g = min(qg, n_qtiles - gi * qg);
         const int stl = r / g;
