@@ -187,14 +187,20 @@ __global__ __launch_bounds__(256) void nw_merge_runs_kernel(
 // threads = 16 queries x 16 tile lanes, so every workspace read is a 64-byte run along the query
 // axis (the one-workgroup-per-query kernel above reads 4 bytes per 16 KB stride: 53 us at B = 4096,
 // n_stiles = 391).  Class sums live in LDS as num[class][query].
-constexpr int MQ = 16, ML = 32, MTHREADS = MQ * ML, MU = 4;
-constexpr int MNS = MQ + 1;  // row stride of num[class][query] in LDS: odd, the output phase reads columns
-template <bool PARTIAL>
+// MQ x ML = 16 x 32 when there are many tiles per query (K3: 391); 32 x 16 when there are few (a shard of
+// the bank at 8 ranks: 49 tiles -- measured there 14.9 / 11.1 / 11.5 us for MQ = 16 / 32 / 64).
+// (A query-blocked workspace with packed run rows -- one contiguous 40 KB piece per 128 queries instead
+//  of 256-byte runs B*4 bytes apart -- was measured too: no change; the walk is bound by its dependent
+//  load latencies, not by locality.)
+constexpr int MTHREADS = 512, MU = 4;
+template <bool PARTIAL, int MQ>
 __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
     const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
     const int* __restrict__ ws_lab, const float* __restrict__ ws_num, float* __restrict__ out,
     float* __restrict__ lse, float* __restrict__ m_out, float* __restrict__ den_out,
     float* __restrict__ num_out, int B, int C, int n_stiles, int BS) {
+    constexpr int ML = MTHREADS / MQ;
+    constexpr int MNS = MQ + 1;  // row stride of num[class][query] in LDS: odd, the output phase reads columns
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // [ML][MQ]
     float* inv_s = red + ML * MQ;                 // [MQ]
@@ -335,15 +341,17 @@ int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_
 
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st) {
-    const size_t blds = ((size_t)ML * MQ + MQ + (size_t)C * MNS) * sizeof(float);
+    // 32 queries x 16 tile lanes per workgroup when a query has few tiles (a shard of the bank), else 16 x 32
+    const int mq = (n_stiles >= 128 || ((size_t)MTHREADS + 32 + (size_t)C * 33) * sizeof(float) > 64 * 1024) ? 16 : 32;
+    const size_t blds = ((size_t)MTHREADS + mq + (size_t)C * (mq + 1)) * sizeof(float);
     if (B >= 512 && blds <= 64 * 1024 && !env_flag("NW_MERGE_PER_QUERY")) {
-        const int grid = (B + MQ - 1) / MQ;
-        if (out)
-            hipLaunchKernelGGL(nw_merge_runs_blk_kernel<false>, dim3(grid), dim3(MTHREADS), blds, st, ws.m, ws.den,
-                               ws.nrun, ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS);
-        else
-            hipLaunchKernelGGL(nw_merge_runs_blk_kernel<true>, dim3(grid), dim3(MTHREADS), blds, st, ws.m, ws.den,
-                               ws.nrun, ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS);
+        const int grid = (B + mq - 1) / mq;
+#define NW_MERGE_BLK(P_, Q_)                                                                                          \
+    hipLaunchKernelGGL((nw_merge_runs_blk_kernel<P_, Q_>), dim3(grid), dim3(MTHREADS), blds, st, ws.m, ws.den, ws.nrun, \
+                       ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS)
+        if (out) { if (mq == 16) NW_MERGE_BLK(false, 16); else NW_MERGE_BLK(false, 32); }
+        else { if (mq == 16) NW_MERGE_BLK(true, 16); else NW_MERGE_BLK(true, 32); }
+#undef NW_MERGE_BLK
         NW_CHECK_LAUNCH();
         return NW_OK;
     }
