@@ -105,6 +105,25 @@ def measure_shape(B, N, d, C, dev, iters):
             "whole_op_frac_of_roofline": max(alg_bytes(B, N, d, C) / (PEAK_HBM_GBS * 1e9), fl / (PEAK_SPLIT_F16_TFLOPS * 1e12)) / t_fwd}
 
 
+def measure_train_head(B, N, d, C, dev, iters=30):
+    """A4 at a large shape: nll_loss(NWHead(x, sx, sy)).backward() with gradients for queries and supports
+    (scores written by the forward, coefficients, two fp32-MFMA products).  Event time of the whole
+    Python-driven step, so torch's autograd bookkeeping (~0.15 ms) is inside it."""
+    import torch.nn.functional as F
+    from nwhead_amd import ops
+    q, s, sy = make_inputs(B, N, d, C, dev)
+    q.requires_grad_(True)
+    s.requires_grad_(True)
+    t = torch.randint(0, C, (B,), device=dev)
+
+    def step():
+        q.grad = s.grad = None
+        F.nll_loss(ops.nw_head(q, s, sy, C), t).backward()
+    dt = time_kernel_events(step, iters)
+    return {"B": B, "N": N, "d": d, "C": C, "ms_per_fwd_bwd": dt * 1e3,
+            "TFLOPs_fwd_plus_bwd_products": 6 * B * N * d / dt / 1e12}
+
+
 def measure_influence(B, N, C, dev, iters=100):
     """K5: support_influence over a 10000-image support bank (HBM-bound streaming kernel)."""
     from nwhead_amd import ops
@@ -370,6 +389,7 @@ def main():
             line["north_star_T"] = measure_shape(256, 10000, 512, 200, dev, 100)
             line["config_K2_head"] = measure_shape(64, 1000, 512, 200, dev, 100)
             line["config_K5_support_influence"] = measure_influence(256, 10000, 200, dev)
+            line["head_train_step_T"] = measure_train_head(256, 10000, 512, 200, dev)
             line.update(measure_backbone_configs(dev))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(32, N, d, C)

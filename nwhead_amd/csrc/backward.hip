@@ -11,9 +11,12 @@
 // Euclidean: df/ddot = 1/D, df/d|q|^2 = df/d|s|^2 = -1/(2D), all taken as 0 where D == 0 (torch's
 // cdist backward masks the zero distance the same way).
 #include "nw_internal.h"
+#include <cstdlib>
 
 namespace nw {
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void nw_rownorm_kernel(const float* __restrict__ x,
                                                           float* __restrict__ n2, int64_t rows,
@@ -28,28 +31,31 @@ __global__ __launch_bounds__(256) void nw_rownorm_kernel(const float* __restrict
     if (lane == 0) n2[r] = a;
 }
 
-// One workgroup per query.  Writes A (B,N), Rs (B,N), rq (B,), gls (B,).
+// One workgroup (256 or 1024 threads) per query.  Writes A (B,N), Rs (B,N), rq (B,), gls (B,).
+// (t = sum_j W_j dW_j could be had without a pass over the supports, as sum_c g[c] (1 - 1e-12 exp(-out[c]));
+//  but for a class the support set lacks that is 1 - 1 computed through a rounded `out`, ~1e-6 g instead
+//  of the exact 0 the sum gives -- measured 26 us saved at B=256, N=10000, not taken.)
 template <int KIND>
-__global__ __launch_bounds__(256) void nw_bwd_coeff_kernel(
+__global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
     const float* __restrict__ scores, const float* __restrict__ lse, const float* __restrict__ out,
     const float* __restrict__ gout, const int64_t* __restrict__ sy, int labels_batched,
     const float* __restrict__ qn2, const float* __restrict__ sn2, int sup_batched,
     const float* __restrict__ logit_scale, float* __restrict__ A, float* __restrict__ Rs,
-    float* __restrict__ rq, float* __restrict__ gls, int64_t N, int64_t C) {
+    float* __restrict__ rq, float* __restrict__ gls, int64_t N, int64_t C, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);
-    float* dP = red + 8;
+    float* dP = red + 16;
     const int64_t b = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const float* row = scores + b * N;
     const int64_t* lab = sy + (labels_batched ? b * N : 0);
     const float l = lse[b];
 
-    for (int64_t c = tid; c < C; c += 256) dP[c] = gout[b * C + c] * expf(-out[b * C + c]);
+    for (int64_t c = tid; c < C; c += nthr) dP[c] = gout[b * C + c] * expf(-out[b * C + c]);
     __syncthreads();
 
     float t = 0.f;
-    for (int64_t j = tid; j < N; j += 256) {
+    for (int64_t j = tid; j < N; j += nthr) {
         const int64_t y = lab[j];
         const float dw = ((uint64_t)y < (uint64_t)C) ? dP[y] : 0.f;
         t += expf(row[j] - l) * dw;
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void nw_bwd_coeff_kernel(
         inq2 = (n > NW_NORM_EPS) ? 1.f / (nq * nq) : 0.f;  // F.normalize clamps: no grad via |q|
     }
     float rq_acc = 0.f, gls_acc = 0.f;
-    for (int64_t j = tid; j < N; j += 256) {
+    for (int64_t j = tid; j < N; j += nthr) {
         const float sc = row[j];
         const int64_t y = lab[j];
         const float dw = ((uint64_t)y < (uint64_t)C) ? dP[y] : 0.f;
@@ -97,8 +103,8 @@ __global__ __launch_bounds__(256) void nw_bwd_coeff_kernel(
             rq_acc += gc * (-0.5f * c * inq2);
             r = gc * (-0.5f * c * ins2);
         }
-        A[b * N + j] = a;
-        Rs[b * N + j] = r;
+        A[b * ld + j] = a;
+        Rs[b * ld + j] = r;
     }
     rq_acc = block_sum(rq_acc, red);
     gls_acc = block_sum(gls_acc, red);
@@ -157,6 +163,225 @@ __global__ __launch_bounds__(256) void nw_bwd_gs_batched_kernel(const float* __r
     gs[bj * d + k] = A[bj] * q[b * d + k] + 2.f * Rs[bj] * s[bj * d + k];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The two products of the backward on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMAs):
+//     gq[b,k] = sum_j A[b,j] s[j,k] + 2 rq[b] q[b,k]        (M = B, K = N; A-operand is K-contiguous)
+//     gs[j,k] = sum_b A[b,j] q[b,k] + 2 rs[j] s[j,k]        (M = N, K = B; A-operand is M-contiguous)
+// One kernel: C[m,n] = sum_k Aop(m,k) Bop[k,n] with Bop row-major (n contiguous) and Aop either way.
+// 128 x 128 output tile per workgroup, four waves of 64 x 64 (16 accumulator blocks), K in steps of 16
+// through two LDS stages: the next step's global loads are issued before the current step's MFMAs and
+// written to the other stage after them, so there is one barrier per step.  LDS rows are [k][m] / [k][n]
+// with a stride of 144 floats (= 16 mod 32 banks: the four k-rows a fragment read touches land on
+// disjoint banks).  K is split over blockIdx.z when M x N alone cannot fill the chip; the partial tiles
+// are summed in chunk order by nw_bwd_reduce_kernel (deterministic), which also adds the rank-one term.
+constexpr int GM = 128, GN = 128, GK = 16, GLD = 144;  // (GK = 32 measured: no faster, half the workgroups per CU)
+
+template <bool A_KCONTIG, bool FUSE>
+__global__ __launch_bounds__(256, 2) void nw_bwd_gemm_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
+    float* __restrict__ Cout, const float* __restrict__ rowscale, const float* __restrict__ X, int M, int Nn,
+    int K, int k_chunk) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK * GLD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    const int kb = blockIdx.z * k_chunk, ke = min(K, kb + k_chunk);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NLD = GK / 8;   // float4 loads per thread and operand per step
+    constexpr int KQ = GK / 4;    // float4s along k in one A row (K-contiguous form)
+    float4 ra[NLD], rb[NLD];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int k = k0 + (tid >> 5) + 8 * u, n = n0 + 4 * (tid & 31);
+            rb[u] = (k < ke && n < Nn) ? *reinterpret_cast<const float4*>(Bm + (int64_t)k * ldb + n) : zero4;
+            if (A_KCONTIG) {
+                const int m = m0 + tid / KQ + (256 / KQ) * u, kk = k0 + 4 * (tid % KQ);
+                float4 v = zero4;
+                if (m < M && kk < ke) {
+                    v = *reinterpret_cast<const float4*>(A + (int64_t)m * lda + kk);
+                    // the row's pad columns (k >= K) are uninitialised: 0 * NaN would poison the sum
+                    if (kk + 1 >= ke) v.y = 0.f;
+                    if (kk + 2 >= ke) v.z = 0.f;
+                    if (kk + 3 >= ke) v.w = 0.f;
+                }
+                ra[u] = v;
+            } else {
+                const int m = m0 + 4 * (tid & 31);  // columns past M only feed output rows that are never stored
+                ra[u] = (k < ke && m < M) ? *reinterpret_cast<const float4*>(A + (int64_t)k * lda + m) : zero4;
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int k = (tid >> 5) + 8 * u, c = 4 * (tid & 31);
+            *reinterpret_cast<float4*>(&Bs[buf][k * GLD + c]) = rb[u];
+            if (A_KCONTIG) {
+                const int m = tid / KQ + (256 / KQ) * u, kk = 4 * (tid % KQ);
+                As[buf][(kk + 0) * GLD + m] = ra[u].x;
+                As[buf][(kk + 1) * GLD + m] = ra[u].y;
+                As[buf][(kk + 2) * GLD + m] = ra[u].z;
+                As[buf][(kk + 3) * GLD + m] = ra[u].w;
+            } else {
+                *reinterpret_cast<float4*>(&As[buf][k * GLD + c]) = ra[u];
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            const int kr = (4 * kk + (lane >> 4)) * GLD + (lane & 15);
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[buf][kr + wm + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kr + wn + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nsteps = (ke - kb + GK - 1) / GK;  // >= 1: the launcher never makes an empty chunk
+    gload(kb);
+    sstore(0);
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+        const bool more = t + 1 < nsteps;
+        if (more) gload(kb + (t + 1) * GK);
+        compute(t & 1);
+        if (more) sstore((t + 1) & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
+            if (m >= M) continue;
+            const float rsc = FUSE ? 2.f * rowscale[m] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn + 16 * j + (lane & 15);
+                if (n >= Nn) continue;
+                if (FUSE) {
+                    const int64_t o = (int64_t)m * Nn + n;
+                    Cout[o] = __builtin_fmaf(rsc, X[o], acc[i][j][r]);
+                } else {
+                    Cout[((int64_t)blockIdx.z * M + m) * Nn + n] = acc[i][j][r];
+                }
+            }
+        }
+}
+
+// C[m,n] = sum_chunks part[c][m,n] + 2 rowscale[m] X[m,n]   (n in float4s; Nn % 4 == 0)
+__global__ __launch_bounds__(256) void nw_bwd_reduce_kernel(const float* __restrict__ part, int nchunks,
+                                                             const float* __restrict__ rowscale,
+                                                             const float* __restrict__ X, float* __restrict__ Cout,
+                                                             int64_t M, int64_t Nn) {
+    const int64_t total4 = M * Nn / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int64_t m = (i * 4) / Nn;
+    float4 a = *reinterpret_cast<const float4*>(part + i * 4);
+    for (int c = 1; c < nchunks; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)c * M * Nn) + i * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const float rsc = 2.f * rowscale[m];
+    const float4 x = *reinterpret_cast<const float4*>(X + i * 4);
+    a.x = __builtin_fmaf(rsc, x.x, a.x); a.y = __builtin_fmaf(rsc, x.y, a.y);
+    a.z = __builtin_fmaf(rsc, x.z, a.z); a.w = __builtin_fmaf(rsc, x.w, a.w);
+    *reinterpret_cast<float4*>(Cout + i * 4) = a;
+}
+
+// rs[j] = sum_b Rs[b*ld + j] in two deterministic stages.  Stage 1: a workgroup owns 256 columns (64
+// float4 lanes) x one slice of the rows, its four waves interleave the rows -> part[slice][j].
+constexpr int CS_MAX_SLICES = 8;
+inline int64_t colsum_rows(int64_t B) {  // rows per slice: >= 32, at most CS_MAX_SLICES slices
+    const int64_t r = (B + CS_MAX_SLICES - 1) / CS_MAX_SLICES;
+    return r < 32 ? 32 : r;
+}
+__global__ __launch_bounds__(256) void nw_colsum_part_kernel(const float* __restrict__ Rs, int64_t ld,
+                                                              float* __restrict__ part, int64_t B, int64_t rows) {
+    __shared__ float4 red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t j = ((int64_t)blockIdx.x * 64 + c) * 4;  // ld % 4 == 0: whole float4s, pad columns included
+    const int64_t b0 = (int64_t)blockIdx.y * rows, b1 = b0 + rows < B ? b0 + rows : B;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < ld)
+        for (int64_t b = b0 + rl; b < b1; b += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(Rs + b * ld + j);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    red[rl][c] = a;
+    __syncthreads();
+    if (rl == 0 && j < ld) {
+        const float4 p = red[1][c], q = red[2][c], r = red[3][c];
+        a.x = (a.x + p.x) + (q.x + r.x); a.y = (a.y + p.y) + (q.y + r.y);
+        a.z = (a.z + p.z) + (q.z + r.z); a.w = (a.w + p.w) + (q.w + r.w);
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * ld + j) = a;
+    }
+}
+// Stage 2: rs[j] = sum_slices part[slice][j]
+__global__ __launch_bounds__(256) void nw_colsum_final_kernel(const float* __restrict__ part, int64_t ld, int nslices,
+                                                               float* __restrict__ rs, int64_t N) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    float a = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) a += part[(int64_t)sl * ld + j];
+    rs[j] = a;
+}
+
+struct GemmPlan {
+    int nchunks, k_chunk;
+};
+// Split K until the grid has >= 512 workgroups (two per CU: the kernel hides its global-load latency with
+// co-resident workgroups), never below 64 of K per chunk.  Measured at M=10000, N=512, K=256 (316 tiles):
+// 83 us unsplit, 46 + 16 (reduce) split in two, 53 + 26 split in four.
+GemmPlan gemm_plan(int64_t M, int64_t Nn, int64_t K) {
+    const int64_t tiles = ((M + GM - 1) / GM) * ((Nn + GN - 1) / GN);
+    int64_t want = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+    const int64_t maxc = K / 64 > 1 ? K / 64 : 1;
+    if (want > maxc) want = maxc;
+    int64_t kc = (K + want - 1) / want;
+    kc = (kc + GK - 1) / GK * GK;
+    GemmPlan p;
+    p.k_chunk = (int)kc;
+    p.nchunks = (int)((K + kc - 1) / kc);
+    return p;
+}
+
+template <bool A_KCONTIG>
+int launch_bwd_gemm(const float* A, int64_t lda, const float* Bm, float* part, const float* rowscale, const float* X,
+                    float* Cout, int64_t M, int64_t Nn, int64_t K, hipStream_t st) {
+    const GemmPlan p = gemm_plan(M, Nn, K);
+    const dim3 grid((unsigned)((Nn + GN - 1) / GN), (unsigned)((M + GM - 1) / GM), (unsigned)p.nchunks);
+    if (grid.y > 65535u || grid.z > 65535u) return NW_ERR_INVALID_ARG;
+    if (p.nchunks == 1) {
+        hipLaunchKernelGGL((nw_bwd_gemm_kernel<A_KCONTIG, true>), grid, dim3(256), 0, st, A, lda, Bm, Nn, Cout, rowscale,
+                           X, (int)M, (int)Nn, (int)K, p.k_chunk);
+    } else {
+        hipLaunchKernelGGL((nw_bwd_gemm_kernel<A_KCONTIG, false>), grid, dim3(256), 0, st, A, lda, Bm, Nn, part,
+                           rowscale, X, (int)M, (int)Nn, (int)K, p.k_chunk);
+        const int64_t total4 = M * Nn / 4;
+        hipLaunchKernelGGL(nw_bwd_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, part,
+                           p.nchunks, rowscale, X, Cout, M, Nn);
+    }
+    return NW_OK;
+}
+
 __global__ __launch_bounds__(256) void nw_sum_kernel(const float* __restrict__ x,
                                                       float* __restrict__ out, int64_t n) {
     __shared__ float red[8];
@@ -167,11 +392,18 @@ __global__ __launch_bounds__(256) void nw_sum_kernel(const float* __restrict__ x
 }
 
 struct BwdWs {
-    float *A, *Rs, *rq, *gls, *qn2, *sn2;
+    float *A, *Rs, *rq, *gls, *qn2, *sn2, *rs, *part, *cs_part;
+    int64_t ld;  // row stride of A and Rs: N, or N rounded up to 4 floats on the matrix-core path
+    bool mfma;
 };
+// Shared support, float4-able rows and enough work to fill the chip: the two products run on the matrix cores.
+bool bwd_use_mfma(int64_t B, int64_t N, int64_t d, int sup_batched) {
+    static const bool off = [] { const char* e = getenv("NW_BWD_NO_MFMA"); return e && e[0] == '1'; }();
+    return !off && !sup_batched && d % 4 == 0 && B * N * d >= (int64_t)1 << 22;
+}
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t bwd_layout(int64_t B, int64_t N, int sup_batched, char* base, BwdWs* ws) {
+size_t bwd_layout(int64_t B, int64_t N, int64_t d, int sup_batched, char* base, BwdWs* ws) {
     size_t off = 0;
     auto take = [&](size_t nfloat) {
         float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
@@ -179,12 +411,22 @@ size_t bwd_layout(int64_t B, int64_t N, int sup_batched, char* base, BwdWs* ws) 
         return p;
     };
     BwdWs w;
-    w.A = take((size_t)B * N);
-    w.Rs = take((size_t)B * N);
+    w.mfma = bwd_use_mfma(B, N, d, sup_batched);
+    w.ld = w.mfma ? (N + 3) / 4 * 4 : N;
+    w.A = take((size_t)B * w.ld);
+    w.Rs = take((size_t)B * w.ld);
     w.rq = take((size_t)B);
     w.gls = take((size_t)B);
     w.qn2 = take((size_t)B);
     w.sn2 = take(sup_batched ? (size_t)B * N : (size_t)N);
+    w.rs = w.part = w.cs_part = nullptr;
+    if (w.mfma) {
+        w.rs = take((size_t)N);
+        w.cs_part = take((size_t)CS_MAX_SLICES * w.ld);
+        const GemmPlan pq = gemm_plan(B, d, N), ps = gemm_plan(N, d, B);
+        const size_t nq = pq.nchunks > 1 ? (size_t)pq.nchunks * B * d : 0, ns = ps.nchunks > 1 ? (size_t)ps.nchunks * N * d : 0;
+        w.part = take(nq > ns ? nq : ns);
+    }
     if (ws) *ws = w;
     return off;
 }
@@ -203,9 +445,9 @@ int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStrea
 
 extern "C" size_t nw_bwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                                          int sup_batched) {
-    (void)d; (void)C; (void)kind;
+    (void)C; (void)kind;
     if (B <= 0 || N < 0) return 0;
-    return nw::bwd_layout(B, N, sup_batched, nullptr, nullptr);
+    return nw::bwd_layout(B, N, d, sup_batched, nullptr, nullptr);
 }
 
 extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, const float* scores,
@@ -229,9 +471,10 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
     if (!q || !s || !sy || !scores || !lse || !out || !gout || !gq || !gs) return NW_ERR_INVALID_ARG;
     if (B > 0x7fffffffLL || gs_rows > 0x7fffffffLL || (d + 255) / 256 > 65535) return NW_ERR_INVALID_ARG;
     BwdWs ws;
-    const size_t need = bwd_layout(B, N, sup_batched, static_cast<char*>(workspace), &ws);
+    const size_t need = bwd_layout(B, N, d, sup_batched, static_cast<char*>(workspace), &ws);
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
-    const size_t lds = (8 + (size_t)C) * sizeof(float);
+    const size_t lds = (16 + (size_t)C) * sizeof(float);
+    const unsigned coeff_threads = N >= 2048 ? 1024 : 256;
     if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
 
     const bool norms = (kind == NW_SCORE_HYPERSPHERE || kind == NW_SCORE_COSINE || kind == NW_SCORE_CLIP);
@@ -240,9 +483,9 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
         hipLaunchKernelGGL(nw_rownorm_kernel, dim3((unsigned)((gs_rows + 3) / 4)), dim3(256), 0, st, s, ws.sn2, gs_rows, d);
     }
 #define NW_COEFF(K)                                                                              \
-    hipLaunchKernelGGL(nw_bwd_coeff_kernel<K>, dim3((unsigned)B), dim3(256), lds, st, scores, lse, \
+    hipLaunchKernelGGL(nw_bwd_coeff_kernel<K>, dim3((unsigned)B), dim3(coeff_threads), lds, st, scores, lse, \
                        out, gout, sy, labels_batched, ws.qn2, ws.sn2, sup_batched, logit_scale_dev, \
-                       ws.A, ws.Rs, ws.rq, ws.gls, N, C)
+                       ws.A, ws.Rs, ws.rq, ws.gls, N, C, ws.ld)
     switch (kind) {
         case NW_SCORE_EUCLIDEAN: NW_COEFF(NW_SCORE_EUCLIDEAN); break;
         case NW_SCORE_HYPERSPHERE: NW_COEFF(NW_SCORE_HYPERSPHERE); break;
@@ -251,6 +494,29 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
         default: NW_COEFF(NW_SCORE_CLIP); break;
     }
 #undef NW_COEFF
+    const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(s) |
+                           reinterpret_cast<uintptr_t>(gq) | reinterpret_cast<uintptr_t>(gs)) & 15) == 0;
+    if (ws.mfma && !aligned) return NW_ERR_INVALID_ARG;  // the layout (row stride of A) is already the matrix-core one
+    if (ws.mfma) {
+        const int64_t cs_rows = colsum_rows(B);
+        const int nslices = (int)((B + cs_rows - 1) / cs_rows);
+        hipLaunchKernelGGL(nw_colsum_part_kernel, dim3((unsigned)((ws.ld / 4 + 63) / 64), (unsigned)nslices), dim3(256), 0,
+                           st, ws.Rs, ws.ld, ws.cs_part, B, cs_rows);
+        hipLaunchKernelGGL(nw_colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, ws.cs_part, ws.ld,
+                           nslices, ws.rs, N);
+        int rc = launch_bwd_gemm<true>(ws.A, ws.ld, s, ws.part, ws.rq, q, gq, B, d, N, st);   // gq = A s + 2 rq q
+        if (rc != NW_OK) return rc;
+        rc = launch_bwd_gemm<false>(ws.A, ws.ld, q, ws.part, ws.rs, s, gs, N, d, B, st);      // gs = A^T q + 2 rs s
+        if (rc != NW_OK) return rc;
+        if (glogit_scale) {
+            if (kind == NW_SCORE_CLIP)
+                hipLaunchKernelGGL(nw_sum_kernel, dim3(1), dim3(256), 0, st, ws.gls, glogit_scale, B);
+            else if (hipMemsetAsync(glogit_scale, 0, 4, st) != hipSuccess)
+                return NW_ERR_LAUNCH;
+        }
+        NW_CHECK_LAUNCH();
+        return NW_OK;
+    }
     const unsigned kd = (unsigned)((d + 255) / 256);
     hipLaunchKernelGGL(nw_bwd_gq_kernel, dim3((unsigned)B, kd), dim3(256), 0, st, ws.A, ws.rq, q, s, gq, N, d, sup_batched);
     if (sup_batched)

@@ -132,6 +132,33 @@ def test_backward_random_shapes(dev, ops, O, i):
         np.testing.assert_allclose(ls.grad.item(), ls64.grad.item(), rtol=1e-4, atol=1e-6, err_msg=info)
 
 
+@pytest.mark.parametrize("B,N,d,C", [(64, 1000, 512, 200), (200, 1037, 96, 10), (1000, 150, 64, 5), (37, 4099, 32, 3),
+                                       (129, 257, 132, 7)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_backward_matrix_core_path(dev, ops, O, B, N, d, C, kind):
+    """Shapes past the B*N*d >= 2^22 threshold: both products of the backward run in nw_bwd_gemm_kernel
+    (ragged M, N and K; K split over workgroups for the tall and the wide case)."""
+    g = torch.Generator().manual_seed(B + N)
+    q0, s0 = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+    if kind == "dotproduct":
+        q0, s0 = q0 * d ** -0.25, s0 * d ** -0.25
+    sy = torch.randint(0, C, (N,), generator=g)
+    t = torch.randint(0, C, (B,), generator=g)
+    q64, s64 = q0.double().requires_grad_(True), s0.double().requires_grad_(True)
+    ls64 = torch.tensor(LS0, dtype=torch.float64, requires_grad=True)
+    F.nll_loss(O.nw_head_f64(q64, s64, sy, C, kind, ls64) if kind != "clip" else _clip_head_f64(q64, s64, sy, C, ls64),
+               t).backward()
+    q, s = q0.to(dev).requires_grad_(True), s0.to(dev).requires_grad_(True)
+    ls = torch.tensor(LS0, device=dev, requires_grad=True) if kind == "clip" else None
+    F.nll_loss(ops.nw_head(q, s, sy.to(dev), C, kind, ls), t.to(dev)).backward()
+    for got, ref in ((q.grad, q64.grad), (s.grad, s64.grad)):
+        ref = ref.numpy()
+        scale = max(float(np.abs(ref).max()), 1e-3)
+        np.testing.assert_allclose(got.cpu().numpy() / scale, ref / scale, rtol=1e-4, atol=1e-4)
+    if kind == "clip":
+        np.testing.assert_allclose(ls.grad.item(), ls64.grad.item(), rtol=1e-4, atol=1e-6)
+
+
 def _clip_head_f64(q, s, sy, C, ls):
     """The oracle's fp64 head takes logit_scale by value; this keeps it in the graph (kernel.py:35-44)."""
     qn = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
