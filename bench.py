@@ -165,9 +165,25 @@ def measure_backbone_configs(dev):
             with torch.no_grad():
                 return head(net(x), s, sy)
         t = time_kernel_events(k2, 10)
+        # what NWNet.predict runs after precompute() with enable_bn_folding(True, channels_last=True)
+        from nwhead_amd.model import fold_batchnorm
+        folded = fold_batchnorm(net).to(memory_format=torch.channels_last)
+        xcl = x.contiguous(memory_format=torch.channels_last)
+
+        def k2f():
+            with torch.no_grad():
+                return head(folded(xcl), s, sy)
+        tf = time_kernel_events(k2f, 10)
+        gf = 3.63 * 64                                        # GFLOP, ResNet-18 forward @224
         out["config_K2_resnet18_plus_head"] = {"images": 64, "N": 1000, "ms_per_call": t * 1e3,
-                                               "images_per_s": 64 / t, "backbone": "torch/MIOpen fp32"}
-        del net
+                                               "images_per_s": 64 / t, "backbone": "torch/MIOpen fp32",
+                                               "backbone_TFLOPs": gf / t / 1e3,
+                                               "frac_of_fp32_mfma_peak": gf / t / 1e3 / PEAK_F32_MFMA_TFLOPS,
+                                               "ms_per_call_bn_folded_channels_last": tf * 1e3,
+                                               "images_per_s_bn_folded_channels_last": 64 / tf,
+                                               "frac_of_fp32_mfma_peak_bn_folded_channels_last":
+                                                   gf / tf / 1e3 / PEAK_F32_MFMA_TFLOPS}
+        del net, folded
     except Exception as e:                                    # never lose the JSON line to an extra
         out["config_K2_resnet18_plus_head"] = {"error": repr(e)[:200]}
     try:
@@ -186,8 +202,10 @@ def measure_backbone_configs(dev):
             loss.backward()
             opt.step()
         t = time_kernel_events(k4, 5, warmup=2)
+        gf4 = 5.67 * 3 * 42                                   # GFLOP, DenseNet-121 fwd+bwd over 32 + 10 images @224
         out["config_K4_densenet121_train_step"] = {"B": 32, "n_way": 10, "n_shot": 1, "ms_per_step": t * 1e3,
-                                                   "backbone": "torch/MIOpen fp32"}
+                                                   "backbone": "torch/MIOpen fp32", "backbone_TFLOPs": gf4 / t / 1e3,
+                                                   "frac_of_fp32_mfma_peak": gf4 / t / 1e3 / PEAK_F32_MFMA_TFLOPS}
     except Exception as e:
         out["config_K4_densenet121_train_step"] = {"error": repr(e)[:200]}
     return out
