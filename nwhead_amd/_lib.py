@@ -56,6 +56,10 @@ def load():
         raise NWHipError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run __graft_entry__.build() "
             "(or `make -C nwhead_amd/csrc`). There is no CPU fallback.")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so); it must be in the process before this
+    # library's NEEDED libamdhip64 is resolved, or the loader pulls /opt/rocm's copy in and the process ends
+    # up with two runtimes, the second of which cannot open the device (nw_device_check: no gfx950 device).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch

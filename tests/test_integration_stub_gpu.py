@@ -40,3 +40,14 @@ def test_integration_stub_runs_as_printed():
         for out in (plain, fast):
             assert out.shape == (B, C)
             assert abs(out.cpu().double().numpy() - ref).max() < 5e-5
+
+
+def test_build_then_smoke_in_one_process():
+    """The library may be loaded before anything has imported torch (build() does): _lib.load() must bring
+    torch's own HIP runtime in first, or the process gets two runtimes and the device check fails."""
+    import subprocess
+    import sys
+    code = ("import __graft_entry__ as g; g.build(); from nwhead_amd import _lib; import torch; "
+            "assert torch.cuda.is_available(); _lib.check(_lib.load().nw_device_check(), 'nw_device_check'); print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
