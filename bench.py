@@ -124,6 +124,21 @@ def measure_train_head(B, N, d, C, dev, iters=30):
             "TFLOPs_fwd_plus_bwd_products": 6 * B * N * d / dt / 1e12}
 
 
+def measure_shuffled(B, N, d, C, dev, iters=20):
+    """SURVEY 8d's shuffled-label variant of the K3 launch (B coalesced queries vs the whole bank): the tile
+    kernels sum per run of equal labels, so the prepared bank keeps a class-sorted copy (ops.SplitBank(s, labels))."""
+    from nwhead_amd import ops
+    q, s, sy = make_inputs(B, N, d, C, dev)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(dev)
+    sy_sh = sy[perm].contiguous()
+    s_sh = s[perm].contiguous()
+    bank_sorted, bank_sh = ops.SplitBank(s, sy), ops.SplitBank(s_sh, sy_sh)
+    t_sorted = time_kernel_events(lambda: ops.nw_head(q, s, sy, C, support_cache=bank_sorted), iters)
+    t_sh = time_kernel_events(lambda: ops.nw_head(q, s_sh, sy_sh, C, support_cache=bank_sh), iters)
+    return {"B": B, "N": N, "ms_per_launch_sorted": t_sorted * 1e3, "ms_per_launch_shuffled": t_sh * 1e3,
+            "query_pred_per_s_shuffled": B / t_sh}
+
+
 def measure_influence(B, N, C, dev, iters=100):
     """K5: support_influence over a 10000-image support bank (HBM-bound streaming kernel)."""
     from nwhead_amd import ops
@@ -233,11 +248,27 @@ def cpu_baseline(B_sample, N, d, C, budget_s=20.0):
             t0 = time.perf_counter()
             O.nw_head_f32(q, s, sy, C)
             times.append(time.perf_counter() - t0)
+        # SURVEY 8d also asks for the single-thread figure: 8 queries, two calls
+        torch.set_num_threads(1)
+        q1 = q[:8]
+        O.nw_head_f32(q1, s, sy, C)
+        t0 = time.perf_counter()
+        O.nw_head_f32(q1, s, sy, C)
+        t1 = time.perf_counter() - t0
+        torch.set_num_threads(cores)
     times.sort()
     med = times[len(times) // 2]
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), model)
+    except OSError:
+        pass
     return {"value": B_sample / med, "unit": "query-predictions/s", "cores": cores, "kind": "port",
             "sample": f"B={B_sample} queries x full bank N={N}, d={d}, C={C}; median of {len(times)} calls, "
-                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+                      f"torch {torch.__version__} CPU fp32, {cores} threads",
+            "value_1_thread": 8 / t1, "sample_1_thread": f"B=8 queries x the same bank, one call after one warm-up",
+            "cpu_model": model, "host_cores_total": os.cpu_count()}
 
 
 def main():
@@ -408,6 +439,7 @@ def main():
             line["config_K2_head"] = measure_shape(64, 1000, 512, 200, dev, 100)
             line["config_K5_support_influence"] = measure_influence(256, 10000, 200, dev)
             line["head_train_step_T"] = measure_train_head(256, 10000, 512, 200, dev)
+            line["K3_shuffled_labels"] = measure_shuffled(4096, N, d, C, dev)
             line.update(measure_backbone_configs(dev))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(32, N, d, C)
