@@ -47,8 +47,9 @@ class NWNet(nn.Module):
     def __init__(self, featurizer, n_classes, support_dataset=None, feat_dim=None, proj_dim=0,
                  kernel_type='euclidean', train_type='random', n_way=None, n_shot=1,
                  n_shot_random=1, n_shot_full=100, n_shot_cluster=1, n_neighbors=10,
-                 env_array=None, debug_mode=False, device='cuda:0', return_mask=False):
+                 env_array=None, debug_mode=False, device='cuda:0', return_mask=False, cluster_backend='auto'):
         super().__init__()
+        self.cluster_backend = cluster_backend   # not in the reference: where 'cluster' mode's k-means runs (utils.compute_clusters)
         if support_dataset is not None:
             assert hasattr(support_dataset, 'targets'), 'Support set must have .targets attribute'
         if proj_dim > 0:
@@ -99,7 +100,8 @@ class NWNet(nn.Module):
     def process_support_eval(self, support_dataset):
         self.support_eval = SupportSetEval(support_dataset, self.n_classes, self.n_shot_random,
                                            self.n_shot_full, n_shot_cluster=self.n_shot_cluster,
-                                           n_neighbors=self.n_neighbors, env_array=self.env_array)
+                                           n_neighbors=self.n_neighbors, env_array=self.env_array,
+                                           cluster_backend=self.cluster_backend)
 
     @torch.no_grad()
     def _compute_all_support_feats(self):

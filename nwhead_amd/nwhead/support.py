@@ -72,8 +72,9 @@ class SupportSetEval(SupportSet):
     MODES = ('random', 'full', 'cluster', 'ensemble', 'knn', 'hnsw')
 
     def __init__(self, support_set, n_classes, n_shot_random, n_shot_full, n_shot_cluster=3,
-                 n_neighbors=20, env_array=None):
+                 n_neighbors=20, env_array=None, cluster_backend="auto"):
         super().__init__(support_set, n_classes, env_array)
+        self.cluster_backend = cluster_backend        # utils.compute_clusters: 'auto' | 'sklearn' | 'device'
         self.n_shot_random, self.n_shot_full = n_shot_random, n_shot_full
         self.n_shot_cluster, self.n_neighbors = n_shot_cluster, n_neighbors
         self.full_datasets = [FullDataset(env, n_shot_full) for env in self.env_datasets]
@@ -84,7 +85,7 @@ class SupportSetEval(SupportSet):
         self.full_feat, self.full_y, self.full_meta = sfeat, sy, smeta
         self.full_feat_sep, self.full_y_sep, self.full_meta_sep = sfeat_env, sy_env, smeta_env
         dev = sfeat.device
-        cf, cy = compute_clusters(sfeat, sy, self.n_shot_cluster)
+        cf, cy = compute_clusters(sfeat, sy, self.n_shot_cluster, backend=self.cluster_backend)
         self.cluster_feat, self.cluster_y = cf.to(dev), cy.to(dev)
         self.random_iter = InfiniteUniformClassLoader(FeatureDataset(sfeat, sy, smeta), self.n_shot_random)
         self.knn = KNN(sfeat, sy, n_neighbors=self.n_neighbors)

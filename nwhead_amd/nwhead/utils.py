@@ -130,9 +130,78 @@ class HNSW(KNN):
     this image, so 'hnsw' mode is served by the exact search above (a superset in recall)."""
 
 
-def compute_clusters(embeddings, labels, n_clusters, closest=False):
-    """Per-class k-means centroids (utils.py:218-246).  k-means itself is third-party CPU code in
-    the reference (sklearn KMeans, random_state=0) and stays so here: out of the HIP scope."""
+def _class_argmax(values, inv, n_groups):
+    """Row index of the largest value inside every group (lowest index on ties), values:(N,), inv:(N,) group ids."""
+    N = values.shape[0]
+    best = torch.full((n_groups,), -float("inf"), device=values.device).scatter_reduce(0, inv, values, "amax")
+    rows = torch.arange(N, device=values.device)
+    cand = torch.where(values >= best[inv], rows, torch.full_like(rows, N))
+    return torch.full((n_groups,), N, dtype=torch.int64, device=values.device).scatter_reduce(0, inv, cand, "amin")
+
+
+def kmeans_per_class_device(emb, lab, n_clusters, closest=False, max_iter=100):
+    """Per-class k-means on the device, all classes at once (the reference runs sklearn's
+    KMeans once per class on the host, utils.py:218-246).
+
+    Lloyd iterations: the assignment step is ONE distance matrix points x all (class, cluster) centroids
+    from the HIP scores kernel (ops.nw_scores) restricted to each point's own class; the update step is a
+    one-hot matmul (deterministic, unlike atomics).  Initialisation is deterministic maximin seeding inside
+    each class (first centre = the point nearest the class mean, every further one = the point farthest
+    from the centres chosen so far), so results do not depend on a RNG; an emptied cluster keeps its centre.
+    n_clusters == 1 is the class mean, which is also what sklearn returns.
+    Returns (centroids (Cn*k, d) fp32 on emb's device, labels (Cn*k,) int64 on the host like the reference)."""
+    from .. import ops
+    emb = emb.detach().float().contiguous()
+    lab = lab.detach().to(emb.device)
+    classes, inv = torch.unique(lab, return_inverse=True)
+    Cn, k, N = classes.numel(), int(n_clusters), emb.shape[0]
+    rows = torch.arange(N, device=emb.device)
+
+    def class_means():
+        oh = torch.zeros(Cn, N, device=emb.device).index_put_((inv, rows), torch.ones((), device=emb.device))
+        return (oh @ emb) / oh.sum(1, keepdim=True)
+
+    cent = class_means()[:, None, :]                                   # (Cn, 1, d)
+    if k > 1:
+        def dist_to(one_per_class):                                    # (Cn, d) -> (N,) distance to own class's row
+            return -ops.nw_scores(emb, one_per_class.contiguous())[rows, inv]
+        chosen = [emb[_class_argmax(-dist_to(cent[:, 0]), inv, Cn)]]
+        dmin = dist_to(chosen[0])
+        for _ in range(1, k):
+            chosen.append(emb[_class_argmax(dmin, inv, Cn)])
+            dmin = torch.minimum(dmin, dist_to(chosen[-1]))
+        cent = torch.stack(chosen, dim=1)                              # (Cn, k, d)
+    assign = None
+    for _ in range(max_iter if k > 1 else 0):
+        sc = ops.nw_scores(emb, cent.reshape(Cn * k, -1).contiguous())  # (N, Cn*k) = -distance
+        own = sc.view(N, Cn, k)[rows, inv]                             # (N, k): this point's class only
+        new_assign = own.argmax(1)
+        if assign is not None and torch.equal(new_assign, assign):
+            break
+        assign = new_assign
+        oh = torch.zeros(Cn * k, N, device=emb.device).index_put_((inv * k + assign, rows), torch.ones((), device=emb.device))
+        cnt = oh.sum(1, keepdim=True)
+        upd = (oh @ emb) / cnt.clamp_min(1)
+        cent = torch.where(cnt.view(Cn, k, 1) > 0, upd.view(Cn, k, -1), cent)
+    cent = cent.reshape(Cn * k, -1).contiguous()
+    if closest:                                                        # nearest actual point of the class
+        own = ops.nw_scores(emb, cent).view(N, Cn, k)[rows, inv]       # (N, k)
+        pick = torch.stack([_class_argmax(own[:, j].contiguous(), inv, Cn) for j in range(k)], dim=1)
+        cent = emb[pick.reshape(-1)].contiguous()
+    return cent, classes.repeat_interleave(k).cpu()
+
+
+def compute_clusters(embeddings, labels, n_clusters, closest=False, backend="auto"):
+    """Per-class k-means centroids (utils.py:218-246).
+    backend 'sklearn': the reference's own call (KMeans(random_state=0) per class on the host) -- what
+    pins parity for n_clusters > 1, where the optimum found depends on sklearn's seeding.
+    backend 'device': kmeans_per_class_device (HIP distance kernel, deterministic seeding).
+    backend 'auto' (default): the device for n_clusters == 1 with features on the GPU (the class mean either
+    way: same centroids, no host round trip of the bank), sklearn otherwise."""
+    if backend not in ("auto", "sklearn", "device"):
+        raise ValueError(backend)
+    if backend == "device" or (backend == "auto" and n_clusters == 1 and not closest and embeddings.is_cuda):
+        return kmeans_per_class_device(embeddings, labels, n_clusters, closest)
     from sklearn.cluster import KMeans
     emb = embeddings.detach().cpu()
     lab = labels.detach().cpu()
