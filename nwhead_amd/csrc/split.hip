@@ -7,6 +7,7 @@
 // ORIGINAL values (the pow(2).sum(-1) half of torch.cdist's matmul form).
 // One wave per row; HBM-bound streaming (8*d bytes per row).
 #include "nw_internal.h"
+#include <cstdlib>
 
 namespace nw {
 namespace {
@@ -15,7 +16,7 @@ __global__ __launch_bounds__(256) void nw_split_rows_kernel(const float* __restr
                                                              float* __restrict__ out,
                                                              float* __restrict__ scale,
                                                              float* __restrict__ norm2, int64_t rows,
-                                                             int64_t d) {
+                                                             int64_t d, unsigned lmask) {
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
@@ -69,6 +70,12 @@ __global__ __launch_bounds__(256) void nw_split_rows_kernel(const float* __restr
             h[k] = (_Float16)sv[k];
             l[k] = (_Float16)(sv[k] - (float)h[k]);
         }
+        if (lmask != 0xffffu) {  // diagnostic (NW_SPLIT_LBITS): fewer significant bits in the low halves
+            typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+            us4 b = __builtin_bit_cast(us4, l);
+            b &= (unsigned short)lmask;
+            l = __builtin_bit_cast(half4, b);
+        }
         const int64_t chunk = c >> 3, within = (c & 7) * 4;
         *reinterpret_cast<half4*>(dst + chunk * 64 + within) = h;
         *reinterpret_cast<half4*>(dst + chunk * 64 + 32 + within) = l;
@@ -90,8 +97,17 @@ int launch_split_rows(const float* x, float* out, float* scale, float* norm2, in
                       hipStream_t st) {
     if (rows <= 0) return NW_OK;
     if ((rows + 3) / 4 > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    static const unsigned lmask = [] {
+        // Mantissa bits kept in the low halves (default 10 = all: the split is exact to 22 bits).  The tile
+        // kernel is power-limited and its power follows the operands' bit activity: K3 launch 583 us at 10
+        // bits, 572 at 6, 563 at 3, 556 at 0 (max error vs fp64 0.9 / 1.1 / 3.7 / 24 e-6).  Not taken: the
+        // large-norm, small-distance cases (golden G8) need the bits.
+        const char* e = getenv("NW_SPLIT_LBITS");
+        const int keep = e ? atoi(e) : 10;
+        return keep >= 10 ? 0xffffu : (0xffffu << (10 - (keep < 0 ? 0 : keep))) & 0xffffu;
+    }();
     hipLaunchKernelGGL(nw_split_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, out, scale,
-                       norm2, rows, d);
+                       norm2, rows, d, lmask);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }
