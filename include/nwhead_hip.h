@@ -180,6 +180,19 @@ int nw_topk_f32(const float *scores, int64_t *idx_out, float *val_out,
                 int64_t B, int64_t N, int64_t k, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Eval-mode BatchNorm (+ ReLU) of the pre-activation backbones as one pass: out = max(x * scale[c] +
+ * shift[c], 0).  Replaces the BatchNorm2d -> ReLU pairs in front of the convolutions of
+ * model/densenet.py:33-60 (_DenseLayer norm1/relu1), :82-91 (_Transition) and :139 + :160 (norm5 + relu)
+ * at inference, where scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale.
+ *   x      n planes-of-c: element (i, ch, p) at x[i * x_batch_stride + ch * hw + p]  (the first c channels
+ *          of a wider NCHW slab qualify: x_batch_stride >= c * hw)
+ *   out    (n, c, hw) contiguous;  scale, shift (c,);  relu != 0 applies the max
+ * ------------------------------------------------------------------------------------------- */
+int nw_scale_shift_relu_f32(const float *x, const float *scale, const float *shift, float *out,
+                            int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride, int relu,
+                            void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): device time of the TILE kernel alone -- the kernel the
  * roofline is quoted on (nw_fused_kernel / nw_fused_f16p_kernel), without the small kernels around
  * it (query split, run tables, merge).  While enabled, every forward brackets its tile-kernel launch

@@ -164,6 +164,8 @@ class _DenseLayer(nn.Sequential):
 
     def forward(self, x):
         # relu1 must not run in place on a slab/concat that later layers re-read
+        if isinstance(self.norm1, ScaleShiftReLU):       # folded inference copy (fold_batchnorm)
+            return self.conv2(self.relu2(self.conv1(self.norm1(x))))
         y = self.conv1(F.relu(self.norm1(x)))
         y = self.conv2(self.relu2(self.norm2(y)))
         return F.dropout(y, self.drop_rate, self.training) if self.drop_rate > 0 else y
@@ -226,6 +228,26 @@ class DenseNet(nn.Module):
 
     def forward(self, x):
         return torch.flatten(F.adaptive_avg_pool2d(F.relu(self.features(x)), (1, 1)), 1)
+
+
+class ScaleShiftReLU(nn.Module):
+    """Eval-mode BatchNorm2d followed by ReLU as one pass, y = max(a_c x + b_c, 0): on the MI355X the HIP
+    kernel nw_scale_shift_relu_f32 (ops.scale_shift_relu), on CPU tensors the same two torch ops the
+    reference backbone runs.  Built by fold_batchnorm for the BN -> ReLU -> conv layers that cannot fold."""
+
+    def __init__(self, bn, relu=True):
+        super().__init__()
+        a = bn.weight.detach() * torch.rsqrt(bn.running_var.detach() + bn.eps)
+        self.register_buffer("scale", a.clone())
+        self.register_buffer("shift", (bn.bias.detach() - bn.running_mean.detach() * a).clone())
+        self.relu = relu
+
+    def forward(self, x):
+        if x.is_cuda:
+            from .. import ops
+            return ops.scale_shift_relu(x, self.scale, self.shift, self.relu)
+        y = x * self.scale.view(1, -1, 1, 1) + self.shift.view(1, -1, 1, 1)
+        return F.relu(y) if self.relu else y
 
 
 # ----------------------------------------------------------------------------- CIFAR DenseNet
@@ -353,7 +375,9 @@ def CIFAR_DenseNet121(pretrained=False, num_classes=10, bias=True, **kw):
 # Eval-mode BatchNorm folding.  In ResNet / Bottleneck blocks and the ResNet stem a
 # BatchNorm directly follows a bias-free convolution, so at inference (running statistics) the pair is
 # one convolution: w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps).
-# The pre-activation nets (CIFAR_ResNet blocks, DenseNets) apply BN -> ReLU -> conv and cannot fold.
+# The pre-activation blocks of CIFAR_ResNet apply BN -> ReLU -> conv and cannot fold.  DenseNet (densenet.py)
+# mixes both: conv0 -> norm0 and every layer's conv1 -> norm2 fold; norm1 / transition norm / norm5 sit in
+# front of their ReLU and become ScaleShiftReLU (one pass instead of torch's batch-norm + relu kernels).
 # ---------------------------------------------------------------------------------------------
 def _fold_pair(conv, bn):
     scale = bn.weight.detach() * torch.rsqrt(bn.running_var.detach() + bn.eps)
@@ -366,11 +390,23 @@ def _fold_pair(conv, bn):
 
 
 def fold_batchnorm(model):
-    """A deep copy of `model` (eval mode) in which every conv -> BatchNorm pair of the ResNet family is one
-    convolution; other architectures come back unchanged.  For inference only: the copy shares nothing with
-    the original and must be re-made after the weights change."""
+    """A deep copy of `model` (eval mode) in which every conv -> BatchNorm pair of the ResNet family and of
+    DenseNet is one convolution and DenseNet's BatchNorm -> ReLU pairs are one pass; other architectures come
+    back unchanged.  For inference only: the copy shares nothing with the original and must be re-made after
+    the weights change."""
     import copy
     m = copy.deepcopy(model).eval()
+    if isinstance(m, DenseNet):
+        f = m.features
+        f.conv0, f.norm0 = _fold_pair(f.conv0, f.norm0), nn.Identity()
+        for mod in list(m.modules()):
+            if isinstance(mod, _DenseLayer):
+                mod.conv1, mod.norm2 = _fold_pair(mod.conv1, mod.norm2), nn.Identity()
+                mod.norm1, mod.relu1 = ScaleShiftReLU(mod.norm1), nn.Identity()
+            elif isinstance(mod, _Transition):
+                mod.norm, mod.relu = ScaleShiftReLU(mod.norm), nn.Identity()
+        f.norm5 = ScaleShiftReLU(f.norm5)       # DenseNet.forward's F.relu on top is then the identity
+        return m
     for mod in m.modules():
         if isinstance(mod, (BasicBlock, Bottleneck, ResNet)) or (isinstance(mod, CIFAR_ResNet) and hasattr(mod, "bn1")):
             k = 1

@@ -311,6 +311,22 @@ def nw_merge(packed_all, B, n_classes, out=None, class_lo=None, c_local=None):
     return out
 
 
+def scale_shift_relu(x, scale, shift, relu=True):
+    """out = max(x * scale[c] + shift[c], 0) for an (n, c, h, w) fp32 activation whose (c, h, w) part is
+    contiguous (a channel prefix of a wider slab is fine): eval-mode BatchNorm + ReLU in one pass."""
+    _need_hip(x, scale, shift)
+    n, c, h, w = x.shape
+    hw = h * w
+    if x.dtype != torch.float32 or (n * c * hw and (x.stride(3) != 1 or x.stride(2) != w or x.stride(1) != hw)):
+        x = x.float().contiguous()
+    out = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().nw_scale_shift_relu_f32(_ptr(x), _ptr(_f32c(scale)), _ptr(_f32c(shift)), _ptr(out), n, c, hw,
+                                                       x.stride(0) if n > 1 else c * hw, int(bool(relu)), _stream(x)),
+                   "nw_scale_shift_relu_f32")
+    return out
+
+
 def support_influence_idx(probs, qy, w, sy):
     """Index-label form of util/metric.py:23-50: probs (B,C), qy (B,), w (B,N), sy (N,) -> (B,N)."""
     _need_hip(probs, qy, w, sy)

@@ -42,14 +42,15 @@ def test_load_model_contract():
 
 
 def test_fold_batchnorm_matches_eval_mode():
-    """model.fold_batchnorm (SURVEY 8f N1): conv -> BN pairs of the ResNet family become one convolution;
-    same eval-mode features up to fp32 re-association; pre-activation nets come back unchanged."""
+    """model.fold_batchnorm: conv -> BN pairs of the ResNet family and of DenseNet become one
+    convolution, DenseNet's BN -> ReLU pairs one pass; same eval-mode features up to fp32 re-association;
+    the CIFAR pre-activation nets come back unchanged."""
     import torch.nn as nn
     from nwhead_amd.model import fold_batchnorm, load_model
     from tests.procedural import fill_procedural
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 3, 64, 64, generator=g)
-    for name in ("resnet18", "resnet50"):
+    for name in ("resnet18", "resnet50", "densenet121"):
         net = load_model(name)
         fill_procedural(net)
         net.train()

@@ -116,3 +116,39 @@ def test_bn_folding_through_nwnet():
     net.train()
     assert net._folded is None
     net.eval()
+
+
+@pytest.mark.parametrize("shape,prefix", [((3, 40, 14, 14), 24), ((2, 17, 7, 7), 17), ((1, 8, 5, 3), 5), ((4, 64, 56, 56), 64)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_scale_shift_relu_kernel(shape, prefix, relu):
+    """nw_scale_shift_relu_f32 (eval BatchNorm + ReLU in one pass) on a channel prefix of a wider slab,
+    float4 and scalar planes, against the two torch ops it replaces."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    slab = torch.randn(*shape, generator=g).cuda()
+    a, b = torch.randn(prefix, generator=g).cuda(), torch.randn(prefix, generator=g).cuda()
+    x = slab[:, :prefix]
+    got = ops.scale_shift_relu(x, a, b, relu)
+    ref = x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    ref = torch.relu(ref) if relu else ref
+    assert got.is_contiguous() and got.shape == x.shape
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_densenet_folded_copy_on_the_device():
+    """fold_batchnorm(DenseNet): conv0+norm0 and conv1+norm2 folded, the other BatchNorm -> ReLU pairs through the
+    HIP kernel; same features as the eval-mode network."""
+    from nwhead_amd.model import fold_batchnorm, load_model
+    from tests.procedural import fill_procedural
+    net = load_model("densenet121")
+    fill_procedural(net)
+    net = net.cuda().train()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        net(torch.randn(4, 3, 64, 64, generator=g).cuda())        # running statistics off their init
+        net.eval()
+        folded = fold_batchnorm(net)
+        x = torch.randn(3, 3, 96, 96, generator=g).cuda()
+        a, b = net(x), folded(x)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules())
+    torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-5 * a.abs().max().item())
