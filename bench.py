@@ -221,8 +221,22 @@ def measure_backbone_configs(dev):
         out["config_K4_densenet121_train_step"] = {"B": 32, "n_way": 10, "n_shot": 1, "ms_per_step": t * 1e3,
                                                    "backbone": "torch/MIOpen fp32", "backbone_TFLOPs": gf4 / t / 1e3,
                                                    "frac_of_fp32_mfma_peak": gf4 / t / 1e3 / PEAK_F32_MFMA_TFLOPS}
+        # the inference side of the same backbone (precompute / predict): plain eval vs the folded copy whose
+        # BatchNorm -> ReLU pairs run in nw_scale_shift_relu_f32
+        from nwhead_amd.model import fold_batchnorm
+        dn.eval()
+        del opt
+        x64 = torch.randn(64, 3, 224, 224, generator=g).to(dev)
+        with torch.no_grad():
+            folded = fold_batchnorm(dn)
+            t_plain = time_kernel_events(lambda: dn(x64), 5, warmup=3)
+            t_fold = time_kernel_events(lambda: folded(x64), 5, warmup=3)
+        out["densenet121_eval_forward"] = {"images": 64, "ms_plain": t_plain * 1e3, "ms_folded": t_fold * 1e3,
+                                           "images_per_s_folded": 64 / t_fold,
+                                           "frac_of_fp32_mfma_peak_folded": 5.67 * 64 / t_fold / 1e3 / PEAK_F32_MFMA_TFLOPS}
     except Exception as e:
-        out["config_K4_densenet121_train_step"] = {"error": repr(e)[:200]}
+        out.setdefault("config_K4_densenet121_train_step", {"error": repr(e)[:200]})
+        out.setdefault("densenet121_eval_forward", {"error": repr(e)[:200]})
     return out
 
 

@@ -111,6 +111,11 @@ class ResNet(nn.Module):
 
 
 # ----------------------------------------------------------------------------- CIFAR pre-act ResNet
+def _bn_relu(bn, x):
+    """BatchNorm -> ReLU in front of a convolution; one pass in a folded inference copy (ScaleShiftReLU)."""
+    return bn(x) if isinstance(bn, ScaleShiftReLU) else F.relu(bn(x))
+
+
 class PreActBlock(nn.Module):
     """bn-relu-conv3x3-bn-relu-conv3x3 with the shortcut taken after the first activation
     (model/resnet.py:111-134)."""
@@ -125,7 +130,7 @@ class PreActBlock(nn.Module):
             self.shortcut = nn.Sequential(_conv(in_planes, planes, 1, stride))
 
     def forward(self, x):
-        a = F.relu(self.bn1(x))
+        a = _bn_relu(self.bn1, x)
         y = self.conv2(F.relu(self.bn2(self.conv1(a))))
         return y + self.shortcut(a)
 
@@ -260,7 +265,7 @@ class CifarBottleneck(nn.Module):
         self.bn2, self.conv2 = nn.BatchNorm2d(4 * growth_rate), _conv(4 * growth_rate, growth_rate, 3, 1, 1)
 
     def forward(self, x):
-        y = self.conv2(F.relu(self.bn2(self.conv1(F.relu(self.bn1(x))))))
+        y = self.conv2(F.relu(self.bn2(self.conv1(_bn_relu(self.bn1, x)))))
         return torch.cat([y, x], 1)
 
 
@@ -270,7 +275,7 @@ class CifarTransition(nn.Module):
         self.bn, self.conv = nn.BatchNorm2d(in_planes), _conv(in_planes, out_planes, 1)
 
     def forward(self, x):
-        return F.avg_pool2d(self.conv(F.relu(self.bn(x))), 2)
+        return F.avg_pool2d(self.conv(_bn_relu(self.bn, x)), 2)
 
 
 class CIFAR_DenseNet(nn.Module):
@@ -300,7 +305,7 @@ class CIFAR_DenseNet(nn.Module):
         x = self.trans2(self.dense2(x))
         x = self.trans3(self.dense3(x))
         x = self.dense4(x)
-        return torch.flatten(F.avg_pool2d(F.relu(self.bn(x)), 4), 1)
+        return torch.flatten(F.avg_pool2d(_bn_relu(self.bn, x), 4), 1)
 
 
 # ----------------------------------------------------------------------------- factories (load_model names)
@@ -375,9 +380,10 @@ def CIFAR_DenseNet121(pretrained=False, num_classes=10, bias=True, **kw):
 # Eval-mode BatchNorm folding.  In ResNet / Bottleneck blocks and the ResNet stem a
 # BatchNorm directly follows a bias-free convolution, so at inference (running statistics) the pair is
 # one convolution: w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps).
-# The pre-activation blocks of CIFAR_ResNet apply BN -> ReLU -> conv and cannot fold.  DenseNet (densenet.py)
-# mixes both: conv0 -> norm0 and every layer's conv1 -> norm2 fold; norm1 / transition norm / norm5 sit in
-# front of their ReLU and become ScaleShiftReLU (one pass instead of torch's batch-norm + relu kernels).
+# The pre-activation designs (DenseNet, CIFAR_DenseNet, CIFAR_ResNet's PreActBlock) apply BN -> ReLU -> conv
+# -> BN -> ReLU -> conv: the inner conv -> BN pair (and the stems') folds; the BatchNorms in front of a ReLU
+# (norm1 / bn1, the transitions', the last one) become ScaleShiftReLU (one pass instead of torch's batch-norm
+# + relu kernels).
 # ---------------------------------------------------------------------------------------------
 def _fold_pair(conv, bn):
     scale = bn.weight.detach() * torch.rsqrt(bn.running_var.detach() + bn.eps)
@@ -407,6 +413,12 @@ def fold_batchnorm(model):
                 mod.norm, mod.relu = ScaleShiftReLU(mod.norm), nn.Identity()
         f.norm5 = ScaleShiftReLU(f.norm5)       # DenseNet.forward's F.relu on top is then the identity
         return m
+    for mod in list(m.modules()):
+        if isinstance(mod, (PreActBlock, CifarBottleneck)):
+            mod.conv1, mod.bn2 = _fold_pair(mod.conv1, mod.bn2), nn.Identity()
+            mod.bn1 = ScaleShiftReLU(mod.bn1)
+        elif isinstance(mod, (CifarTransition, CIFAR_DenseNet)):
+            mod.bn = ScaleShiftReLU(mod.bn)
     for mod in m.modules():
         if isinstance(mod, (BasicBlock, Bottleneck, ResNet)) or (isinstance(mod, CIFAR_ResNet) and hasattr(mod, "bn1")):
             k = 1

@@ -43,8 +43,8 @@ def test_load_model_contract():
 
 def test_fold_batchnorm_matches_eval_mode():
     """model.fold_batchnorm: conv -> BN pairs of the ResNet family and of DenseNet become one
-    convolution, DenseNet's BN -> ReLU pairs one pass; same eval-mode features up to fp32 re-association;
-    the CIFAR pre-activation nets come back unchanged."""
+    convolution, the pre-activation nets' BN -> ReLU pairs one pass (ScaleShiftReLU); same eval-mode features
+    up to fp32 re-association."""
     import torch.nn as nn
     from nwhead_amd.model import fold_batchnorm, load_model
     from tests.procedural import fill_procedural
@@ -67,8 +67,12 @@ def test_fold_batchnorm_matches_eval_mode():
     for name in ("CIFAR_ResNet18", "CIFAR_DenseNet121"):
         net = load_model(name)
         fill_procedural(net)
+        net.train()
+        with torch.no_grad():
+            net(torch.randn(4, 3, 32, 32, generator=g))
         net.eval()
         folded = fold_batchnorm(net)
+        assert not any(isinstance(m, nn.BatchNorm2d) for m in folded.modules())
         with torch.no_grad():
             a, b = net(x32), folded(x32)
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * a.abs().max().item())

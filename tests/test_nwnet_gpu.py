@@ -90,7 +90,8 @@ def test_errors(net_and_g):
         net.support_eval.get_support("nope")
 
 
-def test_bn_folding_through_nwnet():
+@pytest.mark.parametrize("arch", ["CIFAR_ResNet18", "resnet18"])
+def test_bn_folding_through_nwnet(arch):
     """enable_bn_folding(): precompute() / predict() run the folded copy in eval mode, train() drops it, the
     state_dict is unchanged, and the predictions agree with the unfolded network."""
     from nwhead_amd.data import SyntheticImages
@@ -98,7 +99,7 @@ def test_bn_folding_through_nwnet():
     from nwhead_amd.nwhead.nw import NWNet
     from tests.procedural import fill_procedural
     ds = SyntheticImages(6, 5, 32, seed=2)
-    feat = load_model("CIFAR_ResNet18")
+    feat = load_model(arch)
     fill_procedural(feat)
     net = NWNet(feat, 5, support_dataset=ds, n_shot_full=6, device="cuda:0").to("cuda:0").eval()
     x = torch.stack([ds[i][0] for i in range(0, 30, 3)]).to("cuda:0")
@@ -109,7 +110,9 @@ def test_bn_folding_through_nwnet():
         net.enable_bn_folding()
         net.precompute()
         assert net._folded is not None
-        assert not any(isinstance(m, nn.BatchNorm2d) and m is not None for m in [getattr(net._folded.inner, 'bn1', None)])
+        # the ResNet family's copy is kept in channels_last; the pre-activation copy (HIP BatchNorm+ReLU) stays NCHW
+        assert hasattr(net._folded, "inner") == (arch == "resnet18")
+        assert not any(isinstance(m, nn.BatchNorm2d) for m in net._folded.modules())
         out = net.predict(x, "full")
     assert torch.allclose(out, ref, rtol=1e-3, atol=1e-3), (out - ref).abs().max()
     assert list(net.state_dict().keys()) == keys
@@ -135,20 +138,21 @@ def test_scale_shift_relu_kernel(shape, prefix, relu):
     torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
 
 
-def test_densenet_folded_copy_on_the_device():
-    """fold_batchnorm(DenseNet): conv0+norm0 and conv1+norm2 folded, the other BatchNorm -> ReLU pairs through the
-    HIP kernel; same features as the eval-mode network."""
+@pytest.mark.parametrize("arch,size", [("densenet121", 96), ("CIFAR_DenseNet121", 32), ("CIFAR_ResNet18", 32)])
+def test_preactivation_folded_copy_on_the_device(arch, size):
+    """fold_batchnorm on the pre-activation nets: inner conv+BN pairs folded, the BatchNorm -> ReLU pairs through
+    the HIP kernel; same features as the eval-mode network."""
     from nwhead_amd.model import fold_batchnorm, load_model
     from tests.procedural import fill_procedural
-    net = load_model("densenet121")
+    net = load_model(arch)
     fill_procedural(net)
     net = net.cuda().train()
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
-        net(torch.randn(4, 3, 64, 64, generator=g).cuda())        # running statistics off their init
+        net(torch.randn(4, 3, size, size, generator=g).cuda())    # running statistics off their init
         net.eval()
         folded = fold_batchnorm(net)
-        x = torch.randn(3, 3, 96, 96, generator=g).cuda()
+        x = torch.randn(3, 3, size, size, generator=g).cuda()
         a, b = net(x), folded(x)
     assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules())
     torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-5 * a.abs().max().item())

@@ -8,7 +8,8 @@ dev = torch.device("cuda:0")
 arch = sys.argv[1] if len(sys.argv) > 1 else "densenet121"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 net = load_model(arch).to(dev).eval()
-x = torch.randn(n, 3, 224, 224, device=dev)
+side = int(sys.argv[3]) if len(sys.argv) > 3 else 224
+x = torch.randn(n, 3, side, side, device=dev)
 folded = fold_batchnorm(net)
 with torch.no_grad():
     ref = net(x)
