@@ -402,19 +402,17 @@ def fold_batchnorm(model):
     the weights change."""
     import copy
     m = copy.deepcopy(model).eval()
-    if isinstance(m, DenseNet):
-        f = m.features
-        f.conv0, f.norm0 = _fold_pair(f.conv0, f.norm0), nn.Identity()
-        for mod in list(m.modules()):
-            if isinstance(mod, _DenseLayer):
-                mod.conv1, mod.norm2 = _fold_pair(mod.conv1, mod.norm2), nn.Identity()
-                mod.norm1, mod.relu1 = ScaleShiftReLU(mod.norm1), nn.Identity()
-            elif isinstance(mod, _Transition):
-                mod.norm, mod.relu = ScaleShiftReLU(mod.norm), nn.Identity()
-        f.norm5 = ScaleShiftReLU(f.norm5)       # DenseNet.forward's F.relu on top is then the identity
-        return m
-    for mod in list(m.modules()):
-        if isinstance(mod, (PreActBlock, CifarBottleneck)):
+    for mod in list(m.modules()):                # (the featurizer may sit inside a Sequential: proj_dim > 0)
+        if isinstance(mod, DenseNet):
+            f = mod.features
+            f.conv0, f.norm0 = _fold_pair(f.conv0, f.norm0), nn.Identity()
+            f.norm5 = ScaleShiftReLU(f.norm5)   # DenseNet.forward's F.relu on top is then the identity
+        elif isinstance(mod, _DenseLayer):
+            mod.conv1, mod.norm2 = _fold_pair(mod.conv1, mod.norm2), nn.Identity()
+            mod.norm1, mod.relu1 = ScaleShiftReLU(mod.norm1), nn.Identity()
+        elif isinstance(mod, _Transition):
+            mod.norm, mod.relu = ScaleShiftReLU(mod.norm), nn.Identity()
+        elif isinstance(mod, (PreActBlock, CifarBottleneck)):
             mod.conv1, mod.bn2 = _fold_pair(mod.conv1, mod.bn2), nn.Identity()
             mod.bn1 = ScaleShiftReLU(mod.bn1)
         elif isinstance(mod, (CifarTransition, CIFAR_DenseNet)):

@@ -78,6 +78,8 @@ def make_parser():
     p.add_argument("--n_way", type=int, default=None)
     p.add_argument("--freeze_featurizer", action="store_true")
     p.add_argument("--resume", action="store_true", help="continue from the newest checkpoint of this run")
+    p.add_argument("--no_fold_bn", action="store_true",
+                   help="evaluate with the training featurizer instead of its folded inference copy (model.fold_batchnorm)")
     # synthetic dataset shape
     p.add_argument("--synthetic_classes", type=int, default=10)
     p.add_argument("--synthetic_per_class", type=int, default=20)
@@ -119,6 +121,7 @@ class Trainer:
         self.network = NWNet(featurizer, self.num_classes, support_dataset=train_ds, feat_dim=feat_dim,
                              proj_dim=args.proj_dim, kernel_type=args.kernel_type, n_shot=args.n_shot,
                              n_way=args.n_way, device=str(self.device)).to(self.device)
+        self.network.enable_bn_folding(not args.no_fold_bn)   # precompute()/predict() in the eval epochs
         self.criterion = nn.NLLLoss()
         self.optimizer = torch.optim.SGD(self.network.parameters(), lr=args.lr,
                                          momentum=0.9, weight_decay=args.weight_decay, nesterov=True)
