@@ -37,6 +37,148 @@ __global__ __launch_bounds__(256) void nw_scale_shift_kernel(const float* __rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Training-mode BatchNorm2d (+ ReLU), forward and backward, one workgroup per channel.
+// torch runs the pair as batch-norm kernels (MIOpen: mean/variance, final, normalise; backward: three more)
+// plus a relu kernel each way: measured 9.2 ms of a 27 ms DenseNet-121 step (121 pairs).  Here the forward is
+// one kernel (shifted single-pass sums, then normalise + ReLU on the second read, which comes from L2 for all
+// but the stem) and the backward one kernel (sums of g and g*xhat, then dx); the ReLU mask is recomputed from
+// x with the forward's own arithmetic, so no activation is saved for it.
+// Layout: x element (i, c, p) at x[i*x_batch_stride + c*hw + p]; y, dy, dx are (n, C, hw) contiguous.
+template <bool VEC, typename F>
+__device__ __forceinline__ void for_channel(const float* __restrict__ base, int64_t n, int64_t hw, int64_t bstride,
+                                            int tid, int nthr, F&& f) {
+    // f(plane index i, offset inside the plane, value(s)) over the n planes of one channel
+    if (VEC) {
+        const int64_t q = hw / 4, total = n * q;
+        for (int64_t idx = tid; idx < total; idx += nthr) {
+            const int64_t i = idx / q, j = (idx - i * q) * 4;
+            f(i, j, *reinterpret_cast<const float4*>(base + i * bstride + j));
+        }
+    } else {
+        const int64_t total = n * hw;
+        for (int64_t idx = tid; idx < total; idx += nthr) {
+            const int64_t i = idx / hw, j = idx - i * hw;
+            const float v = base[i * bstride + j];
+            f(i, j, make_float4(v, 0.f, 0.f, 0.f));
+        }
+    }
+}
+
+template <bool RELU, bool VEC>
+__global__ __launch_bounds__(1024) void nw_bn_train_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ y,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, int64_t n, int64_t C, int64_t hw,
+    int64_t x_batch_stride, float momentum, float eps) {
+    __shared__ float red[16];
+    const int64_t c = blockIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const float* xc = x + c * hw;
+    // Two centred passes (mean, then sum of (x - mean)^2): a one-pass E[x^2] - E[x]^2 loses the variance of
+    // a channel whose spread is small next to its offset, and 1/sqrt(var + 1e-5) amplifies that.  The second
+    // and third reads of the channel come from L2 for everything but the stem.
+    const float K = xc[0];
+    float s1 = 0.f;
+    for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t, int64_t, const float4 v) {
+        s1 += v.x - K;
+        if (VEC) s1 += (v.y - K) + ((v.z - K) + (v.w - K));
+    });
+    s1 = block_sum(s1, red);
+    const float m = (float)(n * hw);
+    const float mean = K + s1 / m;
+    float s2 = 0.f;
+    for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t, int64_t, const float4 v) {
+        const float d0 = v.x - mean;
+        s2 = __builtin_fmaf(d0, d0, s2);
+        if (VEC) {
+            const float d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+            s2 = __builtin_fmaf(d1, d1, s2); s2 = __builtin_fmaf(d2, d2, s2); s2 = __builtin_fmaf(d3, d3, s2);
+        }
+    });
+    s2 = block_sum(s2, red);
+    const float var = s2 / m;  // biased (normalisation); the running one is unbiased
+    const float invstd = 1.f / sqrtf(var + eps);
+    if (tid == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (m > 1.f ? m / (m - 1.f) : 1.f);
+    }
+    const float a = gamma[c] * invstd, b = beta[c] - mean * a;
+    float* yc = y + c * hw;
+    for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t i, int64_t j, float4 v) {
+        v.x = __builtin_fmaf(v.x, a, b);
+        if (RELU) v.x = fmaxf(v.x, 0.f);
+        if (VEC) {
+            v.y = __builtin_fmaf(v.y, a, b); v.z = __builtin_fmaf(v.z, a, b); v.w = __builtin_fmaf(v.w, a, b);
+            if (RELU) { v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(yc + i * C * hw + j) = v;
+        } else {
+            yc[i * C * hw + j] = v.x;
+        }
+    });
+}
+
+template <bool RELU, bool VEC>
+__global__ __launch_bounds__(1024) void nw_bn_train_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t n, int64_t C, int64_t hw,
+    int64_t x_batch_stride) {
+    __shared__ float red[16];
+    const int64_t c = blockIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const float* xc = x + c * hw;
+    const float* dyc = dy + c * hw;
+    const float mean = save_mean[c], invstd = save_invstd[c], g = gamma[c];
+    const float a = g * invstd, b = beta[c] - mean * a;  // the forward's own y = fma(x, a, b): same ReLU mask
+    float s1 = 0.f, s2 = 0.f;
+    auto term = [&](float xv, float dv, float& gd, float& xh) {
+        xh = (xv - mean) * invstd;
+        gd = (!RELU || __builtin_fmaf(xv, a, b) > 0.f) ? dv : 0.f;
+    };
+    for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t i, int64_t j, const float4 v) {
+        float gd, xh;
+        if (VEC) {
+            const float4 d = *reinterpret_cast<const float4*>(dyc + i * C * hw + j);
+            term(v.x, d.x, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+            term(v.y, d.y, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+            term(v.z, d.z, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+            term(v.w, d.w, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+        } else {
+            term(v.x, dyc[i * C * hw + j], gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+        }
+    });
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (tid == 0) {
+        dbeta[c] = s1;
+        dgamma[c] = s2;
+    }
+    const float m = (float)(n * hw);
+    const float k1 = s1 / m, k2 = s2 / m;
+    float* dxc = dx + c * hw;
+    for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t i, int64_t j, const float4 v) {
+        float gd, xh;
+        if (VEC) {
+            const float4 d = *reinterpret_cast<const float4*>(dyc + i * C * hw + j);
+            float4 o;
+            term(v.x, d.x, gd, xh); o.x = a * (gd - k1 - xh * k2);
+            term(v.y, d.y, gd, xh); o.y = a * (gd - k1 - xh * k2);
+            term(v.z, d.z, gd, xh); o.z = a * (gd - k1 - xh * k2);
+            term(v.w, d.w, gd, xh); o.w = a * (gd - k1 - xh * k2);
+            *reinterpret_cast<float4*>(dxc + i * C * hw + j) = o;
+        } else {
+            term(v.x, dyc[i * C * hw + j], gd, xh);
+            dxc[i * C * hw + j] = a * (gd - k1 - xh * k2);
+        }
+    });
+}
+
+inline unsigned channel_threads(int64_t per_channel) { return per_channel >= 16384 ? 1024u : per_channel >= 2048 ? 512u : 256u; }
+
 }  // namespace
 }  // namespace nw
 
@@ -59,6 +201,50 @@ extern "C" int nw_scale_shift_relu_f32(const float* x, const float* scale, const
     if (relu) { if (vec) NW_SS(true, true); else NW_SS(true, false); }
     else { if (vec) NW_SS(false, true); else NW_SS(false, false); }
 #undef NW_SS
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                        float* running_var, float* y, float* save_mean, float* save_invstd,
+                                        int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride, float momentum,
+                                        float eps, int relu, void* stream) {
+    using namespace nw;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n <= 0 || c < 0 || hw <= 0 || x_batch_stride < c * hw || c > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    if (c == 0) return NW_OK;
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd) return NW_ERR_INVALID_ARG;
+    const bool vec = hw % 4 == 0 && x_batch_stride % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    const unsigned thr = channel_threads(n * hw);
+#define NW_BNF(R_, V_)                                                                                           \
+    hipLaunchKernelGGL((nw_bn_train_fwd_kernel<R_, V_>), dim3((unsigned)c), dim3(thr), 0, st, x, gamma, beta,     \
+                       running_mean, running_var, y, save_mean, save_invstd, n, c, hw, x_batch_stride, momentum, eps)
+    if (relu) { if (vec) NW_BNF(true, true); else NW_BNF(true, false); }
+    else { if (vec) NW_BNF(false, true); else NW_BNF(false, false); }
+#undef NW_BNF
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_bn_relu_train_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                        const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                                        float* dbeta, int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride,
+                                        int relu, void* stream) {
+    using namespace nw;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n <= 0 || c < 0 || hw <= 0 || x_batch_stride < c * hw || c > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    if (c == 0) return NW_OK;
+    if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return NW_ERR_INVALID_ARG;
+    const bool vec = hw % 4 == 0 && x_batch_stride % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    const unsigned thr = channel_threads(n * hw);
+#define NW_BNB(R_, V_)                                                                                          \
+    hipLaunchKernelGGL((nw_bn_train_bwd_kernel<R_, V_>), dim3((unsigned)c), dim3(thr), 0, st, x, dy, gamma, beta, \
+                       save_mean, save_invstd, dx, dgamma, dbeta, n, c, hw, x_batch_stride)
+    if (relu) { if (vec) NW_BNB(true, true); else NW_BNB(true, false); }
+    else { if (vec) NW_BNB(false, true); else NW_BNB(false, false); }
+#undef NW_BNB
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

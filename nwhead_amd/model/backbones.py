@@ -45,7 +45,7 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        y = self.bn2(self.conv2(_bn_relu(self.bn1, self.conv1(x))))
         return self.relu(y + (x if self.downsample is None else self.downsample(x)))
 
 
@@ -63,8 +63,8 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
+        y = _bn_relu(self.bn1, self.conv1(x))
+        y = _bn_relu(self.bn2, self.conv2(y))
         y = self.bn3(self.conv3(y))
         return self.relu(y + (x if self.downsample is None else self.downsample(x)))
 
@@ -105,15 +105,26 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(_bn_relu(self.bn1, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return torch.flatten(self.avgpool(x), 1)
 
 
 # ----------------------------------------------------------------------------- CIFAR pre-act ResNet
+FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
+
+
 def _bn_relu(bn, x):
-    """BatchNorm -> ReLU in front of a convolution; one pass in a folded inference copy (ScaleShiftReLU)."""
-    return bn(x) if isinstance(bn, ScaleShiftReLU) else F.relu(bn(x))
+    """BatchNorm -> ReLU.  One pass in a folded inference copy (ScaleShiftReLU); one HIP kernel each way in
+    training on the device (ops.bn_relu_train); otherwise the two torch ops of the reference."""
+    if isinstance(bn, ScaleShiftReLU):
+        return bn(x)
+    if (FUSED_BN_RELU_TRAINING and isinstance(bn, nn.BatchNorm2d) and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and bn.affine and torch.is_grad_enabled()
+            and (x.stride(3) == 1 and x.stride(2) == x.shape[3] and x.stride(1) == x.shape[2] * x.shape[3])):
+        from .. import ops
+        return ops.bn_relu_train(x, bn)
+    return F.relu(bn(x))
 
 
 class PreActBlock(nn.Module):
@@ -131,7 +142,7 @@ class PreActBlock(nn.Module):
 
     def forward(self, x):
         a = _bn_relu(self.bn1, x)
-        y = self.conv2(F.relu(self.bn2(self.conv1(a))))
+        y = self.conv2(_bn_relu(self.bn2, self.conv1(a)))
         return y + self.shortcut(a)
 
 
@@ -150,7 +161,7 @@ class CIFAR_ResNet(nn.Module):
             setattr(self, f"layer{idx}", nn.Sequential(*blocks))
 
     def forward(self, x, lin=0, lout=5):
-        x = F.relu(self.bn1(self.conv1(x)))
+        x = _bn_relu(self.bn1, self.conv1(x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return torch.flatten(F.avg_pool2d(x, 4), 1)
 
@@ -171,8 +182,8 @@ class _DenseLayer(nn.Sequential):
         # relu1 must not run in place on a slab/concat that later layers re-read
         if isinstance(self.norm1, ScaleShiftReLU):       # folded inference copy (fold_batchnorm)
             return self.conv2(self.relu2(self.conv1(self.norm1(x))))
-        y = self.conv1(F.relu(self.norm1(x)))
-        y = self.conv2(self.relu2(self.norm2(y)))
+        y = self.conv1(_bn_relu(self.norm1, x))
+        y = self.conv2(_bn_relu(self.norm2, y))
         return F.dropout(y, self.drop_rate, self.training) if self.drop_rate > 0 else y
 
 
@@ -204,6 +215,9 @@ class _Transition(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(OrderedDict([("norm", nn.BatchNorm2d(cin)), ("relu", nn.ReLU(inplace=True)),
                                       ("conv", _conv(cin, cout, 1)), ("pool", nn.AvgPool2d(2, 2))]))
+
+    def forward(self, x):
+        return self.pool(self.conv(_bn_relu(self.norm, x)))
 
 
 class DenseNet(nn.Module):
@@ -265,7 +279,7 @@ class CifarBottleneck(nn.Module):
         self.bn2, self.conv2 = nn.BatchNorm2d(4 * growth_rate), _conv(4 * growth_rate, growth_rate, 3, 1, 1)
 
     def forward(self, x):
-        y = self.conv2(F.relu(self.bn2(self.conv1(_bn_relu(self.bn1, x)))))
+        y = self.conv2(_bn_relu(self.bn2, self.conv1(_bn_relu(self.bn1, x))))
         return torch.cat([y, x], 1)
 
 

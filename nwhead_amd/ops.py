@@ -327,6 +327,68 @@ def scale_shift_relu(x, scale, shift, relu=True):
     return out
 
 
+def _plane_view(x):
+    """(n, c, h, w) fp32 with a contiguous (c, h, w) part (batch stride free) -> (tensor, batch stride)."""
+    n, c, h, w = x.shape
+    if x.dtype != torch.float32 or (x.numel() and (x.stride(3) != 1 or x.stride(2) != w or x.stride(1) != h * w)):
+        x = x.float().contiguous()
+    return x, (x.stride(0) if n > 1 else c * h * w)
+
+
+class _BNReLUTrainFn(torch.autograd.Function):
+    """relu(batch_norm(x)) in training mode: nw_bn_relu_train_fwd_f32 / _bwd_f32 (one kernel each)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu):
+        lib = _lib.load()
+        xv, bstride = _plane_view(x.detach())
+        n, c, h, w = xv.shape
+        y = torch.empty(n, c, h, w, dtype=torch.float32, device=xv.device)
+        mean = torch.empty(c, dtype=torch.float32, device=xv.device)
+        invstd = torch.empty_like(mean)
+        track = bn.track_running_stats and bn.running_mean is not None
+        momentum = 0.0
+        if track:
+            bn.num_batches_tracked += 1
+            # momentum None = cumulative moving average (torch.nn.BatchNorm2d)
+            momentum = float(bn.momentum) if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        wc, bc = _f32c(weight), _f32c(bias)
+        with torch.cuda.device(xv.device):
+            _lib.check(lib.nw_bn_relu_train_fwd_f32(_ptr(xv), _ptr(wc), _ptr(bc),
+                                                    _ptr(bn.running_mean) if track else None,
+                                                    _ptr(bn.running_var) if track else None, _ptr(y), _ptr(mean),
+                                                    _ptr(invstd), n, c, h * w, bstride, momentum, float(bn.eps),
+                                                    int(relu), _stream(xv)), "nw_bn_relu_train_fwd_f32")
+        ctx.save_for_backward(xv, wc, bc, mean, invstd)
+        ctx.relu, ctx.bstride = relu, bstride
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xv, wc, bc, mean, invstd = ctx.saved_tensors
+        n, c, h, w = xv.shape
+        gy = _f32c(gy)
+        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=xv.device)
+        dg, db = torch.empty_like(mean), torch.empty_like(mean)
+        with torch.cuda.device(xv.device):
+            _lib.check(lib.nw_bn_relu_train_bwd_f32(_ptr(xv), _ptr(gy), _ptr(wc), _ptr(bc), _ptr(mean), _ptr(invstd),
+                                                    _ptr(dx), _ptr(dg), _ptr(db), n, c, h * w, ctx.bstride,
+                                                    int(ctx.relu), _stream(xv)), "nw_bn_relu_train_bwd_f32")
+        return dx, dg, db, None, None
+
+
+def bn_relu_train(x, bn, relu=True):
+    """relu(bn(x)) for a BatchNorm2d in training mode (batch statistics, running statistics updated), fp32 NCHW
+    on the MI355X."""
+    _need_hip(x, bn.weight, bn.bias)
+    if not (bn.affine and bn.weight is not None):
+        raise ValueError("bn_relu_train needs an affine BatchNorm2d")
+    if bn.running_mean is not None and (bn.running_mean.dtype != torch.float32 or not bn.running_mean.is_contiguous()):
+        raise ValueError("running statistics must be contiguous fp32")
+    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, bool(relu))
+
+
 def support_influence_idx(probs, qy, w, sy):
     """Index-label form of util/metric.py:23-50: probs (B,C), qy (B,), w (B,N), sy (N,) -> (B,N)."""
     _need_hip(probs, qy, w, sy)

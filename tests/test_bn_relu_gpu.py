@@ -1,0 +1,80 @@
+"""Training-mode BatchNorm2d + ReLU through the HIP kernels (nw_bn_relu_train_fwd_f32 / _bwd_f32): one layer
+against torch's batch_norm + relu and their autograd evaluated in fp64 on the host, and whole backbones with
+the fused path on vs off, each against the fp32 CPU run of the same network."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,prefix", [((6, 12, 8, 8), 12), ((5, 20, 7, 7), 20), ((3, 9, 5, 3), 9),
+                                          ((42, 64, 56, 56), 64), ((4, 40, 14, 14), 24), ((2, 8, 1, 1), 8),
+                                          ((8, 600, 4, 4), 600)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_relu_train_matches_torch(shape, prefix, relu):
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + prefix)
+    slab = torch.randn(*shape, generator=g) * 1.7 + torch.randn(1, shape[1], 1, 1, generator=g) * 30   # offsets >> spread
+    bn_a, bn_b = nn.BatchNorm2d(prefix).cuda().train(), nn.BatchNorm2d(prefix).double().train()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.randn(prefix, generator=g)); bn_a.bias.copy_(torch.randn(prefix, generator=g))
+        bn_a.running_mean.normal_(); bn_a.running_var.uniform_(0.5, 2.0)
+        bn_b.load_state_dict({k: v.cpu().double() if v.is_floating_point() else v.cpu() for k, v in bn_a.state_dict().items()})
+    xa = slab.cuda()[:, :prefix].detach().requires_grad_(True)     # a channel prefix of a wider slab when prefix < C
+    xb = slab[:, :prefix].double().clone().requires_grad_(True)
+    ya = ops.bn_relu_train(xa, bn_a, relu)
+    pre = bn_b(xb)
+    yb = F.relu(pre) if relu else pre
+    torch.testing.assert_close(ya.cpu().double(), yb, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(bn_a.running_mean.cpu().double(), bn_b.running_mean, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bn_a.running_var.cpu().double(), bn_b.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+    # an activation within rounding of zero may land on either side of the ReLU: it gets no upstream gradient here
+    w = torch.randn(*ya.shape, generator=g).double()
+    if relu:
+        w = w * (pre.detach().abs() > 1e-4)
+    (ya * w.float().cuda()).sum().backward()
+    (yb * w).sum().backward()
+    scale = max(float(xb.grad.abs().max()), 1e-3)
+    if shape[0] * shape[2] * shape[3] > 2:      # with two values per channel dx is what is left of a total cancellation
+        torch.testing.assert_close(xa.grad.cpu().double() / scale, xb.grad / scale, rtol=1e-4, atol=3e-5)
+    for got, ref in ((bn_a.weight.grad, bn_b.weight.grad), (bn_a.bias.grad, bn_b.bias.grad)):
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("arch,size", [("resnet18", 64), ("densenet121", 64), ("CIFAR_ResNet18", 32), ("CIFAR_DenseNet121", 32)])
+def test_backbone_train_step_fused_vs_torch(arch, size):
+    """One training forward + backward of a backbone on the device with the fused BatchNorm+ReLU path on and
+    off, each compared with the fp32 CPU run of the same network (what fixture G6 pins to the reference): the
+    fused path must be as close to it as torch's own device path is."""
+    from nwhead_amd.model import backbones, load_model
+    from tests.procedural import fill_procedural
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(6, 3, size, size, generator=g)
+
+    def run(dev, fused):
+        backbones.FUSED_BN_RELU_TRAINING = fused
+        try:
+            net = load_model(arch)
+            fill_procedural(net)
+            net = net.to(dev).train()
+            f = net(x.to(dev))
+            f.square().mean().backward()
+            return (f.detach().cpu(), {k: v.detach().cpu() for k, v in net.state_dict().items() if "running" in k},
+                    {k: p.grad.detach().cpu() for k, p in net.named_parameters()})
+        finally:
+            backbones.FUSED_BN_RELU_TRAINING = True
+
+    ref, fused, plain = run("cpu", False), run("cuda:0", True), run("cuda:0", False)
+
+    def err(a, b):
+        worst = float((a[0] - b[0]).abs().max()) / max(float(b[0].abs().max()), 1e-12)
+        for part in (1, 2):
+            for k in b[part]:
+                worst = max(worst, float((a[part][k] - b[part][k]).abs().max()) / max(float(b[part][k].abs().max()), 1e-6))
+        return worst
+    e_fused, e_plain = err(fused, ref), err(plain, ref)
+    assert e_fused <= max(3 * e_plain, 2e-3), (e_fused, e_plain)
