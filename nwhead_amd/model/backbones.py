@@ -197,10 +197,14 @@ class _DenseBlock(nn.Module):
     def forward(self, x):
         layers = list(self.children())
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            feats = [x]
+            # The running concatenation is extended by one layer at a time (same values and copy volume as
+            # concatenating the list of features at every layer, densenet.py:62-80): its backward is then ONE
+            # gradient accumulation per layer instead of one per (feature, later layer) pair -- 58 instead of
+            # 540 small strided adds in a DenseNet-121 step.
+            cur = x
             for layer in layers:
-                feats.append(layer(torch.cat(feats, 1)))
-            return torch.cat(feats, 1)
+                cur = torch.cat((cur, layer(cur)), 1)
+            return cur
         # inference: one slab, each layer appends its channels (no per-layer re-concatenation)
         n, c, h, w = x.shape
         slab = x.new_empty(n, c + len(layers) * self.growth_rate, h, w)
