@@ -198,16 +198,17 @@ int nw_scale_shift_relu_f32(const float *x, const float *scale, const float *shi
  * nw_scale_shift_relu_f32 plus the conv -> bn -> relu pairs of model/resnet.py:31-66; the backward is what
  * autograd derives for relu(batch_norm(x)) at train.py:414.
  *   forward : batch statistics per channel over (n, hw); y = max(gamma (x - mean) / sqrt(var + eps) + beta, 0);
- *             running_mean/var (nullable) updated in place with `momentum` (unbiased variance), save_mean /
- *             save_invstd (c,) written for the backward
+ *             running_mean/var (nullable) updated in place with `momentum` (unbiased variance), the int64
+ *             num_batches_tracked counter (nullable) incremented, save_mean / save_invstd (c,) written for the
+ *             backward
  *   backward: dx (n, c, hw), dgamma (c,), dbeta (c,) from dy (n, c, hw) contiguous; the ReLU mask is recomputed
  *             from x, nothing else is saved
  *   x element (i, ch, p) at x[i * x_batch_stride + ch * hw + p]; y, dy, dx contiguous
  * ------------------------------------------------------------------------------------------- */
 int nw_bn_relu_train_fwd_f32(const float *x, const float *gamma, const float *beta, float *running_mean,
                              float *running_var, float *y, float *save_mean, float *save_invstd,
-                             int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride, float momentum,
-                             float eps, int relu, void *stream);
+                             int64_t *num_batches_tracked, int64_t n, int64_t c, int64_t hw,
+                             int64_t x_batch_stride, float momentum, float eps, int relu, void *stream);
 int nw_bn_relu_train_bwd_f32(const float *x, const float *dy, const float *gamma, const float *beta,
                              const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
                              float *dbeta, int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride,

@@ -70,11 +70,12 @@ template <bool RELU, bool VEC>
 __global__ __launch_bounds__(1024) void nw_bn_train_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ y,
-    float* __restrict__ save_mean, float* __restrict__ save_invstd, int64_t n, int64_t C, int64_t hw,
-    int64_t x_batch_stride, float momentum, float eps) {
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, int64_t* __restrict__ num_batches_tracked,
+    int64_t n, int64_t C, int64_t hw, int64_t x_batch_stride, float momentum, float eps) {
     __shared__ float red[16];
     const int64_t c = blockIdx.x;
     const int tid = threadIdx.x, nthr = blockDim.x;
+    if (num_batches_tracked && c == 0 && tid == 0) *num_batches_tracked += 1;  // BatchNorm2d's step counter, no launch of its own
     const float* xc = x + c * hw;
     // Two centred passes (mean, then sum of (x - mean)^2): a one-pass E[x^2] - E[x]^2 loses the variance of
     // a channel whose spread is small next to its offset, and 1/sqrt(var + 1e-5) amplifies that.  The second
@@ -207,8 +208,8 @@ extern "C" int nw_scale_shift_relu_f32(const float* x, const float* scale, const
 
 extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                         float* running_var, float* y, float* save_mean, float* save_invstd,
-                                        int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride, float momentum,
-                                        float eps, int relu, void* stream) {
+                                        int64_t* num_batches_tracked, int64_t n, int64_t c, int64_t hw,
+                                        int64_t x_batch_stride, float momentum, float eps, int relu, void* stream) {
     using namespace nw;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n <= 0 || c < 0 || hw <= 0 || x_batch_stride < c * hw || c > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
@@ -219,7 +220,8 @@ extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* gamma, cons
     const unsigned thr = channel_threads(n * hw);
 #define NW_BNF(R_, V_)                                                                                           \
     hipLaunchKernelGGL((nw_bn_train_fwd_kernel<R_, V_>), dim3((unsigned)c), dim3(thr), 0, st, x, gamma, beta,     \
-                       running_mean, running_var, y, save_mean, save_invstd, n, c, hw, x_batch_stride, momentum, eps)
+                       running_mean, running_var, y, save_mean, save_invstd, num_batches_tracked, n, c, hw,             \
+                       x_batch_stride, momentum, eps)
     if (relu) { if (vec) NW_BNF(true, true); else NW_BNF(true, false); }
     else { if (vec) NW_BNF(false, true); else NW_BNF(false, false); }
 #undef NW_BNF

@@ -347,17 +347,19 @@ class _BNReLUTrainFn(torch.autograd.Function):
         mean = torch.empty(c, dtype=torch.float32, device=xv.device)
         invstd = torch.empty_like(mean)
         track = bn.track_running_stats and bn.running_mean is not None
-        momentum = 0.0
+        momentum, nbt = 0.0, None
         if track:
-            bn.num_batches_tracked += 1
-            # momentum None = cumulative moving average (torch.nn.BatchNorm2d)
-            momentum = float(bn.momentum) if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            if bn.momentum is None:                 # cumulative moving average: the factor needs the count on the host
+                bn.num_batches_tracked += 1
+                momentum = 1.0 / float(bn.num_batches_tracked)
+            else:
+                momentum, nbt = float(bn.momentum), bn.num_batches_tracked   # counted inside the kernel
         wc, bc = _f32c(weight), _f32c(bias)
         with torch.cuda.device(xv.device):
             _lib.check(lib.nw_bn_relu_train_fwd_f32(_ptr(xv), _ptr(wc), _ptr(bc),
                                                     _ptr(bn.running_mean) if track else None,
                                                     _ptr(bn.running_var) if track else None, _ptr(y), _ptr(mean),
-                                                    _ptr(invstd), n, c, h * w, bstride, momentum, float(bn.eps),
+                                                    _ptr(invstd), _ptr(nbt), n, c, h * w, bstride, momentum, float(bn.eps),
                                                     int(relu), _stream(xv)), "nw_bn_relu_train_fwd_f32")
         ctx.save_for_backward(xv, wc, bc, mean, invstd)
         ctx.relu, ctx.bstride = relu, bstride
