@@ -203,16 +203,18 @@ int nw_scale_shift_relu_f32(const float *x, const float *scale, const float *shi
  *             backward
  *   backward: dx (n, c, hw), dgamma (c,), dbeta (c,) from dy (n, c, hw) contiguous; the ReLU mask is recomputed
  *             from x, nothing else is saved
+ *   residual (nullable, (n, c, hw) contiguous): y = max(bn(x) + residual, 0), the tail of a ResNet block
+ *             (model/resnet.py:58-66, :100-108); the backward then also writes dresidual (the masked dy)
  *   x element (i, ch, p) at x[i * x_batch_stride + ch * hw + p]; y, dy, dx contiguous
  * ------------------------------------------------------------------------------------------- */
-int nw_bn_relu_train_fwd_f32(const float *x, const float *gamma, const float *beta, float *running_mean,
+int nw_bn_relu_train_fwd_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
                              float *running_var, float *y, float *save_mean, float *save_invstd,
                              int64_t *num_batches_tracked, int64_t n, int64_t c, int64_t hw,
                              int64_t x_batch_stride, float momentum, float eps, int relu, void *stream);
-int nw_bn_relu_train_bwd_f32(const float *x, const float *dy, const float *gamma, const float *beta,
-                             const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
-                             float *dbeta, int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride,
-                             int relu, void *stream);
+int nw_bn_relu_train_bwd_f32(const float *x, const float *residual, const float *dy, const float *gamma,
+                             const float *beta, const float *save_mean, const float *save_invstd, float *dx,
+                             float *dresidual, float *dgamma, float *dbeta, int64_t n, int64_t c, int64_t hw,
+                             int64_t x_batch_stride, int relu, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): device time of the TILE kernel alone -- the kernel the

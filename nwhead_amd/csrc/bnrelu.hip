@@ -66,9 +66,11 @@ __device__ __forceinline__ void for_channel(const float* __restrict__ base, int6
     }
 }
 
-template <bool RELU, bool VEC>
+// RES: y = relu(bn(x) + residual) -- the tail of a ResNet block (model/resnet.py:58-66, :100-108); residual and its
+// gradient are (n, C, hw) contiguous like y.
+template <bool RELU, bool VEC, bool RES>
 __global__ __launch_bounds__(1024) void nw_bn_train_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ x, const float* __restrict__ residual, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ y,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, int64_t* __restrict__ num_batches_tracked,
     int64_t n, int64_t C, int64_t hw, int64_t x_batch_stride, float momentum, float eps) {
@@ -109,47 +111,59 @@ __global__ __launch_bounds__(1024) void nw_bn_train_fwd_kernel(
     }
     const float a = gamma[c] * invstd, b = beta[c] - mean * a;
     float* yc = y + c * hw;
+    const float* rc = RES ? residual + c * hw : nullptr;
     for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t i, int64_t j, float4 v) {
         v.x = __builtin_fmaf(v.x, a, b);
-        if (RELU) v.x = fmaxf(v.x, 0.f);
         if (VEC) {
             v.y = __builtin_fmaf(v.y, a, b); v.z = __builtin_fmaf(v.z, a, b); v.w = __builtin_fmaf(v.w, a, b);
-            if (RELU) { v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (RES) {
+                const float4 r = *reinterpret_cast<const float4*>(rc + i * C * hw + j);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(yc + i * C * hw + j) = v;
         } else {
+            if (RES) v.x += rc[i * C * hw + j];
+            if (RELU) v.x = fmaxf(v.x, 0.f);
             yc[i * C * hw + j] = v.x;
         }
     });
 }
 
-template <bool RELU, bool VEC>
+template <bool RELU, bool VEC, bool RES>
 __global__ __launch_bounds__(1024) void nw_bn_train_bwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t n, int64_t C, int64_t hw,
-    int64_t x_batch_stride) {
+    const float* __restrict__ x, const float* __restrict__ residual, const float* __restrict__ dy,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, float* __restrict__ dx, float* __restrict__ dresidual,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t n, int64_t C, int64_t hw, int64_t x_batch_stride) {
     __shared__ float red[16];
     const int64_t c = blockIdx.x;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const float* xc = x + c * hw;
     const float* dyc = dy + c * hw;
+    const float* rc = RES ? residual + c * hw : nullptr;
+    float* drc = RES ? dresidual + c * hw : nullptr;
     const float mean = save_mean[c], invstd = save_invstd[c], g = gamma[c];
     const float a = g * invstd, b = beta[c] - mean * a;  // the forward's own y = fma(x, a, b): same ReLU mask
     float s1 = 0.f, s2 = 0.f;
-    auto term = [&](float xv, float dv, float& gd, float& xh) {
+    auto term = [&](float xv, float rv, float dv, float& gd, float& xh) {
         xh = (xv - mean) * invstd;
-        gd = (!RELU || __builtin_fmaf(xv, a, b) > 0.f) ? dv : 0.f;
+        float pre = __builtin_fmaf(xv, a, b);
+        if (RES) pre += rv;
+        gd = (!RELU || pre > 0.f) ? dv : 0.f;
     };
     for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t i, int64_t j, const float4 v) {
         float gd, xh;
         if (VEC) {
             const float4 d = *reinterpret_cast<const float4*>(dyc + i * C * hw + j);
-            term(v.x, d.x, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
-            term(v.y, d.y, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
-            term(v.z, d.z, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
-            term(v.w, d.w, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (RES) r = *reinterpret_cast<const float4*>(rc + i * C * hw + j);
+            term(v.x, r.x, d.x, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+            term(v.y, r.y, d.y, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+            term(v.z, r.z, d.z, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+            term(v.w, r.w, d.w, gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
         } else {
-            term(v.x, dyc[i * C * hw + j], gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
+            term(v.x, RES ? rc[i * C * hw + j] : 0.f, dyc[i * C * hw + j], gd, xh); s1 += gd; s2 = __builtin_fmaf(gd, xh, s2);
         }
     });
     s1 = block_sum(s1, red);
@@ -165,15 +179,18 @@ __global__ __launch_bounds__(1024) void nw_bn_train_bwd_kernel(
         float gd, xh;
         if (VEC) {
             const float4 d = *reinterpret_cast<const float4*>(dyc + i * C * hw + j);
-            float4 o;
-            term(v.x, d.x, gd, xh); o.x = a * (gd - k1 - xh * k2);
-            term(v.y, d.y, gd, xh); o.y = a * (gd - k1 - xh * k2);
-            term(v.z, d.z, gd, xh); o.z = a * (gd - k1 - xh * k2);
-            term(v.w, d.w, gd, xh); o.w = a * (gd - k1 - xh * k2);
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f), o, go;
+            if (RES) r = *reinterpret_cast<const float4*>(rc + i * C * hw + j);
+            term(v.x, r.x, d.x, gd, xh); o.x = a * (gd - k1 - xh * k2); go.x = gd;
+            term(v.y, r.y, d.y, gd, xh); o.y = a * (gd - k1 - xh * k2); go.y = gd;
+            term(v.z, r.z, d.z, gd, xh); o.z = a * (gd - k1 - xh * k2); go.z = gd;
+            term(v.w, r.w, d.w, gd, xh); o.w = a * (gd - k1 - xh * k2); go.w = gd;
             *reinterpret_cast<float4*>(dxc + i * C * hw + j) = o;
+            if (RES) *reinterpret_cast<float4*>(drc + i * C * hw + j) = go;
         } else {
-            term(v.x, dyc[i * C * hw + j], gd, xh);
+            term(v.x, RES ? rc[i * C * hw + j] : 0.f, dyc[i * C * hw + j], gd, xh);
             dxc[i * C * hw + j] = a * (gd - k1 - xh * k2);
+            if (RES) drc[i * C * hw + j] = gd;
         }
     });
 }
@@ -206,7 +223,7 @@ extern "C" int nw_scale_shift_relu_f32(const float* x, const float* scale, const
     return NW_OK;
 }
 
-extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* running_mean,
                                         float* running_var, float* y, float* save_mean, float* save_invstd,
                                         int64_t* num_batches_tracked, int64_t n, int64_t c, int64_t hw,
                                         int64_t x_batch_stride, float momentum, float eps, int relu, void* stream) {
@@ -216,10 +233,21 @@ extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* gamma, cons
     if (c == 0) return NW_OK;
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd) return NW_ERR_INVALID_ARG;
     const bool vec = hw % 4 == 0 && x_batch_stride % 4 == 0 &&
-                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
     const unsigned thr = channel_threads(n * hw);
+    if (residual && !relu) return NW_ERR_UNSUPPORTED;  // only the relu(bn(x) + r) tail exists in the backbones
+    if (residual) {
+        if (vec)
+            hipLaunchKernelGGL((nw_bn_train_fwd_kernel<true, true, true>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, gamma, beta,
+                               running_mean, running_var, y, save_mean, save_invstd, num_batches_tracked, n, c, hw, x_batch_stride, momentum, eps);
+        else
+            hipLaunchKernelGGL((nw_bn_train_fwd_kernel<true, false, true>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, gamma, beta,
+                               running_mean, running_var, y, save_mean, save_invstd, num_batches_tracked, n, c, hw, x_batch_stride, momentum, eps);
+        NW_CHECK_LAUNCH();
+        return NW_OK;
+    }
 #define NW_BNF(R_, V_)                                                                                           \
-    hipLaunchKernelGGL((nw_bn_train_fwd_kernel<R_, V_>), dim3((unsigned)c), dim3(thr), 0, st, x, gamma, beta,     \
+    hipLaunchKernelGGL((nw_bn_train_fwd_kernel<R_, V_, false>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, gamma, beta, \
                        running_mean, running_var, y, save_mean, save_invstd, num_batches_tracked, n, c, hw,             \
                        x_batch_stride, momentum, eps)
     if (relu) { if (vec) NW_BNF(true, true); else NW_BNF(true, false); }
@@ -229,21 +257,33 @@ extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* gamma, cons
     return NW_OK;
 }
 
-extern "C" int nw_bn_relu_train_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta,
-                                        const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
-                                        float* dbeta, int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride,
-                                        int relu, void* stream) {
+extern "C" int nw_bn_relu_train_bwd_f32(const float* x, const float* residual, const float* dy, const float* gamma,
+                                        const float* beta, const float* save_mean, const float* save_invstd, float* dx,
+                                        float* dresidual, float* dgamma, float* dbeta, int64_t n, int64_t c, int64_t hw,
+                                        int64_t x_batch_stride, int relu, void* stream) {
     using namespace nw;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n <= 0 || c < 0 || hw <= 0 || x_batch_stride < c * hw || c > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
     if (c == 0) return NW_OK;
     if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return NW_ERR_INVALID_ARG;
     const bool vec = hw % 4 == 0 && x_batch_stride % 4 == 0 &&
-                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                       reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(dresidual)) & 15) == 0;
     const unsigned thr = channel_threads(n * hw);
+    if ((residual != nullptr) != (dresidual != nullptr) || (residual && !relu)) return NW_ERR_INVALID_ARG;
+    if (residual) {
+        if (vec)
+            hipLaunchKernelGGL((nw_bn_train_bwd_kernel<true, true, true>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, dy, gamma,
+                               beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, n, c, hw, x_batch_stride);
+        else
+            hipLaunchKernelGGL((nw_bn_train_bwd_kernel<true, false, true>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, dy, gamma,
+                               beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, n, c, hw, x_batch_stride);
+        NW_CHECK_LAUNCH();
+        return NW_OK;
+    }
 #define NW_BNB(R_, V_)                                                                                          \
-    hipLaunchKernelGGL((nw_bn_train_bwd_kernel<R_, V_>), dim3((unsigned)c), dim3(thr), 0, st, x, dy, gamma, beta, \
-                       save_mean, save_invstd, dx, dgamma, dbeta, n, c, hw, x_batch_stride)
+    hipLaunchKernelGGL((nw_bn_train_bwd_kernel<R_, V_, false>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, dy, gamma, beta, \
+                       save_mean, save_invstd, dx, dresidual, dgamma, dbeta, n, c, hw, x_batch_stride)
     if (relu) { if (vec) NW_BNB(true, true); else NW_BNB(true, false); }
     else { if (vec) NW_BNB(false, true); else NW_BNB(false, false); }
 #undef NW_BNB

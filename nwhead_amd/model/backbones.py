@@ -45,8 +45,8 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = self.bn2(self.conv2(_bn_relu(self.bn1, self.conv1(x))))
-        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+        y = self.conv2(_bn_relu(self.bn1, self.conv1(x)))
+        return _bn_relu(self.bn2, y, x if self.downsample is None else self.downsample(x))
 
 
 class Bottleneck(nn.Module):
@@ -65,8 +65,7 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         y = _bn_relu(self.bn1, self.conv1(x))
         y = _bn_relu(self.bn2, self.conv2(y))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+        return _bn_relu(self.bn3, self.conv3(y), x if self.downsample is None else self.downsample(x))
 
 
 class ResNet(nn.Module):
@@ -114,17 +113,18 @@ class ResNet(nn.Module):
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
 
 
-def _bn_relu(bn, x):
-    """BatchNorm -> ReLU.  One pass in a folded inference copy (ScaleShiftReLU); one HIP kernel each way in
-    training on the device (ops.bn_relu_train); otherwise the two torch ops of the reference."""
+def _bn_relu(bn, x, residual=None):
+    """relu(bn(x)), or relu(bn(x) + residual) at the end of a ResNet block.  One pass in a folded inference copy
+    (ScaleShiftReLU); one HIP kernel each way in training on the device (ops.bn_relu_train); otherwise the torch
+    ops of the reference."""
     if isinstance(bn, ScaleShiftReLU):
         return bn(x)
     if (FUSED_BN_RELU_TRAINING and isinstance(bn, nn.BatchNorm2d) and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and bn.affine and torch.is_grad_enabled()
             and (x.stride(3) == 1 and x.stride(2) == x.shape[3] and x.stride(1) == x.shape[2] * x.shape[3])):
         from .. import ops
-        return ops.bn_relu_train(x, bn)
-    return F.relu(bn(x))
+        return ops.bn_relu_train(x, bn, True, residual)
+    return F.relu(bn(x) if residual is None else bn(x) + residual)
 
 
 class PreActBlock(nn.Module):

@@ -336,13 +336,19 @@ def _plane_view(x):
 
 
 class _BNReLUTrainFn(torch.autograd.Function):
-    """relu(batch_norm(x)) in training mode: nw_bn_relu_train_fwd_f32 / _bwd_f32 (one kernel each)."""
+    """relu(batch_norm(x) [+ residual]) in training mode: nw_bn_relu_train_fwd_f32 / _bwd_f32 (one kernel each)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bn, relu):
+    def forward(ctx, x, weight, bias, residual, bn, relu):
         lib = _lib.load()
         xv, bstride = _plane_view(x.detach())
         n, c, h, w = xv.shape
+        rv = None
+        if residual is not None:
+            rv = residual.detach()
+            if rv.shape != xv.shape:
+                raise ValueError("residual must have the shape of x")
+            rv = rv if (rv.dtype == torch.float32 and rv.is_contiguous()) else rv.float().contiguous()
         y = torch.empty(n, c, h, w, dtype=torch.float32, device=xv.device)
         mean = torch.empty(c, dtype=torch.float32, device=xv.device)
         invstd = torch.empty_like(mean)
@@ -356,39 +362,41 @@ class _BNReLUTrainFn(torch.autograd.Function):
                 momentum, nbt = float(bn.momentum), bn.num_batches_tracked   # counted inside the kernel
         wc, bc = _f32c(weight), _f32c(bias)
         with torch.cuda.device(xv.device):
-            _lib.check(lib.nw_bn_relu_train_fwd_f32(_ptr(xv), _ptr(wc), _ptr(bc),
+            _lib.check(lib.nw_bn_relu_train_fwd_f32(_ptr(xv), _ptr(rv), _ptr(wc), _ptr(bc),
                                                     _ptr(bn.running_mean) if track else None,
                                                     _ptr(bn.running_var) if track else None, _ptr(y), _ptr(mean),
                                                     _ptr(invstd), _ptr(nbt), n, c, h * w, bstride, momentum, float(bn.eps),
                                                     int(relu), _stream(xv)), "nw_bn_relu_train_fwd_f32")
-        ctx.save_for_backward(xv, wc, bc, mean, invstd)
+        ctx.save_for_backward(xv, wc, bc, mean, invstd, *(() if rv is None else (rv,)))
         ctx.relu, ctx.bstride = relu, bstride
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.load()
-        xv, wc, bc, mean, invstd = ctx.saved_tensors
+        xv, wc, bc, mean, invstd, *rest = ctx.saved_tensors
+        rv = rest[0] if rest else None
         n, c, h, w = xv.shape
         gy = _f32c(gy)
         dx = torch.empty(n, c, h, w, dtype=torch.float32, device=xv.device)
+        dr = torch.empty_like(dx) if rv is not None else None
         dg, db = torch.empty_like(mean), torch.empty_like(mean)
         with torch.cuda.device(xv.device):
-            _lib.check(lib.nw_bn_relu_train_bwd_f32(_ptr(xv), _ptr(gy), _ptr(wc), _ptr(bc), _ptr(mean), _ptr(invstd),
-                                                    _ptr(dx), _ptr(dg), _ptr(db), n, c, h * w, ctx.bstride,
-                                                    int(ctx.relu), _stream(xv)), "nw_bn_relu_train_bwd_f32")
-        return dx, dg, db, None, None
+            _lib.check(lib.nw_bn_relu_train_bwd_f32(_ptr(xv), _ptr(rv), _ptr(gy), _ptr(wc), _ptr(bc), _ptr(mean),
+                                                    _ptr(invstd), _ptr(dx), _ptr(dr), _ptr(dg), _ptr(db), n, c, h * w,
+                                                    ctx.bstride, int(ctx.relu), _stream(xv)), "nw_bn_relu_train_bwd_f32")
+        return dx, dg, db, dr, None, None
 
 
-def bn_relu_train(x, bn, relu=True):
-    """relu(bn(x)) for a BatchNorm2d in training mode (batch statistics, running statistics updated), fp32 NCHW
-    on the MI355X."""
-    _need_hip(x, bn.weight, bn.bias)
+def bn_relu_train(x, bn, relu=True, residual=None):
+    """relu(bn(x)) -- or relu(bn(x) + residual), the tail of a ResNet block -- for a BatchNorm2d in training mode
+    (batch statistics, running statistics updated), fp32 NCHW on the MI355X."""
+    _need_hip(x, bn.weight, bn.bias, residual)
     if not (bn.affine and bn.weight is not None):
         raise ValueError("bn_relu_train needs an affine BatchNorm2d")
     if bn.running_mean is not None and (bn.running_mean.dtype != torch.float32 or not bn.running_mean.is_contiguous()):
         raise ValueError("running statistics must be contiguous fp32")
-    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, bool(relu))
+    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, residual, bn, bool(relu))
 
 
 def support_influence_idx(probs, qy, w, sy):

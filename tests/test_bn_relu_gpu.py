@@ -45,6 +45,32 @@ def test_bn_relu_train_matches_torch(shape, prefix, relu):
         torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(6, 12, 8, 8), (5, 20, 7, 7), (16, 128, 28, 28)])
+def test_bn_add_relu_train_matches_torch(shape):
+    """relu(bn(x) + residual), the tail of a ResNet block: outputs and all four gradients against fp64 torch."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x0, r0 = torch.randn(*shape, generator=g) * 2 + 5, torch.randn(*shape, generator=g)
+    C = shape[1]
+    bn_a, bn_b = nn.BatchNorm2d(C).cuda().train(), nn.BatchNorm2d(C).double().train()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.randn(C, generator=g)); bn_a.bias.copy_(torch.randn(C, generator=g))
+        bn_b.load_state_dict({k: v.cpu().double() if v.is_floating_point() else v.cpu() for k, v in bn_a.state_dict().items()})
+    xa, ra = x0.cuda().requires_grad_(True), r0.cuda().requires_grad_(True)
+    xb, rb = x0.double().requires_grad_(True), r0.double().requires_grad_(True)
+    ya = ops.bn_relu_train(xa, bn_a, True, ra)
+    pre = bn_b(xb) + rb
+    yb = F.relu(pre)
+    torch.testing.assert_close(ya.cpu().double(), yb, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(bn_a.running_var.cpu().double(), bn_b.running_var, rtol=1e-5, atol=1e-6)
+    w = torch.randn(*shape, generator=g).double() * (pre.detach().abs() > 1e-4)
+    (ya * w.float().cuda()).sum().backward()
+    (yb * w).sum().backward()
+    for got, ref in ((xa.grad, xb.grad), (ra.grad, rb.grad), (bn_a.weight.grad, bn_b.weight.grad), (bn_a.bias.grad, bn_b.bias.grad)):
+        scale = max(float(ref.abs().max()), 1e-3)
+        torch.testing.assert_close(got.cpu().double() / scale, ref / scale, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("arch,size,batch", [("resnet18", 96, 8), ("resnet50", 96, 8), ("densenet121", 96, 8),
                                              ("CIFAR_ResNet18", 32, 16), ("CIFAR_DenseNet121", 32, 16)])
 def test_backbone_train_step_fused_vs_torch(arch, size, batch):
