@@ -49,19 +49,17 @@ __global__ __launch_bounds__(256) void nw_scale_shift_kernel(const float* __rest
 template <bool VEC, typename F>
 __device__ __forceinline__ void for_channel(const float* __restrict__ base, int64_t n, int64_t hw, int64_t bstride,
                                             int tid, int nthr, F&& f) {
-    // f(plane index i, offset inside the plane, value(s)) over the n planes of one channel
-    if (VEC) {
-        const int64_t q = hw / 4, total = n * q;
-        for (int64_t idx = tid; idx < total; idx += nthr) {
-            const int64_t i = idx / q, j = (idx - i * q) * 4;
-            f(i, j, *reinterpret_cast<const float4*>(base + i * bstride + j));
-        }
-    } else {
-        const int64_t total = n * hw;
-        for (int64_t idx = tid; idx < total; idx += nthr) {
-            const int64_t i = idx / hw, j = idx - i * hw;
-            const float v = base[i * bstride + j];
-            f(i, j, make_float4(v, 0.f, 0.f, 0.f));
+    // f(plane index i, offset inside the plane, value(s)) over the n planes of one channel.  32-bit index
+    // arithmetic (a channel has < 2^31 items: checked by the launchers) and four items in flight per thread.
+    const unsigned q = (unsigned)(VEC ? hw / 4 : hw), total = (unsigned)n * q;
+#pragma unroll 4
+    for (unsigned idx = tid; idx < total; idx += nthr) {
+        const unsigned i = idx / q, j = (idx - i * q) * (VEC ? 4u : 1u);
+        const float* p = base + (int64_t)i * bstride + j;
+        if (VEC) {
+            f((int64_t)i, (int64_t)j, *reinterpret_cast<const float4*>(p));
+        } else {
+            f((int64_t)i, (int64_t)j, make_float4(*p, 0.f, 0.f, 0.f));
         }
     }
 }
@@ -229,7 +227,7 @@ extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* residual, c
                                         int64_t x_batch_stride, float momentum, float eps, int relu, void* stream) {
     using namespace nw;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (n <= 0 || c < 0 || hw <= 0 || x_batch_stride < c * hw || c > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    if (n <= 0 || c < 0 || hw <= 0 || x_batch_stride < c * hw || c > 0x7fffffffLL || n * hw > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
     if (c == 0) return NW_OK;
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd) return NW_ERR_INVALID_ARG;
     const bool vec = hw % 4 == 0 && x_batch_stride % 4 == 0 &&
@@ -263,7 +261,7 @@ extern "C" int nw_bn_relu_train_bwd_f32(const float* x, const float* residual, c
                                         int64_t x_batch_stride, int relu, void* stream) {
     using namespace nw;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (n <= 0 || c < 0 || hw <= 0 || x_batch_stride < c * hw || c > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    if (n <= 0 || c < 0 || hw <= 0 || x_batch_stride < c * hw || c > 0x7fffffffLL || n * hw > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
     if (c == 0) return NW_OK;
     if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return NW_ERR_INVALID_ARG;
     const bool vec = hw % 4 == 0 && x_batch_stride % 4 == 0 &&

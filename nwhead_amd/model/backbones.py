@@ -110,6 +110,7 @@ class ResNet(nn.Module):
 
 
 # ----------------------------------------------------------------------------- CIFAR pre-act ResNet
+DENSE_INCREMENTAL_CAT = True    # dense blocks extend one running concatenation (see _DenseBlock.forward)
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
 
 
@@ -201,6 +202,11 @@ class _DenseBlock(nn.Module):
             # concatenating the list of features at every layer, densenet.py:62-80): its backward is then ONE
             # gradient accumulation per layer instead of one per (feature, later layer) pair -- 58 instead of
             # 540 small strided adds in a DenseNet-121 step.
+            if not DENSE_INCREMENTAL_CAT:
+                feats = [x]
+                for layer in layers:
+                    feats.append(layer(torch.cat(feats, 1)))
+                return torch.cat(feats, 1)
             cur = x
             for layer in layers:
                 cur = torch.cat((cur, layer(cur)), 1)

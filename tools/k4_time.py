@@ -7,9 +7,11 @@ from nwhead_amd.model import load_model
 from nwhead_amd.nwhead.kernel import get_kernel
 from nwhead_amd.nwhead.nw import NWHead
 dev = torch.device("cuda:0")
+from nwhead_amd.model import backbones
+backbones.DENSE_INCREMENTAL_CAT = os.environ.get("NW_LIST_CAT", "0") != "1"
 g = torch.Generator().manual_seed(7)
 arch = sys.argv[1] if len(sys.argv) > 1 else "densenet121"
-for fmt in (torch.contiguous_format, torch.channels_last):
+for fmt in (torch.contiguous_format,):
     dn = load_model(arch).to(dev).train().to(memory_format=fmt)
     opt = torch.optim.SGD(dn.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4)
     xq = torch.randn(32, 3, 224, 224, generator=g).to(dev)
