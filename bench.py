@@ -216,7 +216,7 @@ def measure_backbone_configs(dev):
             loss = F.nll_loss(head(feats[:32], feats[32:], ys), yq)
             loss.backward()
             opt.step()
-        t = time_kernel_events(k4, 8, warmup=6)     # MIOpen's first calls of a configuration run slow stand-in kernels
+        t = time_kernel_events(k4, 8, warmup=10)    # MIOpen's first calls of a configuration run slow stand-in kernels
         gf4 = 5.67 * 3 * 42                                   # GFLOP, DenseNet-121 fwd+bwd over 32 + 10 images @224
         out["config_K4_densenet121_train_step"] = {"B": 32, "n_way": 10, "n_shot": 1, "ms_per_step": t * 1e3,
                                                    "backbone": "torch/MIOpen fp32", "backbone_TFLOPs": gf4 / t / 1e3,
