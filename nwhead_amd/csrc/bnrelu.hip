@@ -77,29 +77,36 @@ __global__ __launch_bounds__(1024) void nw_bn_train_fwd_kernel(
     const int tid = threadIdx.x, nthr = blockDim.x;
     if (num_batches_tracked && c == 0 && tid == 0) *num_batches_tracked += 1;  // BatchNorm2d's step counter, no launch of its own
     const float* xc = x + c * hw;
-    // Two centred passes (mean, then sum of (x - mean)^2): a one-pass E[x^2] - E[x]^2 loses the variance of
-    // a channel whose spread is small next to its offset, and 1/sqrt(var + 1e-5) amplifies that.  The second
-    // and third reads of the channel come from L2 for everything but the stem.
-    const float K = xc[0];
-    float s1 = 0.f;
+    // One pass of SHIFTED sums, S1 = sum(x - K), S2 = sum((x - K)^2), var = S2/m - (S1/m)^2.  Unshifted
+    // (K = 0) this loses the variance of a channel whose spread is small next to its offset, and
+    // 1/sqrt(var + 1e-5) amplifies that; with K within a few standard deviations of the mean the
+    // cancellation is harmless ((mean - K)^2 / var enters the relative error once, times 2^-24).  K is the
+    // mean of 64 samples spread over the channel's planes (a single sample could be a border value).
+    __shared__ float k_s;
+    if (tid < 64) {
+        const int64_t i = tid % n, j = ((int64_t)tid * 37) % hw;
+        const float ks = wave_sum(xc[i * x_batch_stride + j]);
+        if (tid == 0) k_s = ks * (1.f / 64.f);
+    }
+    __syncthreads();
+    const float K = k_s;
+    float s1 = 0.f, s2 = 0.f;
     for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t, int64_t, const float4 v) {
-        s1 += v.x - K;
-        if (VEC) s1 += (v.y - K) + ((v.z - K) + (v.w - K));
-    });
-    s1 = block_sum(s1, red);
-    const float m = (float)(n * hw);
-    const float mean = K + s1 / m;
-    float s2 = 0.f;
-    for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t, int64_t, const float4 v) {
-        const float d0 = v.x - mean;
-        s2 = __builtin_fmaf(d0, d0, s2);
+        const float d0 = v.x - K;
+        s1 += d0; s2 = __builtin_fmaf(d0, d0, s2);
         if (VEC) {
-            const float d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-            s2 = __builtin_fmaf(d1, d1, s2); s2 = __builtin_fmaf(d2, d2, s2); s2 = __builtin_fmaf(d3, d3, s2);
+            const float d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
+            s1 += d1; s2 = __builtin_fmaf(d1, d1, s2);
+            s1 += d2; s2 = __builtin_fmaf(d2, d2, s2);
+            s1 += d3; s2 = __builtin_fmaf(d3, d3, s2);
         }
     });
+    s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
-    const float var = s2 / m;  // biased (normalisation); the running one is unbiased
+    const float m = (float)(n * hw);
+    const float md = s1 / m;
+    const float mean = K + md;
+    const float var = fmaxf(s2 / m - md * md, 0.f);  // biased (normalisation); the running one is unbiased
     const float invstd = 1.f / sqrtf(var + eps);
     if (tid == 0) {
         save_mean[c] = mean;
@@ -107,13 +114,15 @@ __global__ __launch_bounds__(1024) void nw_bn_train_fwd_kernel(
         if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
         if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (m > 1.f ? m / (m - 1.f) : 1.f);
     }
-    const float a = gamma[c] * invstd, b = beta[c] - mean * a;
+    // y = (x - mean) * a + beta, not x * a + (beta - mean * a): the latter rounds at the size of mean * a, which a
+    // near-constant channel (a ~ 1/sqrt(eps)) turns into visible error
+    const float a = gamma[c] * invstd, b = beta[c];
     float* yc = y + c * hw;
     const float* rc = RES ? residual + c * hw : nullptr;
     for_channel<VEC>(xc, n, hw, x_batch_stride, tid, nthr, [&](int64_t i, int64_t j, float4 v) {
-        v.x = __builtin_fmaf(v.x, a, b);
+        v.x = __builtin_fmaf(v.x - mean, a, b);
         if (VEC) {
-            v.y = __builtin_fmaf(v.y, a, b); v.z = __builtin_fmaf(v.z, a, b); v.w = __builtin_fmaf(v.w, a, b);
+            v.y = __builtin_fmaf(v.y - mean, a, b); v.z = __builtin_fmaf(v.z - mean, a, b); v.w = __builtin_fmaf(v.w - mean, a, b);
             if (RES) {
                 const float4 r = *reinterpret_cast<const float4*>(rc + i * C * hw + j);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -142,11 +151,11 @@ __global__ __launch_bounds__(1024) void nw_bn_train_bwd_kernel(
     const float* rc = RES ? residual + c * hw : nullptr;
     float* drc = RES ? dresidual + c * hw : nullptr;
     const float mean = save_mean[c], invstd = save_invstd[c], g = gamma[c];
-    const float a = g * invstd, b = beta[c] - mean * a;  // the forward's own y = fma(x, a, b): same ReLU mask
+    const float a = g * invstd, b = beta[c];  // the forward's own y = fma(x - mean, a, beta): same ReLU mask
     float s1 = 0.f, s2 = 0.f;
     auto term = [&](float xv, float rv, float dv, float& gd, float& xh) {
         xh = (xv - mean) * invstd;
-        float pre = __builtin_fmaf(xv, a, b);
+        float pre = __builtin_fmaf(xv - mean, a, b);
         if (RES) pre += rv;
         gd = (!RELU || pre > 0.f) ? dv : 0.f;
     };

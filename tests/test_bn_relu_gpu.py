@@ -45,6 +45,28 @@ def test_bn_relu_train_matches_torch(shape, prefix, relu):
         torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+def test_bn_train_statistics_on_awkward_channels():
+    """Channels the one-pass shifted sums could get wrong: constant, constant plus a rounding-sized ripple, a zero
+    border around an offset interior (the sampled shift sees both), and a huge offset with a tiny spread."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(0)
+    n, h, w = 8, 16, 16
+    x = torch.zeros(n, 5, h, w)
+    x[:, 0] = 50.0
+    x[:, 1] = 50.0 + 1e-5 * torch.randn(n, h, w, generator=g)
+    x[:, 2, 2:-2, 2:-2] = 40.0 + 0.5 * torch.randn(n, h - 4, w - 4, generator=g)
+    x[:, 3] = 1000.0 + 0.01 * torch.randn(n, h, w, generator=g)
+    x[:, 4] = torch.randn(n, h, w, generator=g)
+    bn_a, bn_b = nn.BatchNorm2d(5).cuda().train(), nn.BatchNorm2d(5).double().train()
+    ya = ops.bn_relu_train(x.cuda(), bn_a, False)
+    yb = bn_b(x.double())
+    torch.testing.assert_close(bn_a.running_mean.cpu().double(), bn_b.running_mean, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(bn_a.running_var.cpu().double(), bn_b.running_var, rtol=1e-4, atol=1e-7)
+    # channel 3's inputs carry 6e-5 of representation error each (fp32 at 1000) against a spread of 0.01
+    torch.testing.assert_close(ya.cpu().double()[:, [0, 1, 2, 4]], yb[:, [0, 1, 2, 4]], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ya.cpu().double()[:, 3], yb[:, 3], rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("shape", [(6, 12, 8, 8), (5, 20, 7, 7), (16, 128, 28, 28)])
 def test_bn_add_relu_train_matches_torch(shape):
     """relu(bn(x) + residual), the tail of a ResNet block: outputs and all four gradients against fp64 torch."""
