@@ -205,6 +205,9 @@ int nw_scale_shift_relu_f32(const float *x, const float *scale, const float *shi
  *             from x, nothing else is saved
  *   residual (nullable, (n, c, hw) contiguous): y = max(bn(x) + residual, 0), the tail of a ResNet block
  *             (model/resnet.py:58-66, :100-108); the backward then also writes dresidual (the masked dy)
+ *   acc (nullable, backward): a second gradient of x, element (i, ch, p) at acc[i * acc_batch_stride + ch * hw + p],
+ *             added into dx (the running concatenation of a dense block, model/densenet.py:62-80, feeds this
+ *             BatchNorm and the next concatenation: autograd would add the two with a strided kernel of its own)
  *   x element (i, ch, p) at x[i * x_batch_stride + ch * hw + p]; y, dy, dx contiguous
  * ------------------------------------------------------------------------------------------- */
 int nw_bn_relu_train_fwd_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
@@ -213,7 +216,8 @@ int nw_bn_relu_train_fwd_f32(const float *x, const float *residual, const float 
                              int64_t x_batch_stride, float momentum, float eps, int relu, void *stream);
 int nw_bn_relu_train_bwd_f32(const float *x, const float *residual, const float *dy, const float *gamma,
                              const float *beta, const float *save_mean, const float *save_invstd, float *dx,
-                             float *dresidual, float *dgamma, float *dbeta, int64_t n, int64_t c, int64_t hw,
+                             float *dresidual, float *dgamma, float *dbeta, const float *acc,
+                             int64_t acc_batch_stride, int64_t n, int64_t c, int64_t hw,
                              int64_t x_batch_stride, int relu, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

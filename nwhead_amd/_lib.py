@@ -38,7 +38,7 @@ SIGNATURES = {
     "nw_topk_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "nw_scale_shift_relu_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "nw_bn_relu_train_fwd_f32": (_int, [_p] * 10 + [_i64, _i64, _i64, _i64, C.c_float, C.c_float, _int, _p]),
-    "nw_bn_relu_train_bwd_f32": (_int, [_p] * 11 + [_i64, _i64, _i64, _i64, _int, _p]),
+    "nw_bn_relu_train_bwd_f32": (_int, [_p] * 12 + [_i64, _i64, _i64, _i64, _i64, _int, _p]),
     "nw_debug_tile_timing": (_int, [_int]),
     "nw_debug_tile_timing_read": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -142,12 +142,17 @@ __global__ __launch_bounds__(1024) void nw_bn_train_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ residual, const float* __restrict__ dy,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save_mean,
     const float* __restrict__ save_invstd, float* __restrict__ dx, float* __restrict__ dresidual,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t n, int64_t C, int64_t hw, int64_t x_batch_stride) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ acc, int64_t acc_batch_stride,
+    int64_t n, int64_t C, int64_t hw, int64_t x_batch_stride) {
     __shared__ float red[16];
     const int64_t c = blockIdx.x;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const float* xc = x + c * hw;
     const float* dyc = dy + c * hw;
+    // acc (nullable): another gradient of x, added into dx here instead of by a separate strided add (the running
+    // concatenation of a dense block feeds this BatchNorm AND the next concatenation); element (i, c, p) at
+    // acc[i * acc_batch_stride + c * hw + p]
+    const float* accc = acc ? acc + c * hw : nullptr;
     const float* rc = RES ? residual + c * hw : nullptr;
     float* drc = RES ? dresidual + c * hw : nullptr;
     const float mean = save_mean[c], invstd = save_invstd[c], g = gamma[c];
@@ -192,11 +197,15 @@ __global__ __launch_bounds__(1024) void nw_bn_train_bwd_kernel(
             term(v.y, r.y, d.y, gd, xh); o.y = a * (gd - k1 - xh * k2); go.y = gd;
             term(v.z, r.z, d.z, gd, xh); o.z = a * (gd - k1 - xh * k2); go.z = gd;
             term(v.w, r.w, d.w, gd, xh); o.w = a * (gd - k1 - xh * k2); go.w = gd;
+            if (accc) {
+                const float4 e = *reinterpret_cast<const float4*>(accc + i * acc_batch_stride + j);
+                o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+            }
             *reinterpret_cast<float4*>(dxc + i * C * hw + j) = o;
             if (RES) *reinterpret_cast<float4*>(drc + i * C * hw + j) = go;
         } else {
             term(v.x, RES ? rc[i * C * hw + j] : 0.f, dyc[i * C * hw + j], gd, xh);
-            dxc[i * C * hw + j] = a * (gd - k1 - xh * k2);
+            dxc[i * C * hw + j] = a * (gd - k1 - xh * k2) + (accc ? accc[i * acc_batch_stride + j] : 0.f);
             if (RES) drc[i * C * hw + j] = gd;
         }
     });
@@ -266,7 +275,8 @@ extern "C" int nw_bn_relu_train_fwd_f32(const float* x, const float* residual, c
 
 extern "C" int nw_bn_relu_train_bwd_f32(const float* x, const float* residual, const float* dy, const float* gamma,
                                         const float* beta, const float* save_mean, const float* save_invstd, float* dx,
-                                        float* dresidual, float* dgamma, float* dbeta, int64_t n, int64_t c, int64_t hw,
+                                        float* dresidual, float* dgamma, float* dbeta, const float* acc,
+                                        int64_t acc_batch_stride, int64_t n, int64_t c, int64_t hw,
                                         int64_t x_batch_stride, int relu, void* stream) {
     using namespace nw;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -275,22 +285,24 @@ extern "C" int nw_bn_relu_train_bwd_f32(const float* x, const float* residual, c
     if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return NW_ERR_INVALID_ARG;
     const bool vec = hw % 4 == 0 && x_batch_stride % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
-                       reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(dresidual)) & 15) == 0;
+                       reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(dresidual) |
+                       reinterpret_cast<uintptr_t>(acc)) & 15) == 0 && (!acc || acc_batch_stride % 4 == 0);
+    if (acc && acc_batch_stride < c * hw) return NW_ERR_INVALID_ARG;
     const unsigned thr = channel_threads(n * hw);
     if ((residual != nullptr) != (dresidual != nullptr) || (residual && !relu)) return NW_ERR_INVALID_ARG;
     if (residual) {
         if (vec)
             hipLaunchKernelGGL((nw_bn_train_bwd_kernel<true, true, true>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, dy, gamma,
-                               beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, n, c, hw, x_batch_stride);
+                               beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, acc, acc_batch_stride, n, c, hw, x_batch_stride);
         else
             hipLaunchKernelGGL((nw_bn_train_bwd_kernel<true, false, true>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, dy, gamma,
-                               beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, n, c, hw, x_batch_stride);
+                               beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, acc, acc_batch_stride, n, c, hw, x_batch_stride);
         NW_CHECK_LAUNCH();
         return NW_OK;
     }
 #define NW_BNB(R_, V_)                                                                                          \
     hipLaunchKernelGGL((nw_bn_train_bwd_kernel<R_, V_, false>), dim3((unsigned)c), dim3(thr), 0, st, x, residual, dy, gamma, beta, \
-                       save_mean, save_invstd, dx, dresidual, dgamma, dbeta, n, c, hw, x_batch_stride)
+                       save_mean, save_invstd, dx, dresidual, dgamma, dbeta, acc, acc_batch_stride, n, c, hw, x_batch_stride)
     if (relu) { if (vec) NW_BNB(true, true); else NW_BNB(true, false); }
     else { if (vec) NW_BNB(false, true); else NW_BNB(false, false); }
 #undef NW_BNB

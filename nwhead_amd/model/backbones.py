@@ -110,8 +110,15 @@ class ResNet(nn.Module):
 
 
 # ----------------------------------------------------------------------------- CIFAR pre-act ResNet
+DENSE_PASSTHROUGH = True        # the running concatenation passes through norm1's autograd node (see _DenseBlock.forward)
 DENSE_INCREMENTAL_CAT = True    # dense blocks extend one running concatenation (see _DenseBlock.forward)
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
+
+
+def _fused_training(bn, x):
+    return (FUSED_BN_RELU_TRAINING and isinstance(bn, nn.BatchNorm2d) and bn.training and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4 and bn.affine and torch.is_grad_enabled()
+            and (x.stride(3) == 1 and x.stride(2) == x.shape[3] and x.stride(1) == x.shape[2] * x.shape[3]))
 
 
 def _bn_relu(bn, x, residual=None):
@@ -120,9 +127,7 @@ def _bn_relu(bn, x, residual=None):
     ops of the reference."""
     if isinstance(bn, ScaleShiftReLU):
         return bn(x)
-    if (FUSED_BN_RELU_TRAINING and isinstance(bn, nn.BatchNorm2d) and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-            and bn.affine and torch.is_grad_enabled()
-            and (x.stride(3) == 1 and x.stride(2) == x.shape[3] and x.stride(1) == x.shape[2] * x.shape[3])):
+    if _fused_training(bn, x):
         from .. import ops
         return ops.bn_relu_train(x, bn, True, residual)
     return F.relu(bn(x) if residual is None else bn(x) + residual)
@@ -183,8 +188,10 @@ class _DenseLayer(nn.Sequential):
         # relu1 must not run in place on a slab/concat that later layers re-read
         if isinstance(self.norm1, ScaleShiftReLU):       # folded inference copy (fold_batchnorm)
             return self.conv2(self.relu2(self.conv1(self.norm1(x))))
-        y = self.conv1(_bn_relu(self.norm1, x))
-        y = self.conv2(_bn_relu(self.norm2, y))
+        return self.after_norm1(_bn_relu(self.norm1, x))
+
+    def after_norm1(self, a):
+        y = self.conv2(_bn_relu(self.norm2, self.conv1(a)))
         return F.dropout(y, self.drop_rate, self.training) if self.drop_rate > 0 else y
 
 
@@ -209,7 +216,14 @@ class _DenseBlock(nn.Module):
                 return torch.cat(feats, 1)
             cur = x
             for layer in layers:
-                cur = torch.cat((cur, layer(cur)), 1)
+                if DENSE_PASSTHROUGH and _fused_training(layer.norm1, cur):
+                    # cur feeds norm1 AND the next concatenation: it goes through the BatchNorm node and comes out
+                    # again, so the concatenation's gradient is added to dx inside the backward kernel
+                    from .. import ops
+                    a, cur = ops.bn_relu_train(cur, layer.norm1, True, None, passthrough=True)
+                    cur = torch.cat((cur, layer.after_norm1(a)), 1)
+                else:
+                    cur = torch.cat((cur, layer(cur)), 1)
             return cur
         # inference: one slab, each layer appends its channels (no per-layer re-concatenation)
         n, c, h, w = x.shape

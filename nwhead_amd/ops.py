@@ -339,7 +339,7 @@ class _BNReLUTrainFn(torch.autograd.Function):
     """relu(batch_norm(x) [+ residual]) in training mode: nw_bn_relu_train_fwd_f32 / _bwd_f32 (one kernel each)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, bn, relu):
+    def forward(ctx, x, weight, bias, residual, bn, relu, passthrough=False):
         lib = _lib.load()
         xv, bstride = _plane_view(x.detach())
         n, c, h, w = xv.shape
@@ -368,35 +368,46 @@ class _BNReLUTrainFn(torch.autograd.Function):
                                                     _ptr(invstd), _ptr(nbt), n, c, h * w, bstride, momentum, float(bn.eps),
                                                     int(relu), _stream(xv)), "nw_bn_relu_train_fwd_f32")
         ctx.save_for_backward(xv, wc, bc, mean, invstd, *(() if rv is None else (rv,)))
-        ctx.relu, ctx.bstride = relu, bstride
+        ctx.relu, ctx.bstride, ctx.passthrough = relu, bstride, passthrough
+        if passthrough:                 # (y, x): x leaves again so that it has ONE consumer; its other gradient
+            ctx.set_materialize_grads(False)   # arrives in backward and is added inside the kernel
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gpass=None):
         lib = _lib.load()
         xv, wc, bc, mean, invstd, *rest = ctx.saved_tensors
         rv = rest[0] if rest else None
         n, c, h, w = xv.shape
+        if gy is None:                  # only the pass-through output was used
+            return gpass, None, None, None, None, None, None
         gy = _f32c(gy)
+        acc, acc_bs = None, 0
+        if gpass is not None:
+            acc, acc_bs = _plane_view(gpass)
         dx = torch.empty(n, c, h, w, dtype=torch.float32, device=xv.device)
         dr = torch.empty_like(dx) if rv is not None else None
         dg, db = torch.empty_like(mean), torch.empty_like(mean)
         with torch.cuda.device(xv.device):
             _lib.check(lib.nw_bn_relu_train_bwd_f32(_ptr(xv), _ptr(rv), _ptr(gy), _ptr(wc), _ptr(bc), _ptr(mean),
-                                                    _ptr(invstd), _ptr(dx), _ptr(dr), _ptr(dg), _ptr(db), n, c, h * w,
-                                                    ctx.bstride, int(ctx.relu), _stream(xv)), "nw_bn_relu_train_bwd_f32")
-        return dx, dg, db, dr, None, None
+                                                    _ptr(invstd), _ptr(dx), _ptr(dr), _ptr(dg), _ptr(db), _ptr(acc), acc_bs,
+                                                    n, c, h * w, ctx.bstride, int(ctx.relu), _stream(xv)),
+                       "nw_bn_relu_train_bwd_f32")
+        return dx, dg, db, dr, None, None, None
 
 
-def bn_relu_train(x, bn, relu=True, residual=None):
+def bn_relu_train(x, bn, relu=True, residual=None, passthrough=False):
     """relu(bn(x)) -- or relu(bn(x) + residual), the tail of a ResNet block -- for a BatchNorm2d in training mode
-    (batch statistics, running statistics updated), fp32 NCHW on the MI355X."""
+    (batch statistics, running statistics updated), fp32 NCHW on the MI355X.
+    passthrough=True returns (y, x'): x' is x again, to be used by x's OTHER consumer, so that the gradient
+    coming back through it is added to dx inside the backward kernel."""
     _need_hip(x, bn.weight, bn.bias, residual)
     if not (bn.affine and bn.weight is not None):
         raise ValueError("bn_relu_train needs an affine BatchNorm2d")
     if bn.running_mean is not None and (bn.running_mean.dtype != torch.float32 or not bn.running_mean.is_contiguous()):
         raise ValueError("running statistics must be contiguous fp32")
-    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, residual, bn, bool(relu))
+    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, residual, bn, bool(relu), bool(passthrough))
 
 
 def support_influence_idx(probs, qy, w, sy):

@@ -9,6 +9,7 @@ from nwhead_amd.nwhead.nw import NWHead
 dev = torch.device("cuda:0")
 from nwhead_amd.model import backbones
 backbones.DENSE_INCREMENTAL_CAT = os.environ.get("NW_LIST_CAT", "0") != "1"
+backbones.DENSE_PASSTHROUGH = os.environ.get("NW_NO_PASS", "0") != "1"
 g = torch.Generator().manual_seed(7)
 arch = sys.argv[1] if len(sys.argv) > 1 else "densenet121"
 for fmt in (torch.contiguous_format,):
