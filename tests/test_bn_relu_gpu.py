@@ -133,3 +133,32 @@ def test_backbone_train_step_fused_vs_torch(arch, size, batch):
     e_fused, e_plain = err(fused, ref), err(plain, ref)
     print(f"{arch}: fused vs cpu {e_fused:.2e}   torch-device vs cpu {e_plain:.2e}")
     assert e_fused <= max(4 * e_plain, 1e-2), (e_fused, e_plain)
+
+
+@pytest.mark.parametrize("shape,extra", [((6, 24, 8, 8), 8), ((5, 10, 7, 7), 3)])
+def test_bn_relu_passthrough_accumulates_the_other_gradient(shape, extra):
+    """bn_relu_train(..., passthrough=True): x goes through the node and on into a concatenation (a dense block's
+    running concatenation); the gradient that comes back through the concatenation -- a channel-prefix slice, not
+    contiguous -- is added to dx inside the backward kernel."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    n, c, h, w = shape
+    x0, new0 = torch.randn(*shape, generator=g), torch.randn(n, extra, h, w, generator=g)
+    bn_a, bn_b = nn.BatchNorm2d(c).cuda().train(), nn.BatchNorm2d(c).double().train()
+    xa, xb = x0.cuda().requires_grad_(True), x0.double().requires_grad_(True)
+    a, xpass = ops.bn_relu_train(xa, bn_a, True, None, passthrough=True)
+    cat_a = torch.cat((xpass, new0.cuda()), 1)
+    ref_pre = bn_b(xb)
+    cat_b = torch.cat((xb, new0.double()), 1)
+    w1 = torch.randn(*shape, generator=g).double() * (ref_pre.detach().abs() > 1e-4)
+    w2 = torch.randn(n, c + extra, h, w, generator=g).double()
+    ((a * w1.float().cuda()).sum() + (cat_a * w2.float().cuda()).sum()).backward()
+    ((F.relu(ref_pre) * w1).sum() + (cat_b * w2).sum()).backward()
+    scale = float(xb.grad.abs().max())
+    torch.testing.assert_close(xa.grad.cpu().double() / scale, xb.grad / scale, rtol=1e-4, atol=3e-5)
+    torch.testing.assert_close(bn_a.weight.grad.cpu().double(), bn_b.weight.grad, rtol=1e-4, atol=1e-4 * float(bn_b.weight.grad.abs().max()))
+    # only the pass-through output used: the node is a plain identity for x
+    xa2 = x0.cuda().requires_grad_(True)
+    _, xp = ops.bn_relu_train(xa2, nn.BatchNorm2d(c).cuda().train(), True, None, passthrough=True)
+    (xp * w2[:, :c].float().cuda()).sum().backward()
+    torch.testing.assert_close(xa2.grad.cpu().double(), w2[:, :c], rtol=1e-6, atol=1e-6)
