@@ -34,10 +34,21 @@ with open(f"profiles/{name}_summary.md", "w") as fh:
     fh.write(f"# rocprofv3 summary `{name}`\n\ncommand: `{cmd}`\n\n## --kernel-trace --stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for r in stats:
         fh.write(f"| `{r['kernel']}` | {r['calls']} | {r['avg_us']:.2f} | {r['min_us']:.2f} | {r['max_us']:.2f} | {r['pct']:.1f} |\n")
+    # the dominant kernel launch by launch: after an idle period the clocks ramp for ~40 launches,
+    # so the all-launch average above sits above the steady state bench.py's timed region runs in
+    for f in glob.glob(src + "/trace/**/*kernel_trace.csv", recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if kname(r["Kernel_Name"]) == stats[0]["kernel"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        if len(d) >= 40:
+            tail = d[-20:]
+            fh.write(f"\n`{stats[0]['kernel']}` launch by launch: first 5 = {', '.join(f'{x:.0f}' for x in d[:5])} us; "
+                     f"last 20 average {sum(tail) / len(tail):.1f} us (min {min(tail):.1f}, max {max(tail):.1f}) -- "
+                     f"the steady state `roofline.kernel_us` of the bench line is measured in.\n")
     fh.write("\n## --pmc (separate passes; mean per dispatch)\n\n")
     for k, d in pmc.items():
         fh.write(f"### `{k}`\n\n| counter | mean per dispatch |\n|---|---|\n")
         for c, v in sorted(d.items()):
             fh.write(f"| {c} | {v:,.1f} |\n")
         fh.write("\n")
-print(open(f"profiles/{name}_summary.md").read())
+print(open(f"profiles/{name}_summary.md").read()[:1500])
