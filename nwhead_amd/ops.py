@@ -405,6 +405,8 @@ def bn_relu_train(x, bn, relu=True, residual=None, passthrough=False):
     _need_hip(x, bn.weight, bn.bias, residual)
     if not (bn.affine and bn.weight is not None):
         raise ValueError("bn_relu_train needs an affine BatchNorm2d")
+    if x.shape[0] * x.shape[2] * x.shape[3] <= 1:      # torch.nn.functional.batch_norm's own check
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
     if bn.running_mean is not None and (bn.running_mean.dtype != torch.float32 or not bn.running_mean.is_contiguous()):
         raise ValueError("running statistics must be contiguous fp32")
     return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, residual, bn, bool(relu), bool(passthrough))
