@@ -12,16 +12,24 @@ namespace {
 // One 256-thread workgroup per query row.  HBM-bound streaming of one score row (4*N bytes, re-read
 // from L2 on the later passes) plus 8*N bytes of labels.
 //   pass 1: m = max_j s_j          pass 2: den = sum_j exp(s_j - m)
-//   pass 3: per-class sums of exp(s_j - m) in LDS (ds_add_f32), optional normalised weights
+//   pass 3: per-class sums of exp(s_j - m), optional normalised weights.  No float atomics: the row is
+//           staged through LDS in chunks of AGG_CH supports, every class is owned by ONE thread, which adds
+//           the chunk's members of its class in support order (it scans [first, last] position of the class
+//           inside the chunk, found with integer LDS min / max) -- the result is bit-reproducible.
+constexpr int AGG_CH = 2048;
 template <bool PARTIAL>
 __global__ __launch_bounds__(256) void nw_aggregate_kernel(
     const float* __restrict__ scores, const int64_t* __restrict__ sy, int labels_batched,
     float* __restrict__ out, float* __restrict__ lse, float* __restrict__ weights,
     float* __restrict__ m_out, float* __restrict__ den_out, float* __restrict__ num_out, int64_t N,
-    int64_t C) {
+    int64_t C, int use_ranges) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // 8 floats
-    float* num = red + 8;                         // C floats
+    float* ev = red + 8;                          // AGG_CH: exp(s - m) of the staged chunk
+    int* yv = reinterpret_cast<int*>(ev + AGG_CH);  // AGG_CH: its labels (-1: outside [0, C))
+    float* num = reinterpret_cast<float*>(yv + AGG_CH);  // C floats
+    int* jlo = reinterpret_cast<int*>(num + C);           // C ints (use_ranges)
+    int* jhi = jlo + C;                                   // C ints (use_ranges)
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
     const float* row = scores + b * N;
@@ -55,13 +63,38 @@ __global__ __launch_bounds__(256) void nw_aggregate_kernel(
     den = block_sum(den, red);  // the barriers inside also publish the zeroed num[]
     const float inv_den = 1.f / den;
 
-    for (int64_t j = tid; j < N; j += 256) {
-        const float e = expf(row[j] - m);
-        const int64_t y = lab[j];
-        if ((uint64_t)y < (uint64_t)C) atomicAdd(&num[y], e);
-        if (!PARTIAL && weights) weights[b * N + j] = e * inv_den;
+    for (int64_t base = 0; base < N; base += AGG_CH) {
+        const int len = (int)((N - base < AGG_CH) ? (N - base) : AGG_CH);
+        if (use_ranges) {
+            for (int64_t c = tid; c < C; c += 256) {
+                jlo[c] = 0x7fffffff;
+                jhi[c] = -1;
+            }
+            __syncthreads();
+        }
+        for (int k = tid; k < len; k += 256) {
+            const int64_t j = base + k;
+            const float e = expf(row[j] - m);
+            const int64_t y = lab[j];
+            const int yi = ((uint64_t)y < (uint64_t)C) ? (int)y : -1;
+            ev[k] = e;
+            yv[k] = yi;
+            if (use_ranges && yi >= 0) {
+                atomicMin(&jlo[yi], k);
+                atomicMax(&jhi[yi], k);
+            }
+            if (!PARTIAL && weights) weights[b * N + j] = e * inv_den;
+        }
+        __syncthreads();
+        for (int64_t c = tid; c < C; c += 256) {
+            const int k0 = use_ranges ? jlo[c] : 0, k1 = use_ranges ? jhi[c] : len - 1;
+            float a = num[c];
+            for (int k = k0; k <= k1; ++k)
+                if (yv[k] == (int)c) a += ev[k];
+            num[c] = a;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     if (PARTIAL) {
         if (tid == 0) {
@@ -125,8 +158,10 @@ int launch_aggregate(const float* scores, const int64_t* sy, int labels_batched,
     if (B <= 0) return NW_OK;
     if (B > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
     const bool partial = (out == nullptr);
-    const size_t lds = (8 + (size_t)C) * sizeof(float);
-    if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
+    const size_t lds_min = (8 + 2 * (size_t)AGG_CH + (size_t)C) * sizeof(float);
+    if (lds_min > 160 * 1024) return NW_ERR_UNSUPPORTED;
+    const int use_ranges = lds_min + 2 * (size_t)C * sizeof(int) <= 160 * 1024;  // per-class [first, last] position tables
+    const size_t lds = lds_min + (use_ranges ? 2 * (size_t)C * sizeof(int) : 0);
     if (N == 0) {
         if (partial) {
             const int64_t n = B * C;
@@ -143,10 +178,10 @@ int launch_aggregate(const float* scores, const int64_t* sy, int labels_batched,
     }
     if (partial)
         hipLaunchKernelGGL(nw_aggregate_kernel<true>, dim3((unsigned)B), dim3(256), lds, st, scores, sy,
-                           labels_batched, out, lse, weights, m, den, num, N, C);
+                           labels_batched, out, lse, weights, m, den, num, N, C, use_ranges);
     else
         hipLaunchKernelGGL(nw_aggregate_kernel<false>, dim3((unsigned)B), dim3(256), lds, st, scores, sy,
-                           labels_batched, out, lse, weights, m, den, num, N, C);
+                           labels_batched, out, lse, weights, m, den, num, N, C, use_ranges);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

@@ -137,146 +137,160 @@ size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws
 
 namespace {
 
-// One workgroup per query.  Tiles are rescaled to the global max M; run sums go to their class.
-// ws_m is in base-2 units (u = score * log2 e, see nw_fused_kernel).
-template <bool PARTIAL>
-__global__ __launch_bounds__(256) void nw_merge_runs_kernel(
-    const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
-    const int* __restrict__ ws_lab, const float* __restrict__ ws_num, float* __restrict__ out,
-    float* __restrict__ lse, float* __restrict__ m_out, float* __restrict__ den_out,
-    float* __restrict__ num_out, int B, int C, int n_stiles, int BS) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);
-    float* num = red + 8;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) num[c] = 0.f;
-
-    float M = -INFINITY;
-    for (int t = tid; t < n_stiles; t += 256) M = fmaxf(M, ws_m[(size_t)t * B + b]);
-    M = block_max(M, red);
-
-    float den = 0.f;
-    for (int t = tid; t < n_stiles; t += 256) {
-        const float f = __builtin_amdgcn_exp2f(ws_m[(size_t)t * B + b] - M);
-        den += ws_den[(size_t)t * B + b] * f;
-        const int nr = ws_nrun[t];
-        for (int r = 0; r < nr; ++r) {
-            const int y = ws_lab[(size_t)t * BS + r];
-            if (y >= 0) atomicAdd(&num[y], ws_num[((size_t)t * BS + r) * B + b] * f);
-        }
-    }
-    den = block_sum(den, red);  // its barriers also order the LDS adds before the reads below
-    __syncthreads();
-    if (PARTIAL) {
-        if (tid == 0) {
-            m_out[b] = M * 0.693147180559945309417f;  // back to natural units
-            den_out[b] = den;
-        }
-        for (int c = tid; c < C; c += 256) num_out[(size_t)b * C + c] = num[c];
-    } else {
-        const float inv = 1.f / den;
-        if (tid == 0 && lse) lse[b] = M * 0.693147180559945309417f + logf(den);
-        for (int c = tid; c < C; c += 256) out[(size_t)b * C + c] = logf(num[c] * inv + NW_LOG_EPS);
-    }
-}
-
-// (Merging inside the tile kernel -- the last workgroup of a query tile does it -- was tried and dropped:
-//  one CU's ~450 dependent-latency loads take 25 us where this kernel's 256 workgroups take 6, and
-//  agent-scope release/acquire fences cost ~40 us per launch on the 8-XCD part.)
-// The same merge for large query batches: one workgroup per MQ = 16 consecutive queries, its 256
-// threads = 16 queries x 16 tile lanes, so every workspace read is a 64-byte run along the query
-// axis (the one-workgroup-per-query kernel above reads 4 bytes per 16 KB stride: 53 us at B = 4096,
-// n_stiles = 391).  Class sums live in LDS as num[class][query].
-// MQ x ML = 16 x 32 when there are many tiles per query (K3: 391); 32 x 16 when there are few (a shard of
-// the bank at 8 ranks: 49 tiles -- measured there 14.9 / 11.1 / 11.5 us for MQ = 16 / 32 / 64).
-// (A query-blocked workspace with packed run rows -- one contiguous 40 KB piece per 128 queries instead
-//  of 256-byte runs B*4 bytes apart -- was measured too: no change; the walk is bound by its dependent
-//  load latencies, not by locality.)
-constexpr int MTHREADS = 512, MU = 4;
-template <bool PARTIAL, int MQ>
-__global__ __launch_bounds__(MTHREADS) void nw_merge_runs_blk_kernel(
+// The run merge.  One workgroup per MQ consecutive queries; ws_m is in base-2 units (u = score * log2 e,
+// see nw_fused_kernel).  Three phases, two global round trips, NO float atomics -- every sum has a fixed
+// order, so the output is bit-reproducible from launch to launch:
+//   0  (tables, shared by the workgroup's queries) per class c: the (tile, run) entries that carry it, in
+//      bank order.  A class-sorted bank gives a class 1-3 entries; up to MENT are kept in LDS (integer LDS
+//      atomics hand out the slots, the slots are then sorted: deterministic), a class with more entries is
+//      found again by scanning the run labels of tiles [tlo[c], thi[c]].
+//   1  M = max over tiles, den = sum_t den_t 2^(m_t - M): threads = MQ queries x ML tile lanes, each lane
+//      sums its tiles in order, the lanes are added in order.
+//   2  thread per (class, query): its entries' run sums, rescaled, added in bank order; every address is
+//      known from the LDS tables, so the loads of one thread fly together.
+// The reads of phases 0 and 1 do not depend on each other: one round trip; phase 2 is the second.
+// (History: one LDS float atomicAdd per (tile, run) was 6.2 us at T and not reproducible; merging inside
+//  the tile kernel -- the last workgroup of a query tile does it -- was tried and dropped: one CU's ~450
+//  dependent-latency loads take 25 us, and agent-scope release/acquire fences cost ~40 us per launch on
+//  the 8-XCD part.  A query-blocked workspace with packed run rows was measured too: no change.)
+constexpr int MTHREADS = 512, MENT = 4;
+template <bool PARTIAL, int MQ, bool TABLES>
+__global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
     const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
     const int* __restrict__ ws_lab, const float* __restrict__ ws_num, float* __restrict__ out,
     float* __restrict__ lse, float* __restrict__ m_out, float* __restrict__ den_out,
     float* __restrict__ num_out, int B, int C, int n_stiles, int BS) {
     constexpr int ML = MTHREADS / MQ;
-    constexpr int MNS = MQ + 1;  // row stride of num[class][query] in LDS: odd, the output phase reads columns
+    constexpr int MNS = MQ + 1;  // row stride of res[class][query] in LDS: odd, the output phase reads columns
+    constexpr float LN2 = 0.693147180559945309417f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // [ML][MQ]
-    float* inv_s = red + ML * MQ;                 // [MQ]
-    float* num = inv_s + MQ;                      // [C][MQ]
+    float* Ms = red + MTHREADS;                   // [MQ]
+    float* inv_s = Ms + MQ;                       // [MQ]
+    int* cnt = reinterpret_cast<int*>(inv_s + MQ);  // [C]   entries of class c        (TABLES only, like the next four)
+    int* tlo = cnt + C;                             // [C]   first tile carrying c
+    int* thi = tlo + C;                             // [C]   last tile carrying c
+    int* ent = thi + C;                             // [C][MENT]  tile * BS + run, ascending
+    float* res = reinterpret_cast<float*>(ent + (size_t)C * MENT);  // [C][MNS]
     const int tid = threadIdx.x, bq = tid & (MQ - 1), sl = tid / MQ;
     const int b0 = blockIdx.x * MQ;
     const int b = min(b0 + bq, B - 1);  // rows past the batch repeat the last query and are never written
-    for (int x = tid; x < C * MNS; x += MTHREADS) num[x] = 0.f;
 
+    if (TABLES) {
+        for (int c = tid; c < C; c += MTHREADS) {
+            cnt[c] = 0;
+            tlo[c] = 0x7fffffff;
+            thi[c] = -1;
+        }
+    }
+    // ---- phase 1a: this thread's tiles, max
     float M = -INFINITY;
     for (int t = sl; t < n_stiles; t += ML) M = fmaxf(M, ws_m[(size_t)t * B + b]);
     red[sl * MQ + bq] = M;
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < ML; ++k) M = fmaxf(M, red[k * MQ + bq]);
-    __syncthreads();
-
-    // The walk is latency-bound (a tile's run count gates its label and sum reads), so MU tiles are in
-    // flight per thread and the first two runs of each are read before the count is known: rows past
-    // nrun are allocated but never written, so what comes back is selected away, never used in arithmetic.
-    float den = 0.f;
-    for (int t0 = sl; t0 < n_stiles; t0 += ML * MU) {
-        float mm[MU], dd[MU], n0[MU], n1[MU];
-        int nr[MU], y0[MU], y1[MU], tt[MU];
-#pragma unroll
-        for (int u = 0; u < MU; ++u) {
-            const int t = t0 + u * ML;
-            const bool ok = t < n_stiles;
-            const int tc = ok ? t : t0;
-            tt[u] = tc;
-            mm[u] = ws_m[(size_t)tc * B + b];
-            dd[u] = ws_den[(size_t)tc * B + b];
-            nr[u] = ok ? ws_nrun[tc] : -1;
-            y0[u] = ws_lab[(size_t)tc * BS];
-            y1[u] = ws_lab[(size_t)tc * BS + 1];
-            n0[u] = ws_num[((size_t)tc * BS) * B + b];
-            n1[u] = ws_num[((size_t)tc * BS + 1) * B + b];
-        }
-#pragma unroll
-        for (int u = 0; u < MU; ++u) {
-            if (nr[u] < 0) continue;
-            const float f = __builtin_amdgcn_exp2f(mm[u] - M);
-            den += dd[u] * f;
-            if (nr[u] > 0 && y0[u] >= 0) atomicAdd(&num[y0[u] * MNS + bq], n0[u] * f);
-            if (nr[u] > 1 && y1[u] >= 0) atomicAdd(&num[y1[u] * MNS + bq], n1[u] * f);
-            for (int r = 2; r < nr[u]; ++r) {
-                const int y = ws_lab[(size_t)tt[u] * BS + r];
-                if (y >= 0) atomicAdd(&num[y * MNS + bq], ws_num[((size_t)tt[u] * BS + r) * B + b] * f);
+    // ---- phase 0: class tables.  The first three run labels of a tile are read before its run count is
+    // known (rows past nrun are allocated, never written: what comes back is selected away).
+    if (TABLES) {
+        for (int t = tid; t < n_stiles; t += MTHREADS) {
+            const int nr = ws_nrun[t];
+            const int* lt = ws_lab + (size_t)t * BS;
+            const int l3[3] = {lt[0], lt[1], lt[2]};
+            for (int r = 0; r < nr; ++r) {
+                const int y = r < 3 ? l3[r] : lt[r];
+                if (y < 0) continue;  // padding rows / labels outside [0, C)
+                atomicMin(&tlo[y], t);
+                atomicMax(&thi[y], t);
+                const int slot = atomicAdd(&cnt[y], 1);
+                if (slot < MENT) ent[y * MENT + slot] = t * BS + r;
             }
         }
     }
-    red[sl * MQ + bq] = den;
-    __syncthreads();  // also orders the LDS adds before the reads below
-    den = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < ML; ++k) M = fmaxf(M, red[k * MQ + bq]);
+    __syncthreads();
+    if (TABLES) {  // slots were handed out in arrival order: put each class's entries in bank order
+        for (int c = tid; c < C; c += MTHREADS) {
+            const int n = cnt[c];
+            if (n > 1 && n <= MENT) {
+                int e[MENT];
 #pragma unroll
+                for (int k = 0; k < MENT; ++k) e[k] = k < n ? ent[c * MENT + k] : 0x7fffffff;
+#pragma unroll
+                for (int i = 1; i < MENT; ++i)
+#pragma unroll
+                    for (int j = MENT - 1; j >= i; --j)
+                        if (e[j] < e[j - 1]) { const int x = e[j]; e[j] = e[j - 1]; e[j - 1] = x; }
+#pragma unroll
+                for (int k = 0; k < MENT; ++k)
+                    if (k < n) ent[c * MENT + k] = e[k];
+            }
+        }
+    }
+    // ---- phase 1b: den
+    float den = 0.f;
+    for (int t = sl; t < n_stiles; t += ML)
+        den += ws_den[(size_t)t * B + b] * __builtin_amdgcn_exp2f(ws_m[(size_t)t * B + b] - M);
+    red[sl * MQ + bq] = den;
+    if (sl == 0) Ms[bq] = M;
+    __syncthreads();
+    den = 0.f;
+#pragma unroll 4
     for (int k = 0; k < ML; ++k) den += red[k * MQ + bq];
+    if (sl == 0) inv_s[bq] = 1.f / den;
     const int nq = min(MQ, B - b0);
-    if (PARTIAL) {
-        if (sl == 0 && bq < nq) {
-            m_out[b] = M * 0.693147180559945309417f;  // back to natural units
+    if (sl == 0 && bq < nq) {
+        if (PARTIAL) {
+            m_out[b] = M * LN2;  // back to natural units
             den_out[b] = den;
+        } else if (lse) {
+            lse[b] = M * LN2 + logf(den);
         }
-        for (int x = tid; x < nq * C; x += MTHREADS) {
-            const int qq = x / C, c = x - qq * C;
-            num_out[(size_t)(b0 + qq) * C + c] = num[c * MNS + qq];
+    }
+    // ---- phase 2: class sums
+    for (int x = tid; x < C * MQ; x += MTHREADS) {
+        const int c = x / MQ, q = x - c * MQ;
+        const int bb = min(b0 + q, B - 1);
+        const float Mq = Ms[q];
+        float acc = 0.f;
+        const int n = TABLES ? cnt[c] : MENT + 1;
+        if (n <= MENT) {
+            int e[MENT];
+            float v[MENT], mt[MENT];
+#pragma unroll
+            for (int k = 0; k < MENT; ++k) e[k] = ent[c * MENT + (k < n ? k : 0)];
+#pragma unroll
+            for (int k = 0; k < MENT; ++k) {
+                if (k < n) {
+                    v[k] = ws_num[(size_t)e[k] * B + bb];
+                    mt[k] = ws_m[(size_t)(e[k] / BS) * B + bb];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MENT; ++k)
+                if (k < n) acc += v[k] * __builtin_amdgcn_exp2f(mt[k] - Mq);
+        } else {
+            const int t0 = TABLES ? tlo[c] : 0, t1 = TABLES ? thi[c] : n_stiles - 1;
+            for (int t = t0; t <= t1; ++t) {
+                const int nr = ws_nrun[t];
+                const float f = __builtin_amdgcn_exp2f(ws_m[(size_t)t * B + bb] - Mq);
+                const int* lt = ws_lab + (size_t)t * BS;
+                for (int r = 0; r < nr; ++r)
+                    if (lt[r] == c) acc += ws_num[((size_t)t * BS + r) * B + bb] * f;
+            }
         }
-    } else {
-        if (sl == 0) {
-            inv_s[bq] = 1.f / den;
-            if (lse && bq < nq) lse[b] = M * 0.693147180559945309417f + logf(den);
+        if (TABLES) {
+            res[c * MNS + q] = acc;
+        } else if (q < nq) {  // no room for the staging table: strided stores
+            if (PARTIAL) num_out[(size_t)bb * C + c] = acc;
+            else out[(size_t)bb * C + c] = logf(acc * inv_s[q] + NW_LOG_EPS);
         }
-        __syncthreads();
-        for (int x = tid; x < nq * C; x += MTHREADS) {
-            const int qq = x / C, c = x - qq * C;
-            out[(size_t)(b0 + qq) * C + c] = logf(num[c * MNS + qq] * inv_s[qq] + NW_LOG_EPS);
-        }
+    }
+    if (!TABLES) return;
+    __syncthreads();
+    for (int x = tid; x < nq * C; x += MTHREADS) {
+        const int qq = x / C, c = x - qq * C;
+        if (PARTIAL) num_out[(size_t)(b0 + qq) * C + c] = res[c * MNS + qq];
+        else out[(size_t)(b0 + qq) * C + c] = logf(res[c * MNS + qq] * inv_s[qq] + NW_LOG_EPS);
     }
 }
 
@@ -341,27 +355,35 @@ int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_
 
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st) {
-    // 32 queries x 16 tile lanes per workgroup when a query has few tiles (a shard of the bank), else 16 x 32
-    const int mq = (n_stiles >= 128 || ((size_t)MTHREADS + 32 + (size_t)C * 33) * sizeof(float) > 64 * 1024) ? 16 : 32;
-    const size_t blds = ((size_t)MTHREADS + mq + (size_t)C * (mq + 1)) * sizeof(float);
-    if (B >= 512 && blds <= 64 * 1024 && !env_flag("NW_MERGE_PER_QUERY")) {
-        const int grid = (B + mq - 1) / mq;
-#define NW_MERGE_BLK(P_, Q_)                                                                                          \
-    hipLaunchKernelGGL((nw_merge_runs_blk_kernel<P_, Q_>), dim3(grid), dim3(MTHREADS), blds, st, ws.m, ws.den, ws.nrun, \
-                       ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS)
-        if (out) { if (mq == 16) NW_MERGE_BLK(false, 16); else NW_MERGE_BLK(false, 32); }
-        else { if (mq == 16) NW_MERGE_BLK(true, 16); else NW_MERGE_BLK(true, 32); }
-#undef NW_MERGE_BLK
-        NW_CHECK_LAUNCH();
-        return NW_OK;
+    // LDS: reduction scratch + per-class tables (count, first / last tile, MENT entries) + res[class][query]
+    auto lds_bytes = [&](int mq, bool tables) {
+        return ((size_t)MTHREADS + 2 * mq + (tables ? (size_t)C * (3 + MENT + mq + 1) : 0)) * sizeof(float);
+    };
+    const size_t cap = 150 * 1024;
+    // 32 queries x 16 tile lanes per workgroup when a query has few tiles (a shard of the bank), else 16 x 32;
+    // below 512 queries one workgroup per query (T: 256 workgroups, one per CU)
+    int mq = 1;
+    if (B >= 512 && !env_flag("NW_MERGE_PER_QUERY")) {
+        mq = n_stiles >= 128 ? 16 : 32;
+        if (lds_bytes(mq, true) > cap) mq = 16;
+        if (lds_bytes(mq, true) > cap) mq = 1;
     }
-    const size_t mlds = (8 + (size_t)C) * sizeof(float);
-    if (out)
-        hipLaunchKernelGGL(nw_merge_runs_kernel<false>, dim3(B), dim3(256), mlds, st, ws.m, ws.den, ws.nrun,
-                           ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS);
-    else
-        hipLaunchKernelGGL(nw_merge_runs_kernel<true>, dim3(B), dim3(256), mlds, st, ws.m, ws.den, ws.nrun,
-                           ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS);
+    const bool tables = lds_bytes(mq, true) <= cap;
+    const size_t lds = lds_bytes(mq, tables);
+    const int grid = (B + mq - 1) / mq;
+#define NW_MERGE(P_, Q_, T_)                                                                                       \
+    hipLaunchKernelGGL((nw_merge_runs_kernel<P_, Q_, T_>), dim3(grid), dim3(MTHREADS), lds, st, ws.m, ws.den, ws.nrun, \
+                       ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS)
+    if (!tables) {
+        if (out) NW_MERGE(false, 1, false); else NW_MERGE(true, 1, false);
+    } else if (mq == 1) {
+        if (out) NW_MERGE(false, 1, true); else NW_MERGE(true, 1, true);
+    } else if (mq == 16) {
+        if (out) NW_MERGE(false, 16, true); else NW_MERGE(true, 16, true);
+    } else {
+        if (out) NW_MERGE(false, 32, true); else NW_MERGE(true, 32, true);
+    }
+#undef NW_MERGE
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

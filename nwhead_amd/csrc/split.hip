@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void nw_split_rows_kernel(const float* __restr
     if (mx > 0.f && mx < INFINITY) {
         frexpf(mx, &e);   // mx = f * 2^e, f in [0.5, 1)
         e = 14 - e;       // mx * 2^e in [2^13, 2^14)
+        if (e > 126) e = 126;  // a row of subnormal magnitudes (max < 2^-112): 2^e must stay finite and 2^-e normal
     }
     const float up = ldexpf(1.f, e);
     if (lane == 0) {

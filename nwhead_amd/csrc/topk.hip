@@ -25,6 +25,7 @@ constexpr int TK_MAXK = 1024;
 
 __device__ __forceinline__ unsigned ordered_bits(float f) {  // larger float <=> larger uint; NaN on top
     unsigned b = __float_as_uint(f);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // every NaN, either sign: one image above +inf (torch's order)
     if ((b << 1) == 0) b = 0;  // -0.0 == +0.0: one image, so that their order is the index order
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }

@@ -80,10 +80,18 @@ class NWNet(nn.Module):
         object.__setattr__(self, '_fold_cl', bool(channels_last))
         object.__setattr__(self, '_folded', None)
 
+    def _weights_signature(self):
+        """Changes whenever a parameter or buffer of the featurizer is written in place (optimizer step,
+        load_state_dict, BatchNorm statistics) or replaced: the folded inference copy is rebuilt then."""
+        ts = list(self.featurizer.parameters()) + list(self.featurizer.buffers())
+        return (len(ts), sum(t._version for t in ts), sum(t.data_ptr() & 0xffff for t in ts))
+
     def _eval_featurizer(self, rebuild=False):
         if not getattr(self, '_fold_bn', False) or self.featurizer.training:
             return self.featurizer
-        if rebuild or getattr(self, '_folded', None) is None:
+        sig = self._weights_signature()
+        if rebuild or getattr(self, '_folded', None) is None or getattr(self, '_folded_sig', None) != sig:
+            object.__setattr__(self, '_folded_sig', sig)
             from ..model import fold_batchnorm
             from ..model.backbones import ScaleShiftReLU
             folded = fold_batchnorm(self.featurizer)
@@ -95,9 +103,15 @@ class NWNet(nn.Module):
         return self._folded
 
     def train(self, mode=True):
-        if mode and getattr(self, '_fold_bn', False):
-            object.__setattr__(self, '_folded', None)   # the weights are about to change
+        if mode:                                         # the weights are about to change
+            object.__setattr__(self, '_folded', None)
+            self.sharded_bank = None                     # a shard featurised with the old weights must not serve 'full'
         return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        object.__setattr__(self, '_folded', None)
+        self.sharded_bank = None
+        return super().load_state_dict(*args, **kwargs)
 
     # ------------------------------------------------------------------ evaluation bank
     def process_support_eval(self, support_dataset):
@@ -125,6 +139,7 @@ class NWNet(nn.Module):
     def precompute(self):
         assert not self.featurizer.training
         info = self._compute_all_support_feats()
+        self.sharded_bank = None                     # predict('full') serves the bank built here
         self.full_feat, self.full_y = info[0], info[1]
         self.full_cache = ops.SplitBank(self.full_feat, labels=self.full_y)   # norms + split-fp16 rows for predict('full')
         self.full_norm2 = self.full_cache.norm2
@@ -177,7 +192,11 @@ class NWNet(nn.Module):
             probs = sum(self.nwhead(qfeat, f.to(x.device), y.to(x.device)).exp() for f, y in zip(sfeat, sy))
             out = torch.log(probs / len(sfeat))
         elif mode == 'full':
-            out = self.nwhead(qfeat, sfeat.to(x.device), sy.to(x.device), support_cache=self.full_cache)
+            sfeat, sy = sfeat.to(x.device), sy.to(x.device)
+            cache = getattr(self, 'full_cache', None)
+            if cache is None or not cache.matches(sfeat):   # the bank was replaced or updated since precompute()
+                cache = self.full_cache = ops.SplitBank(sfeat, labels=sy)
+            out = self.nwhead(qfeat, sfeat, sy, support_cache=cache)
         else:
             out = self.nwhead(qfeat, sfeat.to(x.device), sy.to(x.device))
         if self.return_mask:

@@ -116,6 +116,14 @@ class SplitBank:
         _need_hip(s, labels)
         lib = _lib.load()
         sc = _f32c(s)
+        # the tensor this bank was prepared from: identity, shape and in-place version (see matches())
+        self._src = (s.data_ptr(), tuple(s.shape), s._version)
+        self.label_max = None
+        if labels is not None and labels.numel():
+            lo, hi = (int(v) for v in torch.aminmax(labels.detach()))
+            if lo < 0:
+                raise ValueError("support labels must be non-negative class indices (F.one_hot, nw.py:276, raises too)")
+            self.label_max = hi                # nw_head refuses n_classes <= label_max, like F.one_hot
         self.sorted_rows = self.sorted_labels = None
         if labels is not None and sc.dim() == 2 and labels.dim() == 1 and labels.numel() > 1:
             lab = labels.detach().to(torch.int64)
@@ -136,6 +144,10 @@ class SplitBank:
                                                    N, d, _stream(sc)), "nw_split_rows_f16x2")
         else:
             self.norm2 = row_norm2(sc)
+
+    def matches(self, s):
+        """True when `s` is the very tensor (storage, shape, no in-place update since) this bank was prepared from."""
+        return (s.data_ptr(), tuple(s.shape), s._version) == self._src
 
 
 def _resolve_sorted_bank(s, sy, cache, per_position_outputs=False):
@@ -232,8 +244,13 @@ def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weig
         if s.dim() != 2 or support_norm2.shape != (s.shape[0],):
             raise ValueError("support_norm2 must be (N,) for an (N,d) support")
         support_norm2 = _f32c(support_norm2)
-    if support_cache is not None and (s.dim() != 2 or tuple(s.shape) != support_cache.shape):
-        raise ValueError("support_cache was built for a different support")
+    if support_cache is not None and (s.dim() != 2 or not support_cache.matches(s)):
+        raise ValueError("support_cache was prepared from another support tensor (or the tensor was modified in place "
+                         "since): build a new ops.SplitBank(s) -- the split rows and norms it holds are those of the "
+                         "tensor it was built from")
+    if support_cache is not None and support_cache.label_max is not None and support_cache.label_max >= int(n_classes):
+        raise ValueError(f"support label {support_cache.label_max} is outside [0, n_classes={int(n_classes)}) "
+                         "(the reference's F.one_hot, nw.py:276, raises)")
     s, sy, support_cache = _resolve_sorted_bank(s, sy, support_cache,
                                                 return_weights or (torch.is_grad_enabled() and s.requires_grad))
     needs_grad = torch.is_grad_enabled() and (q.requires_grad or s.requires_grad or

@@ -89,42 +89,51 @@ class ShardedBank:
         return self.predict_stream([q], bucket=1)[0]
 
     def predict_stream(self, batches, bucket=8):
-        """Pipelined prediction of a list of equally-shaped query batches.
+        """Pipelined prediction of a list of (B_i, d) query batches (B_i may differ: the ragged tail of a
+        loader is an ordinary case).
 
         Every `bucket` consecutive batches are coalesced into ONE launch of the partial forward (the
-        kernel tiles over queries anyway, and one launch over bucket*B queries amortises the launch,
+        kernel tiles over queries anyway, and one launch over the bucket's rows amortises the launch,
         the tile prologue and the merge), ONE packed buffer [m | den | num] and ONE all-gather; the
         merge of bucket i runs after the kernels of bucket i+1 have been queued, so the collective
         flies under them.  Outputs are returned per batch, in order."""
         if not batches:
             return []
-        B = batches[0].shape[0]
+        d = batches[0].shape[-1]
+        for k, qb in enumerate(batches):
+            if qb.dim() != 2 or qb.shape[1] != d:
+                raise ValueError(f"predict_stream: batch {k} has shape {tuple(qb.shape)}, expected (B, {d})")
         dev, G = self.feat.device, self.world
         outs, pending = [], None
         ring = {}
 
+        def split(out, sizes):
+            pos = 0
+            for n in sizes:
+                outs.append(out[pos:pos + n])
+                pos += n
+
         def finish(p):
-            work, gathered, nb = p
+            work, gathered, sizes = p
             if work is not None:
                 work.wait()
-            out = self._merge(gathered, nb * B)            # (nb*B, C)
-            outs.extend(out[k * B:(k + 1) * B] for k in range(nb))
+            split(self._merge(gathered, sum(sizes)), sizes)          # (rows of the bucket, C)
 
         for n_bucket, i0 in enumerate(range(0, len(batches), bucket)):
             chunk = batches[i0:i0 + bucket]
-            nb = len(chunk)
-            Bq = nb * B
+            sizes = [int(c.shape[0]) for c in chunk]
+            Bq = sum(sizes)
             L = self.row_len(Bq)
-            key = (n_bucket % 3, nb)
+            key = (n_bucket % 3, Bq)
             if key not in ring:
                 ring[key] = (torch.empty(L, dtype=torch.float32, device=dev),
                              torch.empty(G, L, dtype=torch.float32, device=dev))
             packed, gathered = ring[key]
-            qcat = chunk[0] if nb == 1 else _coalesce(chunk)
+            qcat = chunk[0] if len(chunk) == 1 else _coalesce(chunk)
             if G == 1 and self._partial == self._hip_partial:
                 # one rank: nothing to exchange, the forward finalises in place
-                out = ops.nw_head(qcat, self.feat, self.y, self.C, self.kind, self.logit_scale, support_cache=self.cache)
-                outs.extend(out[k * B:(k + 1) * B] for k in range(nb))
+                split(ops.nw_head(qcat, self.feat, self.y, self.C, self.kind, self.logit_scale, support_cache=self.cache),
+                      sizes)
                 continue
             self._partial(packed, qcat.detach().to(torch.float32).contiguous())
             if G > 1:
@@ -133,7 +142,7 @@ class ShardedBank:
                 gathered, work = packed.view(1, L), None
             if pending is not None:
                 finish(pending)
-            pending = (work, gathered, nb)
+            pending = (work, gathered, sizes)
         if pending is not None:
             finish(pending)
         return outs

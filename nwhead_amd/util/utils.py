@@ -33,11 +33,14 @@ def save_checkpoint(epoch, network, optimizer, model_folder, scheduler=None, is_
     return path
 
 
-def load_checkpoint(network, path, optimizer=None, scheduler=None, verbose=True):
-    """Restores what is given; returns the checkpoint dictionary (epoch, extras) for the caller."""
+def load_checkpoint(network, path, optimizer=None, scheduler=None, verbose=True, trust_pickle=False):
+    """Restores what is given; returns the checkpoint dictionary (epoch, extras) for the caller.
+    Checkpoints are read with torch's weights-only unpickler (tensors, numbers, strings, containers: all that
+    save_checkpoint writes); trust_pickle=True opts into the full unpickler for files from a trusted source
+    that carry other objects."""
     if verbose:
         print("Loading checkpoint from", path)
-    ckpt = torch.load(path, map_location=torch.device("cpu"), weights_only=False)
+    ckpt = torch.load(path, map_location=torch.device("cpu"), weights_only=not trust_pickle)
     network.load_state_dict(ckpt["network_state_dict"])
     if optimizer is not None and "optimizer" in ckpt:
         optimizer.load_state_dict(ckpt["optimizer"])
@@ -62,3 +65,32 @@ def parse_bool(v):
     if v.lower() == "false":
         return False
     raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+class ParseKwargs(argparse.Action):
+    """`--flag a=1 b=0.5 c=true d=text` -> {'a': 1, 'b': 0.5, 'c': True, 'd': 'text'} (the reference's command line
+    takes its wandb options this way, util/utils.py:87-102)."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        out = {}
+        for item in values:
+            key, text = item.split("=")
+            digits = text.replace("-", "")
+            if digits.isnumeric():
+                val = int(text)
+            elif digits.replace(".", "").isnumeric():
+                val = float(text)
+            elif text in ("True", "true"):
+                val = True
+            elif text in ("False", "false"):
+                val = False
+            else:
+                val = text
+            out[key] = val
+        setattr(namespace, self.dest, out)
+
+
+def initialize_wandb(config):
+    """Experiment logging to wandb is outside this implementation's scope: the name exists so
+    that the reference's import line resolves; calling it says so."""
+    raise NotImplementedError("wandb logging is not part of nwhead_amd (DESIGN.md section 7); run with logging off")

@@ -286,7 +286,42 @@ def g6():
     npz("g6_backbones.npz", **out)
 
 
+def g9():
+    """A11 projection (nw.py:74-79) and the CLIP kernel's doubly registered parameter (nw.py:82,85): state_dict
+    key lists and shapes of the reference's NWNet, and what forward() returns with those weights."""
+    C, shape, n = 10, (3, 4, 4), 120
+    ds = _FakeDS(n, C, shape, seed=909)
+    out = {"C": C, "ds_data": ds.data, "ds_targets": np.array(ds.targets)}
+    g = torch.Generator().manual_seed(910)
+    xq = torch.randn(6, *shape, generator=g)
+    yq = torch.randint(0, C, (6,), generator=g)
+    sx = torch.randn(30, *shape, generator=g)
+    sy = torch.arange(30) % C
+    out.update({"xq": xq, "yq": yq, "sx": sx, "sy": sy})
+    for tag, kw in (("proj", dict(feat_dim=16, proj_dim=8)),
+                    ("clip", dict(kernel_type="clip")),
+                    ("projclip", dict(feat_dim=16, proj_dim=8, kernel_type="clip"))):
+        torch.manual_seed(3)
+        feat = nn.Sequential(nn.Flatten(), nn.Linear(48, 16))
+        net = NWNet(feat, C, support_dataset=ds, n_shot=2, n_shot_full=5, device="cpu", **kw)
+        sd = net.state_dict()
+        out[f"{tag}_keys"] = np.array(list(sd.keys()))
+        out[f"{tag}_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        out[f"{tag}_param_names"] = np.array([k for k, _ in net.named_parameters()])
+        for k, v in sd.items():
+            out[f"{tag}_sd_{k}"] = v.detach().clone()
+        net.eval()
+        with torch.no_grad():
+            out[f"{tag}_fwd"] = net(xq, yq, support_data=(sx, sy, None))
+            net.precompute()
+            out[f"{tag}_full_feat_shape"] = np.array(net.full_feat.shape)
+            out[f"{tag}_pred_full"] = net.predict(xq, "full")
+    npz("g9_state_dict.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
-        fn()
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+        if not only or fn.__name__ in only:
+            fn()

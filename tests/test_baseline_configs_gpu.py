@@ -1,0 +1,225 @@
+"""GPU parity AT THE WORKLOADS BASELINE.json NAMES (configs[2] = K3, configs[3] = K4), through the C ABI.
+
+K3: precompute()+predict('full'), N_support = 50000, d = 512, C = 200 class-sorted, sharded 8 ways.
+    The fp64 oracle cannot hold the (B, N, d) cube of a whole batch, so a 32-row slice of the queries is
+    held to it (rows are independent), and the whole batch goes through the size-independent properties:
+    rows sum to 1 + C*1e-12, 8-shard partials + merge with class windows == unsharded, run twice == bit-equal.
+K4: DenseNet-121 + NW head training step, n_way = 10, B = 32: the head at (B=32, N=10, d=1024, C=10) forward and
+    backward against fp64 autograd of the oracle (N <= 25: torch's direct-difference regime), then one whole
+    step -- NWNet.forward(support_data=...) -> NLL -> backward through DenseNet-121 @224 -- against CPU autograd of
+    the same network with the oracle head.
+Tolerance: BASELINE north_star, 1e-5 relative on the log-probabilities (+ absolute floor 3e-5); gradients 1e-4 of
+their own scale.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 3e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nwhead_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import nw_oracle
+    return nw_oracle
+
+
+@pytest.fixture(scope="module")
+def k3(dev, ops):
+    g = torch.Generator().manual_seed(0)
+    N, d, C = 50000, 512, 200
+    s = torch.randn(N, d, generator=g)
+    sy = (torch.arange(N) % C).sort().values          # the bank of precompute(): class-sorted, balanced
+    q = torch.randn(4096, d, generator=g)
+    sd, syd = s.to(dev), sy.to(dev)
+    return dict(q=q, s=s, sy=sy, qd=q.to(dev), sd=sd, syd=syd, C=C, bank=ops.SplitBank(sd, labels=syd))
+
+
+@pytest.mark.parametrize("B", [256, 4096])
+def test_k3_full_bank_slice_vs_fp64_oracle(dev, ops, O, k3, B):
+    C = k3["C"]
+    out = ops.nw_head(k3["qd"][:B], k3["sd"], k3["syd"], C, support_cache=k3["bank"])
+    assert out.shape == (B, C) and torch.isfinite(out).all()
+    rows = torch.arange(0, B, max(1, B // 32))[:32]            # 32 rows spread over the batch
+    ref = O.nw_head_f64(k3["q"][rows], k3["s"], k3["sy"], C)
+    np.testing.assert_allclose(out[rows.to(dev)].cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+    p = out.exp().sum(-1).cpu()
+    assert torch.allclose(p, torch.full_like(p, 1 + C * 1e-12), atol=2e-5)      # rows sum to 1 + C*eps
+    # the fp32 path (no prepared bank) gives the same answer
+    if B == 256:
+        np.testing.assert_allclose(ops.nw_head(k3["qd"][:B], k3["sd"], k3["syd"], C).cpu().numpy(), out.cpu().numpy(),
+                                   rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("B", [256, 4096])
+def test_k3_eight_shards_with_class_windows_equal_unsharded(dev, ops, k3, B):
+    """SURVEY 8e at BASELINE's size: rank g's partial forward over rows [lo, hi) of the class-sorted bank with labels
+    shifted to its class window, one packed row per rank, nw_merge_finalize scattering the windows back."""
+    from nwhead_amd.sharded import shard_bounds
+    C, G, N = k3["C"], 8, k3["s"].shape[0]
+    q = k3["qd"][:B]
+    whole = ops.nw_head(q, k3["sd"], k3["syd"], C, support_cache=k3["bank"])
+    bounds = [shard_bounds(N, G, r) for r in range(G)]
+    los = [int(k3["sy"][a:b].min()) for a, b in bounds]
+    CL = max(int(k3["sy"][a:b].max()) - lo + 1 for (a, b), lo in zip(bounds, los))
+    assert CL == 25                                              # 200 classes of 250 rows over 8 ranks
+    rows = []
+    for (a, b), lo in zip(bounds, los):
+        shard = k3["sd"][a:b].contiguous()
+        rows.append(ops.nw_partials(q, shard, k3["syd"][a:b] - lo, CL, support_cache=ops.SplitBank(shard)).view(-1))
+    out = ops.nw_merge(torch.stack(rows), B, C, class_lo=torch.tensor(los, dtype=torch.int64, device=dev), c_local=CL)
+    np.testing.assert_allclose(out.cpu().numpy(), whole.cpu().numpy(), rtol=RTOL, atol=ATOL)
+    # full-width partials (no class windows) merge to the same
+    rows = [ops.nw_partials(q, k3["sd"][a:b].contiguous(), k3["syd"][a:b], C).view(-1) for a, b in bounds]
+    np.testing.assert_allclose(ops.nw_merge(torch.stack(rows), B, C).cpu().numpy(), whole.cpu().numpy(), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("B", [256, 4096])
+def test_k3_forward_is_bit_reproducible(dev, ops, k3, B):
+    """Same inputs, two launches: identical bits (the merge sums in a fixed order; no float atomics)."""
+    a = ops.nw_head(k3["qd"][:B], k3["sd"], k3["syd"], k3["C"], support_cache=k3["bank"]).clone()
+    junk = torch.randn(1 << 22, device=dev).sum()              # other work in between
+    b = ops.nw_head(k3["qd"][:B], k3["sd"], k3["syd"], k3["C"], support_cache=k3["bank"])
+    assert torch.equal(a, b), (a - b).abs().max()
+    pa = ops.nw_partials(k3["qd"][:B], k3["sd"], k3["syd"], k3["C"], support_cache=k3["bank"]).clone()
+    pb = ops.nw_partials(k3["qd"][:B], k3["sd"], k3["syd"], k3["C"], support_cache=k3["bank"])
+    assert torch.equal(pa, pb)
+    del junk
+
+
+def test_reproducible_with_unsorted_labels_and_small_shapes(dev, ops):
+    """The run merge with many runs per tile (unsorted labels) and the two-kernel fallback (N <= 25, weights)."""
+    g = torch.Generator().manual_seed(3)
+    for B, N, d, C in ((300, 5000, 64, 37), (64, 1000, 512, 200), (8, 20, 32, 5), (700, 3000, 36, 1000)):
+        q, s = torch.randn(B, d, generator=g).to(dev), torch.randn(N, d, generator=g).to(dev)
+        sy = torch.randint(0, C, (N,), generator=g).to(dev)
+        a = ops.nw_head(q, s, sy, C).clone()
+        assert torch.equal(a, ops.nw_head(q, s, sy, C))
+        a, wa = ops.nw_head(q, s, sy, C, return_weights=True)
+        a, wa = a.clone(), wa.clone()
+        b, wb = ops.nw_head(q, s, sy, C, return_weights=True)
+        assert torch.equal(a, b) and torch.equal(wa, wb)
+
+
+# ------------------------------------------------------------------ K4
+@pytest.mark.parametrize("kind", ["euclidean", "cosine", "clip"])
+@pytest.mark.parametrize("n_shot", [1, 4])
+def test_k4_head_shape_forward_backward(dev, ops, O, kind, n_shot):
+    """(B=32, N=10*n_shot, d=1024, C=10): DenseNet-121's feature width; N=10 sits in the direct-difference regime."""
+    from test_fuzz_gpu import LS0, _clip_head_f64
+    B, d, C = 32, 1024, 10
+    N = C * n_shot
+    g = torch.Generator().manual_seed(4 + n_shot)
+    q0 = torch.rand(B, d, generator=g) * 2                     # post-ReLU, pooled features: non-negative, common mean
+    s0 = torch.rand(N, d, generator=g) * 2
+    sy = torch.arange(C).repeat_interleave(n_shot)
+    t = torch.randint(0, C, (B,), generator=g)
+    q64, s64 = q0.double().requires_grad_(True), s0.double().requires_grad_(True)
+    ls64 = torch.tensor(LS0, dtype=torch.float64, requires_grad=True)
+    ref = O.nw_head_f64(q64, s64, sy, C, kind, ls64) if kind != "clip" else _clip_head_f64(q64, s64, sy, C, ls64)
+    F.nll_loss(ref, t).backward()
+    q, s = q0.to(dev).requires_grad_(True), s0.to(dev).requires_grad_(True)
+    ls = torch.tensor(LS0, device=dev, requires_grad=True) if kind == "clip" else None
+    out = ops.nw_head(q, s, sy.to(dev), C, kind, ls)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=RTOL, atol=ATOL)
+    F.nll_loss(out, t.to(dev)).backward()
+    for got, want in ((q.grad, q64.grad), (s.grad, s64.grad)):
+        want = want.numpy()
+        scale = max(float(np.abs(want).max()), 1e-3)
+        np.testing.assert_allclose(got.cpu().numpy() / scale, want / scale, rtol=1e-4, atol=1e-4)
+    if kind == "clip":
+        np.testing.assert_allclose(ls.grad.item(), ls64.grad.item(), rtol=1e-4, atol=1e-6)
+    # the reference's own fp32 op sequence (cdist direct form for N <= 25) agrees too
+    if kind == "euclidean":
+        np.testing.assert_allclose(out.detach().cpu().numpy(), O.nw_head_f32(q0, s0, sy, C).numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_k4_densenet121_train_step_vs_cpu_autograd(dev, O):
+    """BASELINE configs[3]: DenseNet-121 @224 + NW head, n_way = 10, B = 32 queries, one support image per class
+    (through forward(x, y, support_data=...)).  The device step (MIOpen convolutions, the hand-written
+    BatchNorm+ReLU kernels, the HIP head forward and backward) against the same network on the host with the
+    oracle head: loss, log-probabilities and the gradients at both ends of the network."""
+    from nwhead_amd.model import load_model
+    from nwhead_amd.nwhead.nw import NWNet
+    torch.manual_seed(0)
+    net = NWNet(load_model("densenet121"), 10, device="cuda:0")
+    ref_feat = load_model("densenet121")
+    ref_feat.load_state_dict(net.featurizer.state_dict())
+    net = net.to(dev).train()
+    ref_feat.train()
+    g = torch.Generator().manual_seed(1)
+    protos = torch.randn(10, 3, 224, 224, generator=g)
+    sy = torch.arange(10)
+    sx = protos + 0.3 * torch.randn(10, 3, 224, 224, generator=g)
+    y = torch.randint(0, 10, (32,), generator=g)
+    x = protos[y] + 0.3 * torch.randn(32, 3, 224, 224, generator=g)
+    out = net(x.to(dev), y.to(dev), support_data=(sx, sy, None))
+    assert out.shape == (32, 10)
+    loss = F.nll_loss(out, y.to(dev))
+    loss.backward()
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    feats = ref_feat(torch.cat((x, sx), 0))                       # joint pass: shared BN statistics (nw.py:182-184)
+    assert feats.shape == (42, 1024)
+    out_ref = O.nw_head_f32(feats[:32], feats[32:], sy, 10)
+    loss_ref = F.nll_loss(out_ref, y)
+    loss_ref.backward()
+    # 120 layers of fp32 convolutions in two different summation orders: the features agree to ~1e-5 relative,
+    # the log-probabilities to ~1e-3 absolute; the head itself is pinned tightly by the test above
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=5e-3, atol=5e-3)
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * max(1.0, abs(loss_ref.item()))
+    for name in ("features.conv0.weight", "features.denseblock4.denselayer16.conv2.weight", "features.norm5.weight"):
+        g_gpu = dict(net.featurizer.named_parameters())[name].grad.cpu().flatten()
+        g_ref = dict(ref_feat.named_parameters())[name].grad.flatten()
+        cos = F.cosine_similarity(g_gpu, g_ref, dim=0).item()
+        assert cos > 0.995, (name, cos)
+        np.testing.assert_allclose(g_gpu.norm().item(), g_ref.norm().item(), rtol=3e-2, err_msg=name)
+    # running statistics were updated by the fused kernels exactly once
+    assert int(net.featurizer.features.norm0.num_batches_tracked) == 1
+    np.testing.assert_allclose(net.featurizer.features.norm0.running_mean.cpu().numpy(),
+                               ref_feat.features.norm0.running_mean.numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------ G6 on the device
+@pytest.mark.parametrize("name", ["resnet18", "CIFAR_ResNet18", "densenet121", "CIFAR_DenseNet121"])
+def test_g6_backbones_on_device(dev, name):
+    """Fixture G6 (reference modules, procedural weights) against the DEVICE run of our definitions: eval mode
+    (concat-free slabs, MIOpen), the folded inference copy (conv+BN folded, HIP scale-shift-ReLU), training mode
+    (hand-written BatchNorm+ReLU kernels: batch statistics, running statistics)."""
+    from conftest import T, load_golden
+    from procedural import fill_procedural
+    from nwhead_amd.model import fold_batchnorm, load_model
+    g = load_golden("g6_backbones.npz")
+    net = fill_procedural(load_model(name)).to(dev)
+    x = T(g[f"{name}_x"]).to(dev)
+    # fp32 convolutions on the device sum in another order than the host's: tolerance 2e-4 of the feature scale
+    scale = float(np.abs(g[f"{name}_eval"]).max())
+    with torch.no_grad():
+        net.eval()
+        ev = net(x)
+        np.testing.assert_allclose(ev.cpu().numpy(), g[f"{name}_eval"], rtol=2e-4, atol=2e-4 * scale)
+        folded = fold_batchnorm(net)
+        np.testing.assert_allclose(folded(x).cpu().numpy(), g[f"{name}_eval"], rtol=2e-4, atol=2e-4 * scale)
+    net.train()
+    tr = net(x.clone().requires_grad_(True)).detach()
+    tscale = float(np.abs(g[f"{name}_train"]).max())
+    # (the batch-2 DenseNet fixtures end on 2x2 maps: 8 samples per channel, ill-conditioned statistics)
+    loose = "ense" in name
+    np.testing.assert_allclose(tr.cpu().numpy(), g[f"{name}_train"], rtol=5e-3 if loose else 5e-4,
+                               atol=(5e-3 if loose else 5e-4) * tscale)
+    np.testing.assert_allclose(net.state_dict()[str(g[f"{name}_rm_name"])].cpu().numpy(), g[f"{name}_rm_after"],
+                               rtol=1e-4, atol=1e-6)

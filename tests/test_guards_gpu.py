@@ -1,0 +1,151 @@
+"""Guards and edge cases of the host layer, on the MI355X: a prepared bank is tied to the tensor it was built
+from, labels outside [0, C) are refused where the check is free, rows of subnormal magnitude split to finite
+halves, NaN scores sort like torch's, and the library's default dispatch (no NW_SPLIT_ALWAYS) is checked too."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_split_bank_is_tied_to_its_tensor(dev):
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(300, 64, generator=g).to(dev)
+    sy = (torch.arange(300) % 7).to(dev)
+    q = torch.randn(9, 64, generator=g).to(dev)
+    bank = ops.SplitBank(s, sy)
+    ops.nw_head(q, s, sy, 7, support_cache=bank)
+    with pytest.raises(ValueError, match="another support tensor"):
+        ops.nw_head(q, torch.randn_like(s), sy, 7, support_cache=bank)        # same shape, other data
+    s.mul_(2.0)                                                               # updated in place
+    with pytest.raises(ValueError, match="another support tensor"):
+        ops.nw_head(q, s, sy, 7, support_cache=bank)
+    with pytest.raises(ValueError, match="outside"):
+        ops.nw_head(q, s, sy, 5, support_cache=ops.SplitBank(s, sy))         # label 6 with 5 classes
+    with pytest.raises(ValueError, match="non-negative"):
+        ops.SplitBank(s, sy - 1)
+
+
+def test_nwnet_refreshes_stale_inference_state(dev):
+    """Weights written while the featurizer stays in eval mode (frozen-BN fine-tuning, load_state_dict) rebuild the
+    folded inference copy; a bank swapped in by hand gets a fresh SplitBank; precompute() drops an old shard."""
+    import torch.nn as nn
+    from nwhead_amd.nwhead.nw import NWNet
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self):
+            g = torch.Generator().manual_seed(1)
+            self.data, self.targets = torch.randn(60, 3, 8, 8, generator=g), (torch.arange(60) % 4).tolist()
+
+        def __len__(self):
+            return 60
+
+        def __getitem__(self, i):
+            return self.data[i], self.targets[i]
+    feat = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten())
+    net = NWNet(feat, 4, support_dataset=DS(), n_shot_full=10, device="cuda:0").to(dev).eval()
+    net.enable_bn_folding(True)
+    net.precompute()
+    x = torch.randn(5, 3, 8, 8, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        a = net.predict(x, "full")
+        with torch.no_grad():
+            net.featurizer[0].weight.mul_(1.5)                # in-place update, still in eval mode
+        b = net.predict(x, "full")
+        want = net.nwhead(net.featurizer(x), net.full_feat, net.full_y)
+    assert not torch.allclose(a, b)
+    np.testing.assert_allclose(b.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=3e-5)
+    net.sharded_bank = object()
+    net.precompute()
+    assert net.sharded_bank is None
+    net.support_eval.full_feat = net.full_feat = net.full_feat * 0.5          # replaced by hand
+    with torch.no_grad():
+        c = net.predict(x, "full")
+        want = net.nwhead(net.featurizer(x), net.full_feat, net.full_y)
+    np.testing.assert_allclose(c.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=3e-5)
+
+
+def test_split_rows_of_subnormal_magnitude(dev):
+    from nwhead_amd import ops
+    s = torch.zeros(6, 64, device=dev)
+    s[0] = 1e-40                      # subnormal
+    s[1, 3] = 1e-38
+    s[2] = 3e-39
+    s[3] = 1.0
+    s[4, 0] = float(np.float32(2.0) ** -149)
+    bank = ops.SplitBank(s)
+    assert torch.isfinite(bank.split.view(torch.float16).float()).all()
+    assert torch.isfinite(bank.scale).all() and (bank.scale > 0).all()
+    q = torch.randn(4, 64, device=dev)
+    sy = torch.arange(6, device=dev) % 2
+    s2 = torch.cat([s] * 8)           # N > 25: the fused path
+    out = ops.nw_head(q, s2, torch.cat([sy] * 8), 2, support_cache=ops.SplitBank(s2))
+    ref = ops.nw_head(q, s2, torch.cat([sy] * 8), 2)
+    assert torch.isfinite(out).all()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=3e-5)
+
+
+def test_topk_orders_nan_like_torch(dev):
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(3)
+    sc = torch.randn(4, 500, generator=g)
+    sc[0, 7] = float("nan")
+    sc[0, 300] = -float("nan")        # sign bit set
+    sc[1, :] = float("nan")
+    sc[2, 11] = float("inf")
+    sc[2, 12] = float("nan")
+    want = torch.argsort(sc, dim=-1, descending=True, stable=True)[:, :16]
+    got = ops.nw_topk(sc.to(dev), 16).cpu()
+    assert torch.equal(got, want)
+
+
+def test_default_dispatch_without_split_always():
+    """conftest pins NW_SPLIT_ALWAYS=1 for the suite; the library's own choice (fp32 matrix cores with cached norms
+    below 2e8 multiply-adds, split-fp16 above) gets a process of its own and the same parity bar."""
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from nwhead_amd import ops
+from oracle import nw_oracle as O
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+for B, N, d, C in ((64, 1000, 512, 200), (8, 64, 128, 10), (256, 10000, 512, 200), (100, 3000, 96, 17)):
+    q, s = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+    sy = (torch.arange(N) %% C).sort().values
+    sd, syd = s.to(dev), sy.to(dev)
+    out = ops.nw_head(q.to(dev), sd, syd, C)
+    outc = ops.nw_head(q.to(dev), sd, syd, C, support_cache=ops.SplitBank(sd, syd))
+    ref = O.nw_head_f64(q[:32], s, sy, C)
+    np.testing.assert_allclose(out[:32].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(outc[:32].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=3e-5)
+print("ok")
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "NW_SPLIT_ALWAYS"}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two devices (one rank per GPU)")
+def test_rccl_two_ranks_sharded_predict():
+    """The `nccl` (= RCCL) path of ShardedBank.predict_stream on two devices against the oracle: so that the first
+    multi-GPU bench run is not also the first RCCL run.  Skipped on the one-GPU test box (the gloo rehearsal on
+    one device, test_sharded_hip_world2_gpu.py, covers the same code with another backend)."""
+    worker = os.path.join(ROOT, "tests", "_rccl_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", worker],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("rccl-ok") == 2

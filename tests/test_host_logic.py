@@ -89,13 +89,26 @@ def test_dropin_import_paths():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("from nwhead.nw import NWNet, NWHead; from nwhead.kernel import get_kernel; from model import load_model; "
-            "from util.metric import support_influence, Metric, ECELoss; from util.utils import save_checkpoint, load_checkpoint; "
+            "from util.metric import support_influence, Metric, ECELoss; from util import metric; "
+            "from util.utils import parse_bool, ParseKwargs, summary, save_checkpoint, initialize_wandb; "   # train.py:16, verbatim
+            "from util.utils import load_checkpoint; "
             "import nwhead_amd.nwhead.nw as a; assert NWNet is a.NWNet; "
             "m = load_model('resnet18'); print(type(m).__name__, type(get_kernel('euclidean')).__name__)")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "dropin"), root]))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp", timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
     assert r.stdout.split()[0] == "ResNet"
+
+
+def test_parse_kwargs_action():
+    import argparse
+    from nwhead_amd.util.utils import ParseKwargs, initialize_wandb
+    p = argparse.ArgumentParser()
+    p.add_argument("--kw", nargs="*", action=ParseKwargs)
+    ns = p.parse_args(["--kw", "a=1", "b=-0.5", "c=true", "d=False", "e=run-7x"])
+    assert ns.kw == {"a": 1, "b": -0.5, "c": True, "d": False, "e": "run-7x"}
+    with pytest.raises(NotImplementedError):
+        initialize_wandb(ns)
 
 
 def test_bucket_coalescing_views():

@@ -110,3 +110,22 @@ def test_g8_adversarial():
     assert np.abs(near64.numpy() - g["out_near"]).max() < 5e-3
     far64 = O.nw_head_f64(T(g["xf"]), T(g["sxf"]), sy, C)
     np.testing.assert_allclose(far64.numpy(), g["out_far"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["proj", "clip", "projclip"])
+def test_g9_projection_and_clip_forward(tag):
+    """A11 (nw.py:74-79): the projected features go through the same head; CLIP's scale is the checkpoint's."""
+    g = load_golden("g9_state_dict.npz")
+    C = int(g["C"])
+    sd = {str(k): T(g[f"{tag}_sd_{k}"]) for k in g[f"{tag}_keys"]}
+    pre = "featurizer.0.1" if "proj" in tag else "featurizer.1"
+
+    def feat(x):
+        f = F.linear(x.flatten(1), sd[pre + ".weight"], sd[pre + ".bias"])
+        return F.linear(f, sd["featurizer.1.weight"], sd["featurizer.1.bias"]) if "proj" in tag else f
+    kind = "clip" if "clip" in tag else "euclidean"
+    ls = sd["kernel.logit_scale"] if "clip" in tag else O.CLIP_LOGIT_SCALE_INIT
+    xq, sx, sy = T(g["xq"]), T(g["sx"]), T(g["sy"])
+    f = feat(torch.cat((xq, sx)))                      # joint pass, nw.py:181-184
+    out = O.nw_head_f32(f[:len(xq)], f[len(xq):], sy, C, kind, ls)
+    np.testing.assert_allclose(out.numpy(), g[f"{tag}_fwd"], rtol=1e-6, atol=2e-6)

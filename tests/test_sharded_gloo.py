@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
         B, N, d, C = 6, 103, 24, 5
         s = torch.randn(N, d, generator=g)
         sy = (torch.arange(N) % C).sort().values
-        batches = [torch.randn(B, d, generator=g) for _ in range(5)]
+        batches = [torch.randn(B, d, generator=g) for _ in range(4)] + [torch.randn(B - 2, d, generator=g)]   # ragged tail
         lo, hi = shard_bounds(N, world, rank)
 
         def partial_fn(row, qb):                      # oracle stands in for nw_fwd_partial_f32
@@ -55,6 +55,14 @@ def _worker(rank, world, port, q):
 
         bank = ShardedBank(s[lo:hi], sy[lo:hi], C, partial_fn=partial_fn, merge_fn=merge_fn)
         outs = bank.predict_stream(batches, bucket=2)          # buckets of 2, 2, 1
+        outs3 = bank.predict_stream(batches, bucket=3)         # 3, then 2 with the short batch inside the bucket
+        assert [tuple(o.shape) for o in outs] == [(len(qb), C) for qb in batches]
+        assert all(torch.equal(a, b) for a, b in zip(outs, outs3))
+        try:
+            bank.predict_stream([batches[0], torch.zeros(B, d + 1)])
+            raise SystemExit("a batch with another feature width must be refused")
+        except ValueError:
+            pass
         one = bank.predict(batches[0])
         ref = [O.nw_head_f64(qb, s, sy, C).float() for qb in batches]
         err = max((o - r).abs().max().item() for o, r in zip(outs, ref))
