@@ -214,14 +214,17 @@ __device__ __forceinline__ void tile_dots(const float* __restrict__ q, const flo
 #endif
 
         if (NEED_NORM) {
-            // the 8 threads lt&7 = 0..7 of one row hold the 8 slot-partials of its squared norm
+            // the 8 threads lt&7 = 0..7 of one row hold the 8 slot-partials of its squared norm; every loader
+            // group parks its partial in the (dead) stage ring, the groups are added in order below: no float
+            // atomics, the norms are bit-reproducible
+            float* part = reinterpret_cast<float*>(stage) + grp * (BQ + Cfg::BS);
 #pragma unroll
             for (int it = 0; it < Q_IT; ++it) {
                 float v = nq[it];
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
-                if (cslot == 0) atomicAdd(&qn2[crow + RSTEP * it], v);
+                if (cslot == 0) part[crow + RSTEP * it] = v;
             }
 #pragma unroll
             for (int it = 0; it < S_IT; ++it) {
@@ -229,7 +232,7 @@ __device__ __forceinline__ void tile_dots(const float* __restrict__ q, const flo
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
-                if (cslot == 0) atomicAdd(&sn2[crow + RSTEP * it], v);
+                if (cslot == 0) part[BQ + crow + RSTEP * it] = v;
             }
         }
 #pragma unroll
@@ -264,10 +267,6 @@ __device__ __forceinline__ void tile_dots(const float* __restrict__ q, const flo
 
 #pragma unroll
         for (int r = 0; r < RS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (NEED_NORM) {  // the loader groups add their partial norms here at the end
-            for (int x = tid; x < BQ; x += 64 * NCONS) qn2[x] = 0.f;
-            for (int x = tid; x < Cfg::BS; x += 64 * NCONS) sn2[x] = 0.f;
-        }
         tile_barrier();  // stages 0 and 1 are in LDS
         Frag f0, f1;
         int b0 = 0, b1 = 1, b2 = 2;  // buffers of stage kt, kt+1, kt+2
@@ -295,7 +294,17 @@ __device__ __forceinline__ void tile_dots(const float* __restrict__ q, const flo
 #ifdef NW_DIAG_PHASES
     if (diag && tid == 0) diag[4 * blockIdx.x + 3] = dg[3];
 #endif
-    if (NEED_NORM) __syncthreads();  // norms published
+    if (NEED_NORM) {
+        __syncthreads();  // the loader groups' partial norms are in the stage ring (its last stage has been consumed)
+        const float* part = reinterpret_cast<const float*>(stage);
+        for (int x = tid; x < BQ + Cfg::BS; x += TILE_THREADS) {
+            float v = part[x];
+#pragma unroll
+            for (int gi = 1; gi < NGRP; ++gi) v += part[gi * (BQ + Cfg::BS) + x];
+            if (x < BQ) qn2[x] = v; else sn2[x - BQ] = v;
+        }
+        __syncthreads();  // norms published
+    }
 }
 
 // XCD-aware block decode: the n_qtiles workgroups that stream the same support tile get block ids

@@ -143,7 +143,9 @@ def test_k4_head_shape_forward_backward(dev, ops, O, kind, n_shot):
         scale = max(float(np.abs(want).max()), 1e-3)
         np.testing.assert_allclose(got.cpu().numpy() / scale, want / scale, rtol=1e-4, atol=1e-4)
     if kind == "clip":
-        np.testing.assert_allclose(ls.grad.item(), ls64.grad.item(), rtol=1e-4, atol=1e-6)
+        # d/d(logit_scale) = sum_bj dS_bj * score_bj with sum_j dS_bj = 0: on post-ReLU-like features every cosine is
+        # ~0.75, the terms (|dS * score| sums to ~10) cancel to ~3e-3, so fp32 leaves ~1e-6 absolute whatever the order
+        np.testing.assert_allclose(ls.grad.item(), ls64.grad.item(), rtol=1e-4, atol=5e-6)
     # the reference's own fp32 op sequence (cdist direct form for N <= 25) agrees too
     if kind == "euclidean":
         np.testing.assert_allclose(out.detach().cpu().numpy(), O.nw_head_f32(q0, s0, sy, C).numpy(), rtol=RTOL, atol=ATOL)
@@ -215,11 +217,22 @@ def test_g6_backbones_on_device(dev, name):
         folded = fold_batchnorm(net)
         np.testing.assert_allclose(folded(x).cpu().numpy(), g[f"{name}_eval"], rtol=2e-4, atol=2e-4 * scale)
     net.train()
-    tr = net(x.clone().requires_grad_(True)).detach()
-    tscale = float(np.abs(g[f"{name}_train"]).max())
-    # (the batch-2 DenseNet fixtures end on 2x2 maps: 8 samples per channel, ill-conditioned statistics)
-    loose = "ense" in name
-    np.testing.assert_allclose(tr.cpu().numpy(), g[f"{name}_train"], rtol=5e-3 if loose else 5e-4,
-                               atol=(5e-3 if loose else 5e-4) * tscale)
+    tr = net(x.clone().requires_grad_(True)).detach().cpu().numpy()
+    # Training mode on these fixtures is ILL-CONDITIONED for three of the four nets (batch 2-3 at 64x64 ends on 2x2
+    # maps: 8-12 samples per channel, and 1/sqrt(var + eps) amplifies every rounding difference): an fp64 run of the
+    # same network is 0.11 (resnet18), 0.12 (densenet121), 0.03 (CIFAR_DenseNet121) away from the reference's fp32
+    # output, torch's own device BatchNorm 0.14 / 0.24 / 0.03 -- only CIFAR_ResNet18 (48 samples) pins to 1e-5.
+    # So the bar is the fixture's own conditioning: the device run may be as far from the reference's fp32 output as
+    # exact arithmetic is (x3), plus 5e-4 of the feature scale.  (Well-conditioned training parity of the fused
+    # BatchNorm kernels: test_bn_relu_gpu.py.)
+    net64 = fill_procedural(load_model(name)).double().train()
+    exact = net64(T(g[f"{name}_x"]).double().requires_grad_(True)).detach().numpy()
+    ref = g[f"{name}_train"]
+    tscale = float(np.abs(ref).max())
+    cond = float(np.abs(exact - ref).max())
+    err = float(np.abs(tr - ref).max())
+    assert err <= 3 * cond + 5e-4 * tscale, (name, err, cond, tscale)
+    if name == "CIFAR_ResNet18":
+        np.testing.assert_allclose(tr, ref, rtol=5e-4, atol=5e-5 * tscale)
     np.testing.assert_allclose(net.state_dict()[str(g[f"{name}_rm_name"])].cpu().numpy(), g[f"{name}_rm_after"],
                                rtol=1e-4, atol=1e-6)
