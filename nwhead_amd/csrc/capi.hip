@@ -8,9 +8,9 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool bad_kind(int kind) { return kind < NW_SCORE_EUCLIDEAN || kind > NW_SCORE_CLIP; }
 }  // namespace
 
-// The split-fp16 path adds a launch (splitting the query rows) in front of the tile kernel; below
-// ~2e8 multiply-adds the fp32-MFMA path with cached norms is the shorter one (measured: B=64 N=1000
-// d=512 19.7 vs 29.8 us; B=256 N=10000 d=512 36.1 vs 23.9 us).  NW_SPLIT_ALWAYS=1 forces the split path.
+// Below ~2e8 multiply-adds the fp32-MFMA path with cached norms was the shorter one while the split-fp16 path
+// had a query-split launch in front (measured then: B=64 N=1000 d=512 19.7 vs 29.8 us; B=256 N=10000 d=512
+// 36.1 vs 23.9 us).  NW_SPLIT_ALWAYS=1 forces the split path.
 static bool split_pays(int64_t B, int64_t N, int64_t d) {
     static const bool always = [] { const char* e = getenv("NW_SPLIT_ALWAYS"); return e && e[0] == '1'; }();
     return always || (double)B * (double)N * (double)d >= 2.0e8;
@@ -64,24 +64,6 @@ extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_
     return (plain > fused ? plain : fused) + qsplit;
 }
 
-namespace {
-// Carves the query-split area out of the tail of the workspace and fills it (one small kernel).
-struct QSplit {
-    float *rows, *scale, *norm2;
-};
-int split_queries(const float* q, void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t d,
-                  int64_t C, QSplit* qs, hipStream_t st) {
-    const size_t total = nw_fwd_workspace_bytes(B, N, d, C);
-    if (!workspace || workspace_bytes < total) return NW_ERR_WORKSPACE;
-    const size_t a = align256((size_t)B * (size_t)d * sizeof(float)), b = align256((size_t)B * sizeof(float));
-    char* base = static_cast<char*>(workspace) + (total - a - 2 * b);
-    qs->rows = reinterpret_cast<float*>(base);
-    qs->scale = reinterpret_cast<float*>(base + a);
-    qs->norm2 = reinterpret_cast<float*>(base + a + b);
-    return nw::launch_split_rows(q, qs->rows, qs->scale, qs->norm2, B, d, st);
-}
-}  // namespace
-
 extern "C" int nw_row_norm2_f32(const float* x, float* n2, int64_t rows, int64_t d, void* stream) {
     if (rows < 0 || d < 0) return NW_ERR_INVALID_ARG;
     if (rows == 0) return NW_OK;
@@ -107,14 +89,11 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, con
         if (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C)) return NW_ERR_WORKSPACE;
         if (s_split && s_scale && s_norm2 && d % 32 == 0 && split_pays(B, N, d) &&
             ((reinterpret_cast<uintptr_t>(s_split) | reinterpret_cast<uintptr_t>(q)) & 15) == 0) {
-            QSplit qs;
-            const int rc = split_queries(q, workspace, workspace_bytes, B, N, d, C, &qs, st);
-            if (rc != NW_OK) return rc;
-            return nw::launch_fused(qs.rows, s_split, sy, s_norm2, s_scale, qs.norm2, qs.scale, logit_scale_dev,
+            return nw::launch_fused(q, s_split, sy, s_norm2, s_scale, logit_scale_dev,
                                     out, scores_out, lse_out, nullptr, nullptr, nullptr, workspace,
                                     workspace_bytes, B, N, d, C, kind, st);
         }
-        return nw::launch_fused(q, s, sy, s_norm2, nullptr, nullptr, nullptr, logit_scale_dev, out, scores_out,
+        return nw::launch_fused(q, s, sy, s_norm2, nullptr, logit_scale_dev, out, scores_out,
                                 lse_out, nullptr, nullptr, nullptr, workspace, workspace_bytes, B, N, d, C, kind, st);
     }
     float* scores = scores_out;
@@ -145,14 +124,11 @@ extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t*
     if (N > 0 && C > 0 && nw::fused_eligible(q, s, B, N, d, C)) {
         if (s_split && s_scale && s_norm2 && d % 32 == 0 && split_pays(B, N, d) &&
             ((reinterpret_cast<uintptr_t>(s_split) | reinterpret_cast<uintptr_t>(q)) & 15) == 0) {
-            QSplit qs;
-            const int rc = split_queries(q, workspace, workspace_bytes, B, N, d, C, &qs, st);
-            if (rc != NW_OK) return rc;
-            return nw::launch_fused(qs.rows, s_split, sy, s_norm2, s_scale, qs.norm2, qs.scale, logit_scale_dev,
+            return nw::launch_fused(q, s_split, sy, s_norm2, s_scale, logit_scale_dev,
                                     nullptr, nullptr, nullptr, m, den, num, workspace, workspace_bytes, B, N, d,
                                     C, kind, st);
         }
-        return nw::launch_fused(q, s, sy, s_norm2, nullptr, nullptr, nullptr, logit_scale_dev, nullptr, nullptr,
+        return nw::launch_fused(q, s, sy, s_norm2, nullptr, logit_scale_dev, nullptr, nullptr,
                                 nullptr, m, den, num, workspace, workspace_bytes, B, N, d, C, kind, st);
     }
     int rc = nw::launch_scores(q, s, scores, B, N, d, kind, logit_scale_dev, 0, st);

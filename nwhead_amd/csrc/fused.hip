@@ -22,7 +22,7 @@ namespace nw {
 // instantiated in fused_k0.hip .. fused_k4.hip
 #define NW_EXTERN_FUSED_KIND(K)                                                                          \
     extern template int launch_fused_kind<K>(const float*, const float*, const int64_t*, const float*,   \
-                                             const float*, const float*, const float*,                   \
+                                             const float*,                                               \
                                              const float*, float*, float*, float*, float*, float*,       \
                                              float*, void*, size_t, int, int, int, int, hipStream_t);
 NW_EXTERN_FUSED_KIND(NW_SCORE_EUCLIDEAN)
@@ -153,29 +153,55 @@ namespace {
 //  the tile kernel -- the last workgroup of a query tile does it -- was tried and dropped: one CU's ~450
 //  dependent-latency loads take 25 us, and agent-scope release/acquire fences cost ~40 us per launch on
 //  the 8-XCD part.  A query-blocked workspace with packed run rows was measured too: no change.)
-constexpr int MTHREADS = 512, MENT = 4;
+constexpr int MTHREADS = 512, MENT = 4, MTPT = 16;
 template <bool PARTIAL, int MQ, bool TABLES>
 __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
     const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
     const int* __restrict__ ws_lab, const float* __restrict__ ws_num, float* __restrict__ out,
     float* __restrict__ lse, float* __restrict__ m_out, float* __restrict__ den_out,
     float* __restrict__ num_out, int B, int C, int n_stiles, int BS) {
-    constexpr int ML = MTHREADS / MQ;
-    constexpr int MNS = MQ + 1;  // row stride of res[class][query] in LDS: odd, the output phase reads columns
+    constexpr int ML = MTHREADS / MQ;  // tile lanes per query
+    constexpr int MNS = MQ + 1;        // row stride of res[class][query] in LDS: odd, the output phase reads columns
+    constexpr int NW = MTHREADS / 64;  // waves
     constexpr float LN2 = 0.693147180559945309417f;
+    static_assert(MQ <= 32 && (MQ & (MQ - 1)) == 0, "a wave holds whole groups of MQ queries");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);  // [ML][MQ]
-    float* Ms = red + MTHREADS;                   // [MQ]
+    float* red = reinterpret_cast<float*>(smem);  // [NW][MQ] x 2
+    float* Ms = red + 2 * NW * MQ;                // [MQ]
     float* inv_s = Ms + MQ;                       // [MQ]
     int* cnt = reinterpret_cast<int*>(inv_s + MQ);  // [C]   entries of class c        (TABLES only, like the next four)
     int* tlo = cnt + C;                             // [C]   first tile carrying c
     int* thi = tlo + C;                             // [C]   last tile carrying c
     int* ent = thi + C;                             // [C][MENT]  tile * BS + run, ascending
     float* res = reinterpret_cast<float*>(ent + (size_t)C * MENT);  // [C][MNS]
-    const int tid = threadIdx.x, bq = tid & (MQ - 1), sl = tid / MQ;
+    const int tid = threadIdx.x, bq = tid & (MQ - 1), sl = tid / MQ, wave = tid >> 6;
     const int b0 = blockIdx.x * MQ;
     const int b = min(b0 + bq, B - 1);  // rows past the batch repeat the last query and are never written
 
+    // ---- round trip 1: this thread's tiles (kept in registers when there are at most MTPT of them) and the
+    // run tables.  The first three run labels of a tile are read before its run count is known (rows past nrun
+    // are allocated, never written: what comes back is selected away).
+    const bool in_regs = n_stiles <= ML * MTPT;
+    float mr[MTPT], dr[MTPT];
+    float M = -INFINITY;
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < MTPT; ++u) {
+            const int t = sl + u * ML;
+            const bool ok = t < n_stiles;
+            mr[u] = ok ? ws_m[(size_t)t * B + b] : -INFINITY;
+            dr[u] = ok ? ws_den[(size_t)t * B + b] : 0.f;
+        }
+    }
+    int tnr = 0, tl3[3] = {-1, -1, -1};
+    const bool one_pass_tables = TABLES && n_stiles <= MTHREADS;
+    if (one_pass_tables && tid < n_stiles) {
+        tnr = ws_nrun[tid];
+        const int* lt = ws_lab + (size_t)tid * BS;
+        tl3[0] = lt[0];
+        tl3[1] = lt[1];
+        tl3[2] = lt[2];
+    }
     if (TABLES) {
         for (int c = tid; c < C; c += MTHREADS) {
             cnt[c] = 0;
@@ -183,18 +209,20 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
             thi[c] = -1;
         }
     }
-    // ---- phase 1a: this thread's tiles, max
-    float M = -INFINITY;
-    for (int t = sl; t < n_stiles; t += ML) M = fmaxf(M, ws_m[(size_t)t * B + b]);
-    red[sl * MQ + bq] = M;
-    __syncthreads();
-    // ---- phase 0: class tables.  The first three run labels of a tile are read before its run count is
-    // known (rows past nrun are allocated, never written: what comes back is selected away).
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < MTPT; ++u) M = fmaxf(M, mr[u]);
+    } else {
+        for (int t = sl; t < n_stiles; t += ML) M = fmaxf(M, ws_m[(size_t)t * B + b]);
+    }
+#pragma unroll
+    for (int o = 32; o >= MQ; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));  // lanes l, l ^ MQ, ... hold the same query
+    if ((tid & 63) < MQ) red[wave * MQ + bq] = M;
+    __syncthreads();  // also publishes the reset tables
+    // ---- phase 0: class tables
     if (TABLES) {
-        for (int t = tid; t < n_stiles; t += MTHREADS) {
-            const int nr = ws_nrun[t];
+        auto add_tile = [&](int t, int nr, const int (&l3)[3]) {
             const int* lt = ws_lab + (size_t)t * BS;
-            const int l3[3] = {lt[0], lt[1], lt[2]};
             for (int r = 0; r < nr; ++r) {
                 const int y = r < 3 ? l3[r] : lt[r];
                 if (y < 0) continue;  // padding rows / labels outside [0, C)
@@ -203,11 +231,35 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
                 const int slot = atomicAdd(&cnt[y], 1);
                 if (slot < MENT) ent[y * MENT + slot] = t * BS + r;
             }
+        };
+        if (one_pass_tables) {
+            if (tid < n_stiles) add_tile(tid, tnr, tl3);
+        } else {
+            for (int t = tid; t < n_stiles; t += MTHREADS) {
+                const int* lt = ws_lab + (size_t)t * BS;
+                const int l3[3] = {lt[0], lt[1], lt[2]};
+                add_tile(t, ws_nrun[t], l3);
+            }
         }
     }
-#pragma unroll 4
-    for (int k = 0; k < ML; ++k) M = fmaxf(M, red[k * MQ + bq]);
-    __syncthreads();
+    M = red[bq];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) M = fmaxf(M, red[k * MQ + bq]);
+    // ---- den: every thread adds its tiles in order, the tile lanes of a wave are added in a fixed tree, the
+    // waves in order
+    float den = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < MTPT; ++u) den += dr[u] * __builtin_amdgcn_exp2f(mr[u] - M);  // absent tiles: 0 * 2^-inf = 0
+    } else {
+        for (int t = sl; t < n_stiles; t += ML)
+            den += ws_den[(size_t)t * B + b] * __builtin_amdgcn_exp2f(ws_m[(size_t)t * B + b] - M);
+    }
+#pragma unroll
+    for (int o = 32; o >= MQ; o >>= 1) den += __shfl_xor(den, o);
+    if ((tid & 63) < MQ) red[NW * MQ + wave * MQ + bq] = den;
+    if (sl == 0) Ms[bq] = M;
+    __syncthreads();  // partial dens and the class tables are complete
     if (TABLES) {  // slots were handed out in arrival order: put each class's entries in bank order
         for (int c = tid; c < C; c += MTHREADS) {
             const int n = cnt[c];
@@ -226,16 +278,9 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
             }
         }
     }
-    // ---- phase 1b: den
-    float den = 0.f;
-    for (int t = sl; t < n_stiles; t += ML)
-        den += ws_den[(size_t)t * B + b] * __builtin_amdgcn_exp2f(ws_m[(size_t)t * B + b] - M);
-    red[sl * MQ + bq] = den;
-    if (sl == 0) Ms[bq] = M;
-    __syncthreads();
-    den = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < ML; ++k) den += red[k * MQ + bq];
+    den = red[NW * MQ + bq];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) den += red[NW * MQ + k * MQ + bq];
     if (sl == 0) inv_s[bq] = 1.f / den;
     const int nq = min(MQ, B - b0);
     if (sl == 0 && bq < nq) {
@@ -246,7 +291,8 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
             lse[b] = M * LN2 + logf(den);
         }
     }
-    // ---- phase 2: class sums
+    __syncthreads();  // sorted entries, inv_s
+    // ---- round trip 2: class sums
     for (int x = tid; x < C * MQ; x += MTHREADS) {
         const int c = x / MQ, q = x - c * MQ;
         const int bb = min(b0 + q, B - 1);
@@ -278,14 +324,14 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
                     if (lt[r] == c) acc += ws_num[((size_t)t * BS + r) * B + bb] * f;
             }
         }
-        if (TABLES) {
+        if (TABLES && MQ > 1) {
             res[c * MNS + q] = acc;
-        } else if (q < nq) {  // no room for the staging table: strided stores
+        } else if (q < nq) {  // one query per workgroup (consecutive classes: coalesced), or no room for the staging table
             if (PARTIAL) num_out[(size_t)bb * C + c] = acc;
             else out[(size_t)bb * C + c] = logf(acc * inv_s[q] + NW_LOG_EPS);
         }
     }
-    if (!TABLES) return;
+    if (!TABLES || MQ == 1) return;
     __syncthreads();
     for (int x = tid; x < nq * C; x += MTHREADS) {
         const int qq = x / C, c = x - qq * C;
@@ -346,6 +392,19 @@ int env_rs() {
 
 }  // namespace
 
+// The query-split area sits behind the fused area, at the tail of nw_fwd_workspace_bytes (capi.hip sizes it).
+int split_queries_into_workspace(const float* q, void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t d,
+                                 int64_t C, float** rows, float** scale, float** norm2, hipStream_t st) {
+    const size_t total = nw_fwd_workspace_bytes(B, N, d, C);
+    if (!workspace || workspace_bytes < total) return NW_ERR_WORKSPACE;
+    const size_t a = al256((size_t)B * (size_t)d * sizeof(float)), b = al256((size_t)B * sizeof(float));
+    char* base = static_cast<char*>(workspace) + (total - a - 2 * b);
+    *rows = reinterpret_cast<float*>(base);
+    *scale = reinterpret_cast<float*>(base + a);
+    *norm2 = reinterpret_cast<float*>(base + a + b);
+    return launch_split_rows(q, *rows, *scale, *norm2, B, d, st);
+}
+
 int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st) {
     if (BS > 192) return NW_ERR_UNSUPPORTED;  // three rows per lane
     hipLaunchKernelGGL(nw_run_tables_kernel, dim3(n_stiles), dim3(64), 0, st, sy, N, C, BS, ws.runid, ws.nrun, ws.lab, ws.bnd);
@@ -357,7 +416,7 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
                       int B, int C, int n_stiles, int BS, hipStream_t st) {
     // LDS: reduction scratch + per-class tables (count, first / last tile, MENT entries) + res[class][query]
     auto lds_bytes = [&](int mq, bool tables) {
-        return ((size_t)MTHREADS + 2 * mq + (tables ? (size_t)C * (3 + MENT + mq + 1) : 0)) * sizeof(float);
+        return ((size_t)2 * (MTHREADS / 64) * mq + 2 * mq + (tables ? (size_t)C * (3 + MENT + mq + 1) : 0)) * sizeof(float);
     };
     const size_t cap = 150 * 1024;
     // 32 queries x 16 tile lanes per workgroup when a query has few tiles (a shard of the bank), else 16 x 32;
@@ -442,12 +501,12 @@ bool fused_eligible(const float* q, const float* s, int64_t B, int64_t N, int64_
 
 // out != nullptr: final log-probabilities (+ optional scores / lse); out == nullptr: (m, den, num).
 int launch_fused(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
-                 const float* s_scale, const float* q_norm2, const float* q_scale, const float* ls, float* out,
+                 const float* s_scale, const float* ls, float* out,
                  float* scores, float* lse, float* m, float* den, float* num, void* workspace,
                  size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                  hipStream_t st) {
 #define NW_KIND_CASE(K) \
-    case K: return launch_fused_kind<K>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, out, scores, lse, m, den, num, workspace, workspace_bytes, (int)B, (int)N, (int)d, (int)C, st)
+    case K: return launch_fused_kind<K>(q, s, sy, s_norm2, s_scale, ls, out, scores, lse, m, den, num, workspace, workspace_bytes, (int)B, (int)N, (int)d, (int)C, st)
     switch (kind) {
         NW_KIND_CASE(NW_SCORE_EUCLIDEAN);
         NW_KIND_CASE(NW_SCORE_HYPERSPHERE);

@@ -23,6 +23,9 @@ size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws
 int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st);
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st);
+// split form of the query batch in the tail of the forward workspace (fused.hip)
+int split_queries_into_workspace(const float* q, void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t d,
+                                 int64_t C, float** rows, float** scale, float** norm2, hipStream_t st);
 int device_cu_count();
 bool env_flag(const char* name);
 int tile_timer_start(hipStream_t st);          // diagnostics (nw_debug_tile_timing): -1 when disabled
@@ -37,7 +40,11 @@ namespace {
 // MODE_DMA_SN : LDS-DMA loaders, support norms supplied by the caller (cached bank)
 // MODE_F16 : LDS-DMA loaders, split-fp16 operands on the fp16 matrix cores (tile_f16.h): q and s are
 //            SPLIT rows, norms and row scales of both are supplied
-enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2, MODE_F16 = 3 };
+// MODE_F16Q: as MODE_F16, but q holds the caller's RAW fp32 rows: the consumer waves compute the row scales and
+//            norms in their prologue and split their query fragments in registers (tile_f16.h, QRAW) -- the
+//            one-workgroup-per-tile kernel of small grids (T) runs without a query-split launch in front
+enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2, MODE_F16 = 3, MODE_F16Q = 4 };
+constexpr bool mode_is_f16(int m) { return m == MODE_F16 || m == MODE_F16Q; }
 
 // Runs of equal consecutive labels inside one support tile, by ONE wave (3 rows per lane): fills
 // runid[t] (run of tile row t), runlab[run] (its class, -1 = padding / out-of-range label), nrun_s[0] =
@@ -81,6 +88,11 @@ __device__ __forceinline__ void load_tile_labels(const int64_t* __restrict__ sy,
     }
 }
 
+#ifdef NW_DIAG_FUSED   // diagnostic build only (tools/bench_fused.hip): phase stamps go to `scores`
+#define NW_FSTAMP(k) if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(scores)[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime()
+#else
+#define NW_FSTAMP(k)
+#endif
 // The epilogue of one tile: scores -> tile-local softmax statistics -> run sums -> workspace.
 // Called by all threads of the workgroup (loader waves only take part in the run-table copy).
 template <int RS, int KIND, bool WRITE_SCORES, int MODE>
@@ -106,7 +118,7 @@ __device__ __forceinline__ void fused_epilogue(
     const int qrow = 16 * (wave & 3) + i;
     const int b = q0 + qrow;
     const float qn = NEED_NORM ? qn2[qrow] : 0.f;
-    const float qsc = (MODE == MODE_F16) ? qsc_s[qrow] : 1.f;  // 2^-e of this lane's query row (LDS header)
+    const float qsc = mode_is_f16(MODE) ? qsc_s[qrow] : 1.f;  // 2^-e of this lane's query row (LDS header)
     const bool partial_tile = s0 + BS > N;  // only the last support tile has rows past the bank
 
     float sc[RS][4];
@@ -120,7 +132,7 @@ __device__ __forceinline__ void fused_epilogue(
         for (int r = 0; r < RS; ++r) {
             float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
             if (NEED_NORM) n2 = *reinterpret_cast<const float4*>(sn2 + 16 * r + 4 * g);
-            if (MODE == MODE_F16) s4 = *reinterpret_cast<const float4*>(ssc + 16 * r + 4 * g);  // 2^-e of the support rows
+            if (mode_is_f16(MODE)) s4 = *reinterpret_cast<const float4*>(ssc + 16 * r + 4 * g);  // 2^-e of the support rows
             const float nn[4] = {n2.x, n2.y, n2.z, n2.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -158,6 +170,7 @@ __device__ __forceinline__ void fused_epilogue(
         // tile-local max over the wave's 16 query columns: lanes i, i+16, i+32, i+48 hold one query
         mloc = group4_max(mloc);
     }
+    NW_FSTAMP(3);
 
     // ---- 2^(u - mu) and its sums over the runs of equal labels, on the matrix cores:
     //   P[run][query] = sum_t [runid_t == run] * E[t][query]
@@ -222,16 +235,19 @@ __device__ __forceinline__ void fused_epilogue(
             for (int r = 0; r < RS; ++r) dl[r & 3] += (sc[r][0] + sc[r][1]) + (sc[r][2] + sc[r][3]);
             dloc = group4_sum((dl[0] + dl[1]) + (dl[2] + dl[3]));
             for (int run_base = 0; run_base < nrun; run_base += 16) {
-                f32x4 P = {0.f, 0.f, 0.f, 0.f};
+                // four independent accumulation chains (a dependent fp32 MFMA waits 40 cycles, an independent
+                // one issues every 32), added at the end in a fixed order
+                f32x4 P0 = {0.f, 0.f, 0.f, 0.f}, P1 = P0, P2 = P0, P3 = P0;
                 const int want = run_base + i;
 #pragma unroll
                 for (int r = 0; r < RS; ++r) {
                     const int4 rid = *reinterpret_cast<const int4*>(runid + 16 * r + 4 * g);
-                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.x == want ? 1.f : 0.f, sc[r][0], P, 0, 0, 0);
-                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.y == want ? 1.f : 0.f, sc[r][1], P, 0, 0, 0);
-                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.z == want ? 1.f : 0.f, sc[r][2], P, 0, 0, 0);
-                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.w == want ? 1.f : 0.f, sc[r][3], P, 0, 0, 0);
+                    P0 = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.x == want ? 1.f : 0.f, sc[r][0], P0, 0, 0, 0);
+                    P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.y == want ? 1.f : 0.f, sc[r][1], P1, 0, 0, 0);
+                    P2 = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.z == want ? 1.f : 0.f, sc[r][2], P2, 0, 0, 0);
+                    P3 = __builtin_amdgcn_mfma_f32_16x16x4f32(rid.w == want ? 1.f : 0.f, sc[r][3], P3, 0, 0, 0);
                 }
+                const f32x4 P = (P0 + P1) + (P2 + P3);
                 // P[j] = sum of run (run_base + 4g + j) for query column i
                 if (b < B) {
 #pragma unroll
@@ -242,11 +258,13 @@ __device__ __forceinline__ void fused_epilogue(
                 }
             }
         }
+        NW_FSTAMP(4);
         if (g == 0 && b < B) {
             ws_m[(size_t)st * B + b] = mloc;
             ws_den[(size_t)st * B + b] = dloc;
         }
     }
+    NW_FSTAMP(5);
     if (qt == 0) {  // run table is a property of the support tile: written once per tile
         const int nrun = *nrun_s;
         if (tid == 0) ws_nrun[st] = nrun;
@@ -284,20 +302,17 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
     const int q0 = qt * BQ, s0 = st * BS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 15, g = lane >> 4;
-#ifdef NW_DIAG_FUSED   // diagnostic build only (tools/bench_fused.hip): phase stamps go to `scores`
-#define NW_FSTAMP(k) if (tid == 0) reinterpret_cast<unsigned long long*>(scores)[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime()
-#else
-#define NW_FSTAMP(k)
-#endif
     NW_FSTAMP(0);
 
     // cached support norms: fetched now, long before the epilogue needs them (the DMA loop never
     // touches sn2 in this mode)
-    if ((MODE == MODE_DMA_SN || MODE == MODE_F16) && NEED_NORM) {
+    if ((MODE == MODE_DMA_SN || mode_is_f16(MODE)) && NEED_NORM) {
         for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
     }
-    if (MODE == MODE_F16) {
+    if (mode_is_f16(MODE)) {
         for (int t = tid; t < BS; t += TILE_THREADS) ssc[t] = s_scale[min(s0 + t, N - 1)];
+    }
+    if (MODE == MODE_F16) {  // MODE_F16Q: the consumer waves fill qn2 / qsc_s themselves
         if (NEED_NORM)
             for (int t = tid; t < BQ; t += TILE_THREADS) qn2[t] = q_norm2[min(q0 + t, B - 1)];
         for (int t = tid; t < BQ; t += TILE_THREADS) qsc_s[t] = q_scale[min(q0 + t, B - 1)];
@@ -316,8 +331,8 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
     const int nk = (d + BK - 1) / BK;
     const int rot = st % nk;
     f32x4 acc[RS];
-    if (MODE == MODE_F16) {
-        tile_dots_f16x2<RS>(q, s, B, N, d, q0, s0, stage, acc, rot);
+    if (mode_is_f16(MODE)) {
+        tile_dots_f16x2<RS, MODE == MODE_F16Q>(q, s, B, N, d, q0, s0, stage, acc, rot, qn2, qsc_s);
         __syncthreads();  // header tables written at kernel start are visible; the ring is dead
     } else if (MODE == MODE_REG) {
         tile_dots<RS, NEED_NORM>(q, s, B, N, d, q0, s0, stage, qn2, sn2, acc, rot);
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(TILE_THREADS, (RS <= 5 ? 4 : 2)) void nw_fused_kern
     }
     // (both end behind a barrier: the run tables above and the norms are visible, and the stage
     //  buffers are dead from here on)
-    if (MODE != MODE_DMA_SN && MODE != MODE_F16 && NEED_NORM && s_norm2 != nullptr) {  // cached norms win over computed ones
+    if (MODE != MODE_DMA_SN && !mode_is_f16(MODE) && NEED_NORM && s_norm2 != nullptr) {  // cached norms win over computed ones
         for (int t = tid; t < BS; t += TILE_THREADS) sn2[t] = s_norm2[min(s0 + t, N - 1)];
         __syncthreads();
     }
@@ -345,12 +360,16 @@ int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* 
                 const float* q_norm2, const float* q_scale, const float* ls, const FusedWs& ws, int B, int N,
                 int d, int C, int n_stiles, int n_qtiles, hipStream_t st);
 
+// q: the caller's RAW fp32 queries.  s_scale != nullptr: s holds the SPLIT rows of a prepared bank (d % 32 == 0,
+// s_norm2 given).  The persistent kernel and the score-writing variant take split queries: the split launch
+// (nw_split_rows_kernel into the tail of the workspace) happens here, only for them.
 template <int RS, int KIND>
 int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
-                    const float* s_scale, const float* q_norm2, const float* q_scale,
+                    const float* s_scale,
                     const float* ls, float* out, float* scores, float* lse, float* m, float* den,
                     float* num, void* workspace, size_t workspace_bytes, int B, int N, int d, int C,
                     hipStream_t st) {
+    const float *q_norm2 = nullptr, *q_scale = nullptr;
     constexpr int BS = 16 * RS;
     const int n_stiles = (N + BS - 1) / BS;
     const int n_qtiles = (B + BQ - 1) / BQ;
@@ -376,10 +395,28 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
         const int rc = launch_run_tables(ws, sy, N, C, n_stiles, 16 * RS, st);
         if (rc != NW_OK) return rc;
     }
+    if (s_scale) {  // split-fp16 operands (the caller has checked d % 32 == 0 and supplied the bank's norms)
+        if (!dma || !s_norm2) return NW_ERR_INVALID_ARG;
+        // Raw queries (MODE_F16Q) cost every workgroup a pass over its 64 query rows and the split in its loop
+        // (~5.4 k cycles at T); the split launch costs ~4.4 us + a kernel boundary once.  Measured per forward
+        // (N = 10000, d = 512; raw / split launch): B = 256 20.2 / 21.8 us, 512 40.6 / 40.1, 768 52.7 / 50.4, 1000
+        // 62.4 / 62.3: raw up to 1.5 workgroups per CU.  NW_SPLIT_QUERIES=1 / 0 forces either.
+        static const int force_split = [] { const char* e = getenv("NW_SPLIT_QUERIES"); return e ? atoi(e) : -1; }();
+        const bool raw_ok = force_split == 0 || (force_split < 0 && 2 * grid <= 3 * device_cu_count());
+        if (scores || persistent || !raw_ok) {
+            float *qr, *qsc, *qn;
+            const int rc = split_queries_into_workspace(q, workspace, workspace_bytes, B, N, d, C, &qr, &qsc, &qn, st);
+            if (rc != NW_OK) return rc;
+            q = qr;
+            q_scale = qsc;
+            q_norm2 = qn;
+        }
+    }
     const int timer_slot = tile_timer_start(st);
-    if (s_scale) {  // split-fp16 operands (the caller has checked d % 32 == 0 and supplied everything)
-        if (!dma || !s_norm2 || !q_norm2 || !q_scale) return NW_ERR_INVALID_ARG;
-        if (scores) {
+    if (s_scale) {
+        if (!q_scale) {
+            NW_LAUNCH(false, MODE_F16Q, lds_dma);
+        } else if (scores) {
             NW_LAUNCH(true, MODE_F16, lds_dma);
         } else if (persistent) {
             const int rc = launch_f16p<RS, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, ws, B, N, d, C,
@@ -405,11 +442,11 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
 
 template <int KIND>
 int launch_fused_kind(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
-                      const float* s_scale, const float* q_norm2, const float* q_scale,
+                      const float* s_scale,
                       const float* ls, float* out, float* scores, float* lse, float* m, float* den,
                       float* num, void* workspace, size_t wsb, int B, int N, int d, int C, hipStream_t st) {
 #define NW_RS_CASE(R) \
-    case R: return launch_fused_rs<R, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st)
+    case R: return launch_fused_rs<R, KIND>(q, s, sy, s_norm2, s_scale, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st)
     switch (pick_rs(B, N, d, s_scale != nullptr)) {
         NW_RS_CASE(2);
         NW_RS_CASE(4);
@@ -417,7 +454,7 @@ int launch_fused_kind(const float* q, const float* s, const int64_t* sy, const f
         NW_RS_CASE(6);
         NW_RS_CASE(8);
         NW_RS_CASE(10);
-        default: return launch_fused_rs<12, KIND>(q, s, sy, s_norm2, s_scale, q_norm2, q_scale, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st);
+        default: return launch_fused_rs<12, KIND>(q, s, sy, s_norm2, s_scale, ls, out, scores, lse, m, den, num, workspace, wsb, B, N, d, C, st);
     }
 #undef NW_RS_CASE
 }
@@ -465,7 +502,7 @@ int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* 
 
 #define NW_INSTANTIATE_FUSED_KIND(K)                                                                   \
     template int launch_fused_kind<K>(const float*, const float*, const int64_t*, const float*,        \
-                                      const float*, const float*, const float*,                        \
+                                      const float*,                                                    \
                                       const float*, float*, float*, float*, float*, float*, float*,    \
                                       void*, size_t, int, int, int, int, hipStream_t);
 

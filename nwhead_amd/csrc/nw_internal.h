@@ -42,7 +42,7 @@ size_t fused_workspace_bytes(int64_t B, int64_t N, int64_t d);
 int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d,
                       hipStream_t st);
 int launch_fused(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
-                 const float* s_scale, const float* q_norm2, const float* q_scale,
+                 const float* s_scale,
                  const float* logit_scale_dev, float* out, float* scores, float* lse, float* m,
                  float* den, float* num,
                  void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C,

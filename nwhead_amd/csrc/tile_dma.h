@@ -57,6 +57,22 @@ struct DmaCfg {
     static_assert((NBUF - 3) * NI < 64, "vmcnt is a 6-bit field");
 };
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#ifdef NW_DIAG_FUSED   // diagnostic build only (tools/bench_fused.hip): end of the consumers' query prologue per workgroup
+__device__ unsigned long long nw_diag_q[4096];
+#endif
+
+// Exponent of the split-row scale: 2^e with rowmax * 2^e in [2^13, 2^14) (e = 0 for an all-zero / non-finite row;
+// capped so that 2^e stays finite and 2^-e normal for rows of subnormal magnitude).  The rule of split.hip.
+__device__ __forceinline__ int split_exponent(float rowmax) {
+    int e = 0;
+    if (rowmax > 0.f && rowmax < INFINITY) {
+        e = 14 - __builtin_amdgcn_frexp_expf(rowmax);  // rowmax = f * 2^x, f in [0.5, 1)
+        if (e > 126) e = 126;
+    }
+    return e;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -65,7 +81,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // The loader role (waves 4-7), shared by the fp32 and the split-fp16 consumers: the stage image in
 // LDS is byte-identical in both (128 B per row per stage).
-template <int RS>
+//
+// QRAW (split-fp16 consumers, raw fp32 queries; tile_f16.h): the query rows are DMA'd RAW and the consumers split
+// their fragment in registers.  They read slots 2g and 2g+1 of a query row (k = 8g .. 8g+7 as fp32) instead of g
+// and 4+g, so the query rows' 16-byte slots are swizzled with (row >> 1) & 5 -- conflict-free for that pattern --
+// while the support rows keep (row >> 1) & 7.
+//   (Splitting in place in LDS by the loader waves was measured and dropped: the loaders are the pole of this
+//    loop -- 7 DMA issues of ~100 cycles per stage against 480 cycles of MFMA -- and the conversion's LDS round
+//    trip added 390 cycles per stage, 19.3 vs 13.4 us at T; row statistics in the loaders' prologue serialise
+//    behind the DMA fill, +4.6 k cycles.)
+template <int RS, bool QRAW = false>
 __device__ __forceinline__ void dma_loader_run(const float* __restrict__ q, const float* __restrict__ s,
                                                int B, int N, int d, int q0, int s0, float4* stage,
                                                int rot, int wave, int lane) {
@@ -87,7 +112,8 @@ __device__ __forceinline__ void dma_loader_run(const float* __restrict__ q, cons
 #pragma unroll
         for (int m = 0; m < NI; ++m) {
             const int R = 8 * (lw + NLOAD * m) + (lane >> 3);
-            const int lslot = (lane & 7) ^ ((R >> 1) & 7);  // source-side swizzle
+            // source-side swizzle; QRAW query rows: (row >> 1) & 5, see above
+            const int lslot = (lane & 7) ^ ((R >> 1) & ((QRAW && 8 * NLOAD * m < BQ) ? 5 : 7));
             // offsets are relative to the tile's first row (the bases below carry q0 / s0 in 64 bits): banks
             // beyond 4 GB are fine, a tile never spans more than (BQ + BS) * d * 4 bytes
             const int rel = (8 * NLOAD * m < BQ) ? min(q0 + R, B - 1) - q0 : min(s0 + R - BQ, N - 1) - s0;

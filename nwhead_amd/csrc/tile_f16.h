@@ -24,11 +24,27 @@ namespace nw {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-// Must be called by all 512 threads; d % 32 == 0, d >= 32; q and s are SPLIT rows (see above).
-template <int RS>
+// Must be called by all 512 threads; d % 32 == 0, d >= 32; s holds SPLIT rows (see above).
+// QRAW = false: q holds split rows too (nw_split_rows_kernel ran over the query batch).
+// QRAW = true : q holds the caller's RAW fp32 rows.  While the loaders fill the DMA pipeline, each consumer wave
+//               reads its own 16 query rows once from global memory (four lanes per row; L2-resident: every support
+//               tile's workgroup reads the same 64 rows) for the row maximum and squared norm -> 2^-e and the norm go
+//               to qsc_s / qn2_s (LDS header) for the epilogue; in the loop a lane splits its query fragment in
+//               registers, one stage ahead of its use (8 values per stage: scale, h = fp16(x), l = fp16(x - h);
+//               24 packed VALU ops under 3*RS MFMAs).  No launch in front of the tile kernel: 16.4 us at T against
+//               13.4 + 4.4 us (the split launch) + a kernel boundary.
+//               Measured on the way (T, cycles per workgroup, tools/bench_fused.hip): raw layout alone +0; the
+//               split in the loop +2.0 k; the statistics pass +3.4 k (its 128 KB per workgroup compete with the DMA
+//               fill).  Dropped: statistics by the loader waves (serialise behind their DMA issue, +4.6 k); the
+//               split by the loader waves in place in LDS (they are the pole of the loop: 7 DMA issues of ~100
+//               cycles per stage; +390 cycles per stage); finding the scale on the way with an exact rescale of
+//               the accumulators when a stage outgrows it (no pre-pass, but the branch at the stage boundary cost
+//               more than the pass it saved: 17.8 k / 24.4 k cycles against 18.2 k).
+template <int RS, bool QRAW = false>
 __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, const float* __restrict__ s,
                                                 int B, int N, int d, int q0, int s0, float4* stage,
-                                                f32x4 (&acc)[RS], int rot) {
+                                                f32x4 (&acc)[RS], int rot, float* qn2_s = nullptr,
+                                                float* qsc_s = nullptr) {
     using Cfg = DmaCfg<RS>;
     constexpr int TILE_F4 = Cfg::TILE_F4;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -36,7 +52,7 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
     const int nk = d / BK;
 
     if (wave >= NCONS) {
-        dma_loader_run<RS>(q, s, B, N, d, q0, s0, stage, rot, wave, lane);
+        dma_loader_run<RS, QRAW>(q, s, B, N, d, q0, s0, stage, rot, wave, lane);
 #pragma unroll
         for (int r = 0; r < RS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};  // loaders hold no results
     } else {
@@ -47,14 +63,68 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
         };
         const int qrow = 16 * wave + i;
         const int rsw = (i >> 1) & 7;
+        const int qsw = (i >> 1) & 5;  // QRAW: swizzle of the raw query rows (tile_dma.h)
 #pragma unroll
         for (int r = 0; r < RS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float up = 1.f;  // QRAW: 2^e of this lane's query row
+        if (QRAW) {
+            // lanes 4r .. 4r+3 take row r of this wave's 16: a quarter of the row each (chunks j, j+4, ...), 16 loads
+            // in flight, two shuffles for the row's maximum and squared norm
+            const int qr = lane >> 2, qj = lane & 3;
+            const float4* src = reinterpret_cast<const float4*>(q + (size_t)min(q0 + 16 * wave + qr, B - 1) * d);
+            const int n16 = d >> 4;  // float4 chunks per lane
+            float mx = 0.f, n2 = 0.f;
+            auto take = [&](const float4 v) {
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                n2 += dot4(v);
+            };
+            int t = 0;
+            for (; t + 16 <= n16; t += 16) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = src[qj + 4 * (t + u)];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) take(v[u]);
+            }
+            for (; t < n16; ++t) take(src[qj + 4 * t]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            n2 += __shfl_xor(n2, 1);
+            n2 += __shfl_xor(n2, 2);
+            const int e = split_exponent(mx);
+            if (qj == 0) {
+                qn2_s[16 * wave + qr] = n2;
+                qsc_s[16 * wave + qr] = __builtin_ldexpf(1.f, -e);
+            }
+            // a wave's LDS operations execute in order: the row this lane multiplies with is one it has just written
+            up = __builtin_ldexpf(1.f, 1 - __builtin_amdgcn_frexp_expf(qsc_s[qrow]));  // qsc_s = 2^-e exactly
+#ifdef NW_DIAG_FUSED
+            if (tid == 0) nw_diag_q[blockIdx.x & 4095] = __builtin_amdgcn_s_memtime();
+#endif
+        }
+        // split this lane's raw query fragment (k = 8g .. 8g+7 of its row) into fp16 halves, in place
+        // split this lane's raw query fragment (k = 8g .. 8g+7 of its row) into fp16 halves, in place
+        auto split_q = [&](Frag& f) {
+#ifdef NW_ABL_NOCVT   // timing ablation only (tools/bench_fused.hip): wrong results
+            return;
+#endif
+            const float x[8] = {f.bh.x * up, f.bh.y * up, f.bh.z * up, f.bh.w * up,
+                                f.bl.x * up, f.bl.y * up, f.bl.z * up, f.bl.w * up};
+            half8 h, l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                h[k] = (_Float16)x[k];
+                l[k] = (_Float16)(x[k] - (float)h[k]);
+            }
+            f.bh = __builtin_bit_cast(float4, h);
+            f.bl = __builtin_bit_cast(float4, l);
+        };
         auto load_frags = [&](Frag& f, int buf) {
             const float4* Qs = stage + buf * TILE_F4;
             const float4* Ss = Qs + BQ * ROW_F4;
             const int sh = g ^ rsw, sl = (4 + g) ^ rsw;
-            f.bh = Qs[qrow * ROW_F4 + sh];
-            f.bl = Qs[qrow * ROW_F4 + sl];
+            f.bh = Qs[qrow * ROW_F4 + (QRAW ? ((2 * g) ^ qsw) : sh)];
+            f.bl = Qs[qrow * ROW_F4 + (QRAW ? ((2 * g + 1) ^ qsw) : sl)];
 #pragma unroll
             for (int r = 0; r < RS; ++r) {
                 f.ah[r] = Ss[(16 * r + i) * ROW_F4 + sh];
@@ -90,20 +160,24 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
             };
             Frag f0, f1;
             load_frags(f0, 0);
+            if (QRAW) split_q(f0);
             int kt = 0;
             for (; kt + 2 < nk; kt += 2) {
                 load_frags(f1, (unsigned)(kt + 1) % Cfg::NBUF);
                 mfma_stage(f0);
+                if (QRAW) split_q(f1);  // the next stage's query fragment, under this stage's MFMAs
                 interleave();
                 tile_barrier();
                 load_frags(f0, (unsigned)(kt + 2) % Cfg::NBUF);
                 mfma_stage(f1);
+                if (QRAW) split_q(f0);
                 interleave();
                 tile_barrier();
             }
             for (; kt < nk; ++kt) {  // tail: one or two stages, nothing further to prefetch
                 if (kt + 1 < nk) load_frags(f1, (unsigned)(kt + 1) % Cfg::NBUF);
                 mfma_stage(f0);
+                if (QRAW && kt + 1 < nk) split_q(f1);
                 tile_barrier();
                 f0 = f1;
             }
@@ -113,6 +187,7 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
             Frag f;
             for (int kt = 0; kt < nk; ++kt) {
                 load_frags(f, (unsigned)kt % Cfg::NBUF);
+                if (QRAW) split_q(f);
                 mfma_stage(f);
                 tile_barrier();
             }

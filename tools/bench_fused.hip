@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "fused_impl.h"
 using namespace nw;
 namespace nw {
@@ -31,6 +32,7 @@ int main(int argc, char** argv) {
     const int n_stiles = (N + BS - 1) / BS, n_qtiles = (B + 63) / 64;
     const bool f16 = argc > 5 && atoi(argv[5]) >= 1;
     const bool persistent = argc > 5 && atoi(argv[5]) == 2;
+    const bool qraw = argc > 5 && atoi(argv[5]) == 3;   // MODE_F16Q: raw fp32 queries, split in the consumer waves
     float *q, *s, *sn, *m, *den, *num, *qsp, *ssp, *qsc, *ssc, *qn; int64_t* sy; int *nrun, *lab; unsigned long long* dbg;
     hipMalloc(&qsp, hq.size() * 4); hipMalloc(&ssp, hs.size() * 4); hipMalloc(&qsc, B * 4); hipMalloc(&ssc, N * 4); hipMalloc(&qn, B * 4);
     hipMalloc(&q, hq.size() * 4); hipMalloc(&s, hs.size() * 4); hipMalloc(&sn, N * 4); hipMalloc(&sy, N * 8);
@@ -64,6 +66,10 @@ int main(int argc, char** argv) {
     auto launch = [&] {
         if (persistent)
             launch_f16p<RS, 0>(qsp, ssp, sy, sn, ssc, qn, qsc, nullptr, wsp, B, N, d, C, n_stiles, n_qtiles, 0);
+        else if (qraw)
+            hipLaunchKernelGGL((nw_fused_kernel<RS, 0, false, MODE_F16Q>), dim3(grid), dim3(TILE_THREADS), lds, 0, q, ssp, sy, sn, ssc,
+                               (const float*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles);
         else if (f16)
             hipLaunchKernelGGL((nw_fused_kernel<RS, 0, false, MODE_F16>), dim3(grid), dim3(TILE_THREADS), lds, 0, qsp, ssp, sy, sn, ssc, qn, qsc,
                                (const float*)nullptr, (float*)dbg, m, den, nrun, lab, num, B, N, d, C, n_stiles, n_qtiles);
@@ -88,9 +94,22 @@ int main(int argc, char** argv) {
     }
     std::vector<unsigned long long> h(8 * grid);
     hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
-    double ph[6] = {0}; int n = 0;
-    for (int b = 0; b < grid; ++b) { if (!h[8 * b + 6]) continue; ++n; for (int k = 0; k < 6; ++k) ph[k] += (double)(h[8 * b + k + 1] - h[8 * b + k]); }
-    printf("kernel %.2f us | cycles per WG: scan %.0f, main loop %.0f, scores+max %.0f, exp+den %.0f, run sums (MFMA)+store %.0f, tail %.0f (n=%d)\n",
-           ms * 10, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, n);
+    std::vector<unsigned long long> hq2(4096);
+    hipMemcpyFromSymbol(hq2.data(), HIP_SYMBOL(nw_diag_q), hq2.size() * 8);
+    double ph[4] = {0}, ep[3] = {0}; int n = 0;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (int b = 0; b < grid; ++b) {
+        if (!h[8 * b + 6]) continue;
+        ++n;
+        ph[0] += (double)(h[8 * b + 1] - h[8 * b + 0]);
+        ph[1] += (double)(h[8 * b + 2] - h[8 * b + 1]);
+        ph[2] += (double)(h[8 * b + 6] - h[8 * b + 2]);
+        if (qraw) ph[3] += (double)(hq2[b & 4095] - h[8 * b + 1]);
+        ep[0] += (double)(h[8 * b + 3] - h[8 * b + 2]); ep[1] += (double)(h[8 * b + 4] - h[8 * b + 3]); ep[2] += (double)(h[8 * b + 6] - h[8 * b + 4]);
+        tmin = std::min(tmin, h[8 * b + 0]); tmax = std::max(tmax, h[8 * b + 6]);
+    }
+    printf("kernel %.2f us | cycles per WG: scan+header %.0f, main loop (incl. query prologue %.0f) %.0f, epilogue %.0f | first start -> last end %.0f ticks (n=%d)\n",
+           ms * 10, ph[0] / n, ph[3] / n, ph[1] / n, ph[2] / n, (double)(tmax - tmin), n);
+    printf("   epilogue: scores+max %.0f, exp2 + run sums + num stores %.0f, m/den stores + run table + end %.0f\n", ep[0] / n, ep[1] / n, ep[2] / n);
     return 0;
 }
