@@ -44,20 +44,21 @@ def make_inputs(B, N, d, C, dev, seed=0):
     return q.to(dev), s.to(dev), sy.to(dev)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass of this very
-    command (profiles/*_pmc.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
-        try:
-            for k, v in json.load(open(f)).items():
-                if "nw_fused" in k and "hbm_bytes_per_launch" in v:
-                    if best is None or v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) >= best[0]:
-                        best = (v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), v["hbm_bytes_per_launch"], os.path.basename(f))
-        except Exception:
-            pass
-    return None if best is None else best[1]
+PMC_FILE = "profiles/r02_bench_pmc.json"   # rocprofv3 --pmc passes of `bench.py --skip-extras` (tools/prof_bench.sh)
+
+
+def pmc_traffic(kernel):
+    """(HBM bytes per launch of `kernel`, source) from the committed rocprofv3 PMC passes of this very command
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE; counters cannot be collected inside a timed run), or
+    (None, why).  The file belongs to one round: a stale profile is named, never silently mixed with fresh timings."""
+    path = os.path.join(ROOT, PMC_FILE)
+    try:
+        for k, v in json.load(open(path)).items():
+            if kernel in k and "hbm_bytes_per_launch" in v:
+                return v["hbm_bytes_per_launch"], PMC_FILE
+    except Exception as e:
+        return None, f"{PMC_FILE}: {type(e).__name__}"
+    return None, f"{PMC_FILE}: no entry for {kernel}"
 
 
 def time_kernel_events(fn, iters, warmup=3, min_warm_ms=30.0):
@@ -140,23 +141,73 @@ def measure_shuffled(B, N, d, C, dev, iters=20):
 
 
 def measure_influence(B, N, C, dev, iters=100):
-    """K5: support_influence over a 10000-image support bank (HBM-bound streaming kernel)."""
-    from nwhead_amd import ops
-    g = torch.Generator().manual_seed(5)
-    w = torch.softmax(torch.randn(B, N, generator=g), -1).to(dev)
-    probs = torch.softmax(torch.randn(B, C, generator=g), -1).to(dev)
-    qy = torch.randint(0, C, (B,), generator=g).to(dev)
-    sy = (torch.arange(N) % C).sort().values.to(dev)
-    # call the C ABI directly: at 20 MB the kernel is shorter than the Python wrapper's bookkeeping
+    """K5: support_influence over a 10000-image support bank: a streaming kernel, 8*B*N + 8*N + 12*B algorithmic
+    bytes per call.  Timed over a ROTATION of input / output sets whose total (> 600 MB) exceeds the
+    256 MB Infinity Cache plus L2, so that every call streams from and to HBM (`frac_hbm`); the single-set figure,
+    which lives in the caches between iterations, is reported next to it and labelled so."""
     from nwhead_amd import _lib
     lib = _lib.load()
-    out = torch.empty(B, N, dtype=torch.float32, device=dev)
+    g = torch.Generator().manual_seed(5)
+    nbytes = 8 * B * N + 8 * N + 12 * B
+    nsets = max(2, int(640e6 // nbytes) + 1)
+    sy = (torch.arange(N) % C).sort().values.to(dev)
+    sets = []
+    for k in range(nsets):
+        w = torch.softmax(torch.randn(B, N, generator=g), -1).to(dev) if k < 4 else sets[k % 4][0].clone()
+        probs = torch.softmax(torch.randn(B, C, generator=g), -1).to(dev)
+        qy = torch.randint(0, C, (B,), generator=g).to(dev)
+        sets.append((w, probs, qy, torch.empty(B, N, dtype=torch.float32, device=dev)))
     stream = torch.cuda.current_stream(dev).cuda_stream
-    args = (probs.data_ptr(), qy.data_ptr(), w.data_ptr(), sy.data_ptr(), out.data_ptr(), B, N, C, stream)
-    t = time_kernel_events(lambda: lib.nw_support_influence_f32(*args), iters)
-    nbytes = 8 * B * N + 8 * N + 12 * B                      # SURVEY 8d
-    return {"B": B, "N": N, "C": C, "us_per_call": t * 1e6, "alg_GBps": nbytes / t / 1e9,
-            "frac_hbm": nbytes / t / 1e9 / PEAK_HBM_GBS}
+    # the C ABI directly: at 20 MB the kernel is shorter than the Python wrapper's bookkeeping
+    argl = [(p.data_ptr(), y.data_ptr(), w.data_ptr(), sy.data_ptr(), o.data_ptr(), B, N, C, stream) for w, p, y, o in sets]
+    state = {"k": 0}
+
+    def rotate():
+        lib.nw_support_influence_f32(*argl[state["k"] % nsets])
+        state["k"] += 1
+    t_hbm = time_kernel_events(rotate, nsets * 2, warmup=nsets)
+    t_one = time_kernel_events(lambda: lib.nw_support_influence_f32(*argl[0]), iters)
+    return {"B": B, "N": N, "C": C, "alg_bytes_per_call": nbytes,
+            "us_per_call": t_hbm * 1e6, "alg_GBps": nbytes / t_hbm / 1e9, "frac_hbm": nbytes / t_hbm / 1e9 / PEAK_HBM_GBS,
+            "rotation": f"{nsets} input/output sets, {nsets * nbytes / 1e6:.0f} MB in total: beyond the 256 MB Infinity Cache",
+            "us_per_call_cache_resident": t_one * 1e6, "alg_GBps_cache_resident": nbytes / t_one / 1e9,
+            "note_cache_resident": "one 20.6 MB set reused: served by L2 / Infinity Cache, NOT an HBM figure"}
+
+
+def measure_forward_influence(B, N, d, C, dev, iters=100):
+    """Forward + support_influence as ONE call (nw_fwd_influence_f32: scores written by the fused tile kernel, one
+    in-place pass) against the two separate calls (forward with softmax weights, then the influence kernel)."""
+    from nwhead_amd import ops
+    q, s, sy = make_inputs(B, N, d, C, dev)
+    qy = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(5)).to(dev)
+    bank = ops.SplitBank(s, sy)
+    t_fused = time_kernel_events(lambda: ops.nw_head_influence(q, s, sy, C, qy, support_cache=bank), iters)
+
+    def two():
+        out, w = ops.nw_head(q, s, sy, C, return_weights=True, support_cache=bank)
+        return ops.support_influence_idx(out.exp(), qy, w, sy)
+    t_two = time_kernel_events(two, iters)
+    t_fwd = time_kernel_events(lambda: ops.nw_head(q, s, sy, C, support_cache=bank), iters)
+    return {"B": B, "N": N, "d": d, "us_forward_plus_influence_one_call": t_fused * 1e6,
+            "us_forward_with_weights_then_influence": t_two * 1e6, "us_forward_alone": t_fwd * 1e6}
+
+
+def measure_latency(bank, q, iters=50):
+    """Device latency of ONE predict('full') call of B queries against this rank's bank (no coalescing): HIP events
+    around single, synchronised calls; median."""
+    ts = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10):
+        bank.predict(q)
+    for _ in range(iters):
+        torch.cuda.synchronize()
+        e0.record()
+        bank.predict(q)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def measure_backbone_configs(dev):
@@ -294,16 +345,20 @@ def main():
     ap.add_argument("--bank", type=int, default=50000)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--classes", type=int, default=200)
-    ap.add_argument("--bucket", type=int, default=0,
-                    help="query batches coalesced per launch (and per RCCL all-gather); 0 = 16 x min(gpus, 4): "
-                         "a rank's shard shrinks with the rank count, the per-launch fixed costs do not")
+    ap.add_argument("--bucket", type=int, default=16,
+                    help="query batches coalesced per launch (and per RCCL all-gather); the same at every --gpus, so "
+                         "that the scaling curve compares like with like")
     ap.add_argument("--min-warmup-ms", type=float, default=40.0,
                     help="the untimed warm-up lasts at least this long (device time): post-idle clock ramp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="only the timed workload (for profiling)")
     args = ap.parse_args()
-    if args.bucket <= 0:
-        args.bucket = 16 * min(max(args.gpus, 1), 4)
+    args.bucket = max(1, args.bucket)
+    # The timed region is made of WHOLE launches and of at least four of them: --steps is rounded up to a multiple
+    # of the bucket (a ragged last bucket would be a launch shape of its own, and two launches are not a
+    # measurement); `steps` in the JSON line is what was timed, `steps_requested` what was asked for.
+    steps_requested = args.steps
+    args.steps = max(4 * args.bucket, -(-args.steps // args.bucket) * args.bucket)
     # Library banners (RCCL prints its version block to stdout when the first communicator comes up)
     # must not land next to the JSON line: stdout is pointed at stderr until the line is printed.
     sys.stdout.flush()
@@ -398,6 +453,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
+    lat_us = measure_latency(bank, qs[0])     # every rank: the sharded call has a collective inside
     line = None
     if rank == 0:
         n_shard = hi - lo
@@ -423,14 +479,25 @@ def main():
         fast = bank.cache is not None and bank.cache.split is not None
         peak = PEAK_SPLIT_F16_TFLOPS if fast else PEAK_F32_MFMA_TFLOPS
         persistent = fast and Bl * n_shard >= 64 * 128 * 1024
+        kname = "nw_fused_f16p_kernel" if persistent else "nw_fused_kernel"
+        traffic, traffic_src = pmc_traffic(kname)
+        ach = flops / t_sc / 1e12
         roof = {"bound": "mfma",
-                "kernel": "nw_fused_f16p_kernel" if persistent else "nw_fused_kernel",
-                "achieved": flops / t_sc / 1e12,
-                "peak": peak, "unit": "TFLOP/s", "frac": flops / t_sc / 1e12 / peak, "traffic": pmc_traffic(),
-                "peak_note": ("fp16 dense MFMA spec peak 2500 / 3 fp16 products per fp32 multiply-add (split-fp16 "
-                              "operands); on random operands the chip holds ~1.5-1.75 GHz on this loop, not the "
-                              "2.4 GHz the spec peak assumes (DESIGN.md, power-limited pace)"
-                              if fast else "fp32 dense MFMA peak"),
+                "kernel": kname,
+                "achieved": ach,
+                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "operands": "split-fp16x2" if fast else "f32",
+                "peak_note": ("`peak` is OUR construction, not a guide number: the guide's fp16 dense MFMA peak (2500 "
+                              "TFLOP/s) divided by the 3 fp16 products issued per algorithmic fp32 multiply-add "
+                              "(x = h + l split, al*bl dropped).  frac_fp16_pipe = 3 * achieved / 2500 (the same "
+                              "number: matrix-pipe utilisation counting issued products); alg_frac_fp16_peak = "
+                              "achieved / 2500 (algorithmic flops against the guide's peak, no factor 3); "
+                              "achieved_vs_fp32_mfma_peak = achieved / 157.3 (the guide's fp32 MFMA peak, > 1 because "
+                              "the work is not on the fp32 pipe).  On random operands the chip holds ~1.5-1.75 GHz "
+                              "on this loop, not the 2.4 GHz the spec peak assumes (DESIGN.md, power-limited pace)"
+                              if fast else "fp32 dense MFMA peak (guide)"),
+                "frac_fp16_pipe": (3 * ach / PEAK_F16_MFMA_TFLOPS) if fast else None,
+                "alg_frac_fp16_peak": ach / PEAK_F16_MFMA_TFLOPS,
                 "achieved_vs_fp32_mfma_peak": flops / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "kernel_us": t_sc * 1e6, "kernel_launches_timed": cnt.value,
                 "launch_us": t_all * 1e6,
@@ -440,9 +507,14 @@ def main():
                 "alg_bytes_per_launch": alg_bytes(Bl, n_shard, d, C),
                 "alg_GBps": alg_bytes(Bl, n_shard, d, C) / t_all / 1e9}
         line = {"metric": "query-predictions/sec", "value": args.steps * B / dt, "unit": "query-predictions/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps,
+                "n_gpus": world, "steps": args.steps, "steps_requested": steps_requested, "warmup": args.warmup,
+                "warmup_steps_run": warm_steps,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None, "dtype": "f32", "operands": "split-fp16x2 (fp32 accumulate)" if fast else "f32",
+                "data": "synthetic",
+                "latency_us_single_call_B256": lat_us,
+                "latency_note": "one uncoalesced predict('full') call of B queries against this rank's shard (plus the "
+                                "exchange when sharded); a `step` of the timed region is 1/bucket of a coalesced launch",
                 "config": {"workload": f"K3 predict('full'): B={B} queries/step vs bank N={N} d={d} C={C}, "
                                        f"bank sharded {world}-way, {args.bucket} query batches coalesced per launch"
                                        + (" and per RCCL all-gather" if world > 1 else ""),
@@ -452,6 +524,9 @@ def main():
             line["north_star_T"] = measure_shape(256, 10000, 512, 200, dev, 100)
             line["config_K2_head"] = measure_shape(64, 1000, 512, 200, dev, 100)
             line["config_K5_support_influence"] = measure_influence(256, 10000, 200, dev)
+            line["config_K5_support_influence"]["B4096"] = {k: v for k, v in measure_influence(4096, 10000, 200, dev, iters=20).items()
+                                                             if k in ("B", "alg_bytes_per_call", "us_per_call", "alg_GBps", "frac_hbm", "rotation")}
+            line["config_K5_support_influence"]["fused_with_forward_T"] = measure_forward_influence(256, 10000, 512, 200, dev)
             line["head_train_step_T"] = measure_train_head(256, 10000, 512, 200, dev)
             line["K3_shuffled_labels"] = measure_shuffled(4096, N, d, C, dev)
             line.update(measure_backbone_configs(dev))

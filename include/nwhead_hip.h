@@ -168,6 +168,22 @@ int nw_support_influence_f32(const float *probs, const int64_t *qy, const float 
                              const int64_t *sy, float *infl,
                              int64_t B, int64_t N, int64_t C, void *stream);
 
+/* Forward + support_influence in one call: nw_fwd_f32's arguments plus
+ *   qy (B,) int64 query labels, infl_out (B,N).
+ * The fused tile kernel writes the raw scores into infl_out, the merge gives out (log-probabilities) and the
+ * log-sum-exp, and ONE in-place pass turns scores into influences with w = exp(score - lse), p = exp(out[b, qy_b])
+ * (util/metric.py:23-50 applied to the head's own outputs, README.md:101-132).  The (B,N) matrix crosses HBM three
+ * times (scores out, scores in, influences out) instead of five (scores, weights written and read, influences), and
+ * no softmax-weight matrix exists.  (Recomputing the scores instead of storing them would cost a second pass of the
+ * tile kernel: 13 us against the 4 us of the round trip at B = 256, N = 10000.)  Shared 2-D supports only.
+ * lse_out optional (B,).  workspace: nw_fwd_workspace_bytes(B,N,d,C). */
+int nw_fwd_influence_f32(const float *q, const float *s, const int64_t *sy, const float *s_norm2,
+                         const float *s_split, const float *s_scale, const int64_t *qy,
+                         float *out, float *lse_out, float *infl_out,
+                         void *workspace, size_t workspace_bytes,
+                         int64_t B, int64_t N, int64_t d, int64_t C,
+                         int kind, const float *logit_scale_dev, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The k best supports per query.  Replaces the full descending argsort that the reference cuts to
  * its first k columns (KNN.__call__, nwhead/utils.py:185-193; 'knn' / 'hnsw' support modes):

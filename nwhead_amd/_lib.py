@@ -35,6 +35,7 @@ SIGNATURES = {
     "nw_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int]),
     "nw_bwd_f32": (_int, [_p] * 10 + [_p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
     "nw_support_influence_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "nw_fwd_influence_f32": (_int, [_p] * 11 + [_sz, _i64, _i64, _i64, _i64, _int, _p, _p]),
     "nw_topk_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "nw_scale_shift_relu_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "nw_bn_relu_train_fwd_f32": (_int, [_p] * 10 + [_i64, _i64, _i64, _i64, C.c_float, C.c_float, _int, _p]),

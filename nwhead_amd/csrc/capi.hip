@@ -61,7 +61,8 @@ extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_
     const size_t fused = align256(nw::fused_workspace_bytes(B, N, d));
     // + room for the split-fp16 form of the queries (rows, scales, norms) behind the fused area
     const size_t qsplit = align256((size_t)B * (size_t)d * sizeof(float)) + 2 * align256((size_t)B * sizeof(float));
-    return (plain > fused ? plain : fused) + qsplit;
+    // + B floats for the log-sum-exp when weights / influences are derived from the fused kernel's scores
+    return (plain > fused ? plain : fused) + qsplit + align256((size_t)B * sizeof(float));
 }
 
 extern "C" int nw_row_norm2_f32(const float* x, float* n2, int64_t rows, int64_t d, void* stream) {
@@ -84,9 +85,22 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, con
     if (N > 0 && (!q || !s || !sy)) return NW_ERR_INVALID_ARG;
     if (kind == NW_SCORE_CLIP && !logit_scale_dev) return NW_ERR_INVALID_ARG;
     if (labels_batched && !sup_batched) return NW_ERR_INVALID_ARG;
-    if (N > 0 && C > 0 && !sup_batched && !weights_out && nw::fused_eligible(q, s, B, N, d, C) &&
-        (!scores_out || (reinterpret_cast<uintptr_t>(scores_out) & 15) == 0)) {
+    // Softmax weights on request: the fused kernel writes the scores where the weights go and one in-place pass
+    // normalises them with the merge's log-sum-exp (w = exp(score - lse)); the two-kernel fallback below streams
+    // the (B,N) matrix five times.
+    float* sc_buf = scores_out ? scores_out : weights_out;
+    if (N > 0 && C > 0 && !sup_batched && nw::fused_eligible(q, s, B, N, d, C) &&
+        (!sc_buf || (reinterpret_cast<uintptr_t>(sc_buf) & 15) == 0)) {
         if (!workspace || workspace_bytes < nw_fwd_workspace_bytes(B, N, d, C)) return NW_ERR_WORKSPACE;
+        if (weights_out) {
+            float* lse = lse_out;
+            if (!lse) lse = reinterpret_cast<float*>(static_cast<char*>(workspace) + nw_fwd_workspace_bytes(B, N, d, C) -
+                                                     align256((size_t)B * sizeof(float)));
+            const int rc = nw_fwd_f32(q, s, sy, s_norm2, s_split, s_scale, out, sc_buf, lse, nullptr, workspace,
+                                      workspace_bytes, B, N, d, C, kind, logit_scale_dev, 0, 0, stream);
+            if (rc != NW_OK) return rc;
+            return nw::launch_weights_from_scores(sc_buf, lse, weights_out, B, N, st);
+        }
         if (s_split && s_scale && s_norm2 && d % 32 == 0 && split_pays(B, N, d) &&
             ((reinterpret_cast<uintptr_t>(s_split) | reinterpret_cast<uintptr_t>(q)) & 15) == 0) {
             return nw::launch_fused(q, s_split, sy, s_norm2, s_scale, logit_scale_dev,
@@ -158,4 +172,26 @@ extern "C" int nw_debug_tile_timing(int enable) { return nw::tile_timer_enable(e
 
 extern "C" int nw_debug_tile_timing_read(double* total_us, int64_t* launches) {
     return nw::tile_timer_read(total_us, launches);
+}
+
+extern "C" int nw_fwd_influence_f32(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
+                                    const float* s_split, const float* s_scale, const int64_t* qy, float* out,
+                                    float* lse_out, float* infl_out, void* workspace, size_t workspace_bytes,
+                                    int64_t B, int64_t N, int64_t d, int64_t C, int kind,
+                                    const float* logit_scale_dev, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
+    if (B == 0) return NW_OK;
+    if (N == 0 || C == 0)   // no supports: log(0 + 1e-12) and nothing to score
+        return nw_fwd_f32(q, s, sy, s_norm2, s_split, s_scale, out, nullptr, lse_out, nullptr, workspace, workspace_bytes,
+                          B, N, d, C, kind, logit_scale_dev, 0, 0, stream);
+    if (!qy || !infl_out || !out) return NW_ERR_INVALID_ARG;
+    const size_t need = nw_fwd_workspace_bytes(B, N, d, C);   // its last B floats: the log-sum-exp slot
+    if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
+    float* lse = lse_out ? lse_out : reinterpret_cast<float*>(static_cast<char*>(workspace) + need - align256((size_t)B * sizeof(float)));
+    // scores into infl_out (fused tile kernel when eligible, else the score kernel of the two-kernel path)
+    const int rc = nw_fwd_f32(q, s, sy, s_norm2, s_split, s_scale, out, infl_out, lse, nullptr, workspace,
+                              workspace_bytes, B, N, d, C, kind, logit_scale_dev, 0, 0, stream);
+    if (rc != NW_OK) return rc;
+    return nw::launch_influence(out, qy, infl_out, sy, lse, infl_out, B, N, C, st);
 }

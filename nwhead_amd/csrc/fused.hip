@@ -398,7 +398,7 @@ int split_queries_into_workspace(const float* q, void* workspace, size_t workspa
     const size_t total = nw_fwd_workspace_bytes(B, N, d, C);
     if (!workspace || workspace_bytes < total) return NW_ERR_WORKSPACE;
     const size_t a = al256((size_t)B * (size_t)d * sizeof(float)), b = al256((size_t)B * sizeof(float));
-    char* base = static_cast<char*>(workspace) + (total - a - 2 * b);
+    char* base = static_cast<char*>(workspace) + (total - a - 3 * b);  // the last b bytes: the log-sum-exp slot (capi.hip)
     *rows = reinterpret_cast<float*>(base);
     *scale = reinterpret_cast<float*>(base + a);
     *norm2 = reinterpret_cast<float*>(base + a + b);

@@ -22,34 +22,128 @@ __device__ __forceinline__ float infl_one(float p, float w, bool same) {
     return __builtin_amdgcn_logf(ratio) * 0.693147180559945309417f;
 }
 
+// One thread = one 16-byte column chunk (4 supports) of IROWS query rows: the chunk's labels are read once and
+// compared per row, the IROWS weight loads are independent (all in flight), every access is a full 1 KB per wave.
+// (One row per workgroup re-read the int64 labels -- 2 bytes per byte of weights -- from L2 for every row:
+//  7.5 us per 20.6 MB call when the rows stream from HBM.)
+// SCORES: `w` holds raw scores, the weight is exp(score - lse[b]) (the forward's log-sum-exp) and p is
+// exp(logp[b, qy_b]): the influence straight from the fused forward's score matrix, in place if infl == w.
+constexpr int IROWS = 4;
+template <bool SCORES>
 __global__ __launch_bounds__(256) void nw_influence_kernel(
-    const float* __restrict__ probs, const int64_t* __restrict__ qy, const float* __restrict__ w,
-    const int64_t* __restrict__ sy, float* __restrict__ infl, int64_t N, int64_t C) {
-    const int64_t b = blockIdx.y;
-    const int64_t q = qy[b];
-    const float p = ((uint64_t)q < (uint64_t)C) ? probs[b * C + q] : 0.f;
-    const float* wr = w + b * N;
-    float* orow = infl + b * N;
-    const bool vec = ((N & 3) == 0) && (((reinterpret_cast<uintptr_t>(wr) | reinterpret_cast<uintptr_t>(orow)) & 15) == 0);
+    const float* __restrict__ probs, const int64_t* __restrict__ qy, const float* w,
+    const int64_t* __restrict__ sy, const float* __restrict__ lse, float* infl, int64_t B, int64_t N, int64_t C) {
+    const int64_t b0 = (int64_t)blockIdx.y * IROWS;
+    const int64_t n4 = N >> 2;
+    const bool vec = ((N & 3) == 0) && (((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(infl)) & 15) == 0);
+    int64_t q[IROWS];
+    float p[IROWS], l[IROWS];
+#pragma unroll
+    for (int r = 0; r < IROWS; ++r) {
+        const int64_t b = min(b0 + r, B - 1);
+        q[r] = qy[b];
+        const float pv = ((uint64_t)q[r] < (uint64_t)C) ? probs[b * C + q[r]] : (SCORES ? -INFINITY : 0.f);
+        p[r] = SCORES ? expf(pv) : pv;
+        l[r] = SCORES ? lse[b] : 0.f;
+    }
     if (vec) {
-        const int64_t n4 = N >> 2;
         for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
-            const float4 v = reinterpret_cast<const float4*>(wr)[j];
             const int64_t* y = sy + 4 * j;
-            float4 o;
-            o.x = infl_one(p, v.x, y[0] == q);
-            o.y = infl_one(p, v.y, y[1] == q);
-            o.z = infl_one(p, v.z, y[2] == q);
-            o.w = infl_one(p, v.w, y[3] == q);
-            reinterpret_cast<float4*>(orow)[j] = o;
+            const int64_t y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+            float4 v[IROWS];
+#pragma unroll
+            for (int r = 0; r < IROWS; ++r)
+                if (b0 + r < B) v[r] = reinterpret_cast<const float4*>(w + (b0 + r) * N)[j];
+#pragma unroll
+            for (int r = 0; r < IROWS; ++r) {
+                if (b0 + r >= B) continue;
+                float4 x = v[r];
+                if (SCORES) x = make_float4(expf(x.x - l[r]), expf(x.y - l[r]), expf(x.z - l[r]), expf(x.w - l[r]));
+                float4 o;
+                o.x = infl_one(p[r], x.x, y0 == q[r]);
+                o.y = infl_one(p[r], x.y, y1 == q[r]);
+                o.z = infl_one(p[r], x.z, y2 == q[r]);
+                o.w = infl_one(p[r], x.w, y3 == q[r]);
+                reinterpret_cast<float4*>(infl + (b0 + r) * N)[j] = o;
+            }
         }
     } else {
-        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < N; j += (int64_t)gridDim.x * 256)
-            orow[j] = infl_one(p, wr[j], sy[j] == q);
+        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < N; j += (int64_t)gridDim.x * 256) {
+            const int64_t y = sy[j];
+#pragma unroll
+            for (int r = 0; r < IROWS; ++r) {
+                if (b0 + r >= B) continue;
+                float x = w[(b0 + r) * N + j];
+                if (SCORES) x = expf(x - l[r]);
+                infl[(b0 + r) * N + j] = infl_one(p[r], x, y == q[r]);
+            }
+        }
     }
 }
 
+// weights[b, j] = exp(scores[b, j] - lse[b]): the softmax weights from the fused forward's score matrix (in place
+// when weights == scores)
+__global__ __launch_bounds__(256) void nw_weights_from_scores_kernel(const float* scores, const float* __restrict__ lse,
+                                                                     float* weights, int64_t B, int64_t N) {
+    const int64_t b0 = (int64_t)blockIdx.y * IROWS;
+    const int64_t n4 = N >> 2;
+    const bool vec = ((N & 3) == 0) && (((reinterpret_cast<uintptr_t>(scores) | reinterpret_cast<uintptr_t>(weights)) & 15) == 0);
+    float l[IROWS];
+#pragma unroll
+    for (int r = 0; r < IROWS; ++r) l[r] = lse[min(b0 + r, B - 1)];
+    if (vec) {
+        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+            float4 v[IROWS];
+#pragma unroll
+            for (int r = 0; r < IROWS; ++r)
+                if (b0 + r < B) v[r] = reinterpret_cast<const float4*>(scores + (b0 + r) * N)[j];
+#pragma unroll
+            for (int r = 0; r < IROWS; ++r)
+                if (b0 + r < B)
+                    reinterpret_cast<float4*>(weights + (b0 + r) * N)[j] =
+                        make_float4(expf(v[r].x - l[r]), expf(v[r].y - l[r]), expf(v[r].z - l[r]), expf(v[r].w - l[r]));
+        }
+    } else {
+        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < N; j += (int64_t)gridDim.x * 256)
+#pragma unroll
+            for (int r = 0; r < IROWS; ++r)
+                if (b0 + r < B) weights[(b0 + r) * N + j] = expf(scores[(b0 + r) * N + j] - l[r]);
+    }
+}
+
+inline unsigned col_blocks(int64_t N) {
+    int64_t gx = (N / 4 + 255) / 256;
+    return (unsigned)(gx < 1 ? 1 : (gx > 64 ? 64 : gx));
+}
+
 }  // namespace
+}  // namespace nw
+
+namespace nw {
+int launch_weights_from_scores(const float* scores, const float* lse, float* weights, int64_t B, int64_t N, hipStream_t st) {
+    for (int64_t b0 = 0; b0 < B; b0 += 65535 * IROWS) {  // grid.y limit: walk the batch in slabs
+        const int64_t nb = (B - b0 < 65535 * IROWS) ? (B - b0) : 65535 * IROWS;
+        hipLaunchKernelGGL(nw_weights_from_scores_kernel, dim3(col_blocks(N), (unsigned)((nb + IROWS - 1) / IROWS)), dim3(256), 0, st,
+                           scores + b0 * N, lse + b0, weights + b0 * N, nb, N);
+    }
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+int launch_influence(const float* probs_or_logp, const int64_t* qy, const float* w_or_scores, const int64_t* sy,
+                     const float* lse, float* infl, int64_t B, int64_t N, int64_t C, hipStream_t st) {
+    for (int64_t b0 = 0; b0 < B; b0 += 65535 * IROWS) {
+        const int64_t nb = (B - b0 < 65535 * IROWS) ? (B - b0) : 65535 * IROWS;
+        const dim3 grid(col_blocks(N), (unsigned)((nb + IROWS - 1) / IROWS));
+        if (lse)
+            hipLaunchKernelGGL(nw_influence_kernel<true>, grid, dim3(256), 0, st, probs_or_logp + b0 * C, qy + b0,
+                               w_or_scores + b0 * N, sy, lse + b0, infl + b0 * N, nb, N, C);
+        else
+            hipLaunchKernelGGL(nw_influence_kernel<false>, grid, dim3(256), 0, st, probs_or_logp + b0 * C, qy + b0,
+                               w_or_scores + b0 * N, sy, nullptr, infl + b0 * N, nb, N, C);
+    }
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
 }  // namespace nw
 
 extern "C" int nw_support_influence_f32(const float* probs, const int64_t* qy, const float* w,
@@ -58,21 +152,5 @@ extern "C" int nw_support_influence_f32(const float* probs, const int64_t* qy, c
     if (B < 0 || N < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (B == 0 || N == 0) return NW_OK;
     if (!probs || !qy || !w || !sy || !infl) return NW_ERR_INVALID_ARG;
-    if (B > 65535) {
-        // grid.y limit: walk the batch in slabs
-        for (int64_t b0 = 0; b0 < B; b0 += 65535) {
-            const int64_t nb = (B - b0 < 65535) ? (B - b0) : 65535;
-            const int rc = nw_support_influence_f32(probs + b0 * C, qy + b0, w + b0 * N, sy,
-                                                    infl + b0 * N, nb, N, C, stream);
-            if (rc != NW_OK) return rc;
-        }
-        return NW_OK;
-    }
-    int64_t gx = (N / 4 + 255) / 256;
-    if (gx < 1) gx = 1;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(nw::nw_influence_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), probs, qy, w, sy, infl, N, C);
-    NW_CHECK_LAUNCH();
-    return NW_OK;
+    return nw::launch_influence(probs, qy, w, sy, nullptr, infl, B, N, C, static_cast<hipStream_t>(stream));
 }

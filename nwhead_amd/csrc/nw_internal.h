@@ -29,6 +29,11 @@ int launch_merge(const float* m, const float* den, const float* num, float* out,
                  int64_t B, int64_t C, int64_t sm, int64_t sd, int64_t sn, const int64_t* class_lo,
                  int64_t CL, hipStream_t st);
 
+// influence.hip: softmax weights / influences from a score matrix and the forward's log-sum-exp (in place allowed)
+int launch_weights_from_scores(const float* scores, const float* lse, float* weights, int64_t B, int64_t N, hipStream_t st);
+int launch_influence(const float* probs_or_logp, const int64_t* qy, const float* w_or_scores, const int64_t* sy,
+                     const float* lse, float* infl, int64_t B, int64_t N, int64_t C, hipStream_t st);
+
 // squared row norms of a (rows,d) matrix (backward.hip)
 int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStream_t st);
 

@@ -429,6 +429,46 @@ def bn_relu_train(x, bn, relu=True, residual=None, passthrough=False):
     return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, residual, bn, bool(relu), bool(passthrough))
 
 
+def nw_head_influence(q, s, sy, n_classes, qy, kind="euclidean", logit_scale=None, support_cache=None):
+    """NWHead.forward plus util/metric.py:23-50 on its own outputs in one call (no grad): returns
+    (out (B,C) log-probabilities, infl (B,N)) with infl[b,j] = log((p - p*w_bj) / (p - w_bj*[sy_j == qy_b])),
+    p = exp(out[b, qy_b]), w = the head's softmax weights -- which are never materialised: the tile kernel writes
+    raw scores into the influence buffer and one in-place pass finishes them (nw_fwd_influence_f32).
+    Shared (N,d) supports only."""
+    _need_hip(q, s, sy, qy, logit_scale)
+    kid = _kind_id(kind)
+    if kid == SCORE_KINDS["clip"] and logit_scale is None:
+        raise ValueError("clip kernel needs logit_scale")
+    if s.dim() != 2 or sy.dim() != 1:
+        raise ValueError("nw_head_influence takes a shared (N,d) support with (N,) labels")
+    if support_cache is not None and not support_cache.matches(s):
+        raise ValueError("support_cache was prepared from another support tensor")
+    # influences are indexed by support position: an unsorted bank's class-sorted copy cannot serve them
+    s, sy, support_cache = _resolve_sorted_bank(s, sy, support_cache, per_position_outputs=True)
+    lib = _lib.load()
+    qc, sc = _f32c(q), _f32c(s)
+    syc = sy.detach().to(torch.int64).contiguous()
+    qyc = qy.detach().to(torch.int64).contiguous()
+    B, d = qc.shape
+    N, C = sc.shape[0], int(n_classes)
+    if qyc.shape != (B,):
+        raise ValueError("qy must be (B,)")
+    dev = qc.device
+    out = torch.empty(B, C, dtype=torch.float32, device=dev)
+    infl = torch.empty(B, N, dtype=torch.float32, device=dev)
+    sn2 = ssplit = sscale = None
+    if support_cache is not None:
+        sn2, ssplit, sscale = support_cache.norm2, support_cache.split, support_cache.scale
+    ls = None if logit_scale is None else _f32c(logit_scale)
+    ws_bytes = lib.nw_fwd_workspace_bytes(B, N, d, C)
+    ws = _workspace(ws_bytes, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nw_fwd_influence_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale), _ptr(qyc),
+                                            _ptr(out), None, _ptr(infl), _ptr(ws), ws.numel(), B, N, d, C, kid, _ptr(ls),
+                                            _stream(qc)), "nw_fwd_influence_f32")
+    return out, infl
+
+
 def support_influence_idx(probs, qy, w, sy):
     """Index-label form of util/metric.py:23-50: probs (B,C), qy (B,), w (B,N), sy (N,) -> (B,N)."""
     _need_hip(probs, qy, w, sy)

@@ -456,3 +456,55 @@ def test_bank_beyond_4gb(dev, ops):
     assert torch.isfinite(out).all() and (out.exp().sum(1) - 1).abs().max().item() < 1e-4
     del bank, s
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ weights / influences from the fused forward
+@pytest.mark.parametrize("B,N,d,C,cache", [(64, 10000, 512, 200, True), (37, 1001, 96, 7, False), (9, 300, 64, 5, True),
+                                           (5, 20, 32, 4, False)])
+def test_weights_from_the_fused_forward(dev, ops, O, B, N, d, C, cache):
+    """return_weights=True: the tile kernel writes the scores where the weights go, one in-place pass normalises
+    them with the merge's log-sum-exp (N > 25); N <= 25 keeps the two-kernel path.  `sweights` of util/metric.py:23."""
+    g = torch.Generator().manual_seed(B + N)
+    q, s = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+    sy = torch.randint(0, C, (N,), generator=g).sort().values
+    qd, sd, syd = q.to(dev), s.to(dev), sy.to(dev)
+    bank = ops.SplitBank(sd, syd) if cache else None
+    out, w = ops.nw_head(qd, sd, syd, C, return_weights=True, support_cache=bank)
+    ref, wref = O.nw_head_f64(q, s, sy, C, return_weights=True)
+    close(out, ref.numpy(), rtol=RTOL, atol=3e-5)
+    np.testing.assert_allclose(w.cpu().numpy(), wref.numpy(), rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(w.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+    # with gradients requested too (scores saved for the backward): weights from the saved scores
+    qg = qd.clone().requires_grad_(True)
+    out2, w2 = ops.nw_head(qg, sd, syd, C, return_weights=True)
+    np.testing.assert_allclose(w2.detach().cpu().numpy(), wref.numpy(), rtol=2e-5, atol=1e-9)
+    F.nll_loss(out2, torch.zeros(B, dtype=torch.int64, device=dev)).backward()
+    assert torch.isfinite(qg.grad).all()
+
+
+@pytest.mark.parametrize("B,N,d,C,cache", [(256, 10000, 512, 200, True), (33, 999, 64, 10, False), (4, 20, 16, 3, False)])
+def test_forward_plus_influence_in_one_call(dev, ops, O, B, N, d, C, cache):
+    """nw_fwd_influence_f32: util/metric.py:23-50 on the head's own outputs without a softmax-weight matrix, against
+    the oracle's influence of the oracle's head (fp64 head, the reference's fp32 influence arithmetic)."""
+    g = torch.Generator().manual_seed(7 * B + N)
+    q, s = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+    sy = (torch.arange(N) % C).sort().values
+    qy = torch.randint(0, C, (B,), generator=g)
+    qd, sd, syd = q.to(dev), s.to(dev), sy.to(dev)
+    bank = ops.SplitBank(sd, syd) if cache else None
+    out, infl = ops.nw_head_influence(qd, sd, syd, C, qy.to(dev), support_cache=bank)
+    rows = slice(0, min(B, 32))
+    ref, wref = O.nw_head_f64(q[rows], s, sy, C, return_weights=True)
+    close(out[rows], ref.numpy(), rtol=RTOL, atol=3e-5)
+    iref = O.support_influence_f32(ref.exp().float(), F.one_hot(qy[rows], C).float(), wref.float(), F.one_hot(sy, C).float())
+    got = infl[rows].cpu().numpy()
+    # entries where the support carries most of its class's mass divide by a near-zero p - w: compare where the
+    # denominator keeps at least 1e-3 of p (elsewhere a last-bit difference in p or w moves the value freely)
+    p = ref.exp().float()[torch.arange(len(ref)), qy[rows]][:, None]
+    ok = ((p - wref.float() * (sy[None, :] == qy[rows][:, None])) > 1e-3 * p).numpy() & np.isfinite(iref.numpy())
+    np.testing.assert_allclose(got[ok], iref.numpy()[ok], rtol=2e-4, atol=2e-6)
+    assert ok.mean() > 0.9
+    # and the composite of the two separate calls gives the same numbers
+    out2, w = ops.nw_head(qd, sd, syd, C, return_weights=True, support_cache=bank)
+    comp = ops.support_influence_idx(out2.exp(), qy.to(dev), w, syd)[rows].cpu().numpy()
+    np.testing.assert_allclose(got[ok], comp[ok], rtol=2e-4, atol=2e-6)
