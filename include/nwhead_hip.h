@@ -168,6 +168,17 @@ int nw_support_influence_f32(const float *probs, const int64_t *qy, const float 
                              const int64_t *sy, float *infl,
                              int64_t B, int64_t N, int64_t C, void *stream);
 
+/* Softmax over supports + label aggregation + log of a GIVEN (B,N) score matrix, and its gradient: the tail of
+ * NWHead.forward (nwhead/nw.py:285-289) for score functions that are not built into the kernels (the reference
+ * accepts any callable kernel module, nw.py:256-264: the scores then come from that module, on the device, through
+ * torch autograd; this is the rest).  sy (N,) or (B,N) when labels_batched.
+ *   nw_aggregate_f32      out (B,C), optional lse_out (B,), optional weights_out (B,N)
+ *   nw_aggregate_bwd_f32  gscores (B,N) = W * (dW - sum_j W dW), dW_j = gout[b, sy_j] * exp(-out[b, sy_j]) */
+int nw_aggregate_f32(const float *scores, const int64_t *sy, float *out, float *lse_out, float *weights_out,
+                     int64_t B, int64_t N, int64_t C, int labels_batched, void *stream);
+int nw_aggregate_bwd_f32(const float *scores, const int64_t *sy, const float *lse, const float *out, const float *gout,
+                         float *gscores, int64_t B, int64_t N, int64_t C, int labels_batched, void *stream);
+
 /* Forward + support_influence in one call: nw_fwd_f32's arguments plus
  *   qy (B,) int64 query labels, infl_out (B,N).
  * The fused tile kernel writes the raw scores into infl_out, the merge gives out (log-probabilities) and the

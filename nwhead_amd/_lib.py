@@ -35,6 +35,8 @@ SIGNATURES = {
     "nw_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int]),
     "nw_bwd_f32": (_int, [_p] * 10 + [_p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
     "nw_support_influence_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "nw_aggregate_f32": (_int, [_p] * 5 + [_i64, _i64, _i64, _int, _p]),
+    "nw_aggregate_bwd_f32": (_int, [_p] * 6 + [_i64, _i64, _i64, _int, _p]),
     "nw_fwd_influence_f32": (_int, [_p] * 11 + [_sz, _i64, _i64, _i64, _i64, _int, _p, _p]),
     "nw_topk_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "nw_scale_shift_relu_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),

@@ -104,11 +104,11 @@ __global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
             r = gc * (-0.5f * c * ins2);
         }
         A[b * ld + j] = a;
-        Rs[b * ld + j] = r;
+        if (Rs) Rs[b * ld + j] = r;
     }
     rq_acc = block_sum(rq_acc, red);
     gls_acc = block_sum(gls_acc, red);
-    if (tid == 0) {
+    if (tid == 0 && rq) {
         rq[b] = rq_acc;
         gls[b] = gls_acc;
     }
@@ -529,6 +529,27 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
         else if (hipMemsetAsync(glogit_scale, 0, 4, st) != hipSuccess)
             return NW_ERR_LAUNCH;
     }
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+// gradient of the aggregation alone w.r.t. a given score matrix: the DOT-product form of the coefficient kernel
+// (A = dS) writes it straight into gscores
+extern "C" int nw_aggregate_bwd_f32(const float* scores, const int64_t* sy, const float* lse, const float* out,
+                                    const float* gout, float* gscores, int64_t B, int64_t N, int64_t C,
+                                    int labels_batched, void* stream) {
+    using namespace nw;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B < 0 || N < 0 || C < 0) return NW_ERR_INVALID_ARG;
+    if (B == 0 || N == 0) return NW_OK;
+    if (!scores || !sy || !lse || !out || !gout || !gscores) return NW_ERR_INVALID_ARG;
+    if (B > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    const size_t lds = (16 + (size_t)C) * sizeof(float);
+    if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
+    const unsigned threads = N >= 2048 ? 1024 : 256;
+    hipLaunchKernelGGL(nw_bwd_coeff_kernel<NW_SCORE_DOT>, dim3((unsigned)B), dim3(threads), lds, st, scores, lse, out, gout,
+                       sy, labels_batched, (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, gscores,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, N, C, N);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

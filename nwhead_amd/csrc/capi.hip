@@ -195,3 +195,12 @@ extern "C" int nw_fwd_influence_f32(const float* q, const float* s, const int64_
     if (rc != NW_OK) return rc;
     return nw::launch_influence(out, qy, infl_out, sy, lse, infl_out, B, N, C, st);
 }
+
+extern "C" int nw_aggregate_f32(const float* scores, const int64_t* sy, float* out, float* lse_out, float* weights_out,
+                                int64_t B, int64_t N, int64_t C, int labels_batched, void* stream) {
+    if (B < 0 || N < 0 || C < 0) return NW_ERR_INVALID_ARG;
+    if (B == 0) return NW_OK;
+    if ((!out && C > 0) || (N > 0 && (!scores || !sy))) return NW_ERR_INVALID_ARG;
+    return nw::launch_aggregate(scores, sy, labels_batched, out, lse_out, weights_out, nullptr, nullptr, nullptr, B, N, C,
+                                static_cast<hipStream_t>(stream));
+}

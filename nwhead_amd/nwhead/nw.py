@@ -31,13 +31,19 @@ class NWHead(nn.Module):
 
     def __init__(self, kernel, n_classes):
         super().__init__()
-        if not isinstance(kernel, _ScoreModule):
-            raise NotImplementedError("NWHead runs the score functions built into the HIP kernels "
-                                      "(see get_kernel); custom kernel modules are not supported")
         self.kernel = kernel
         self.n_classes = n_classes
 
     def forward(self, x, sx, sy, return_weights=False, support_norm2=None, support_cache=None):
+        if not isinstance(self.kernel, _ScoreModule):
+            # any other callable kernel module, as the reference accepts (nw.py:256-264, :277-283): its scores (torch
+            # ops on the device, with their autograd history), then the softmax / aggregation / log tail in HIP
+            if return_weights:
+                raise NotImplementedError("return_weights needs one of the built-in score functions (get_kernel)")
+            b = len(x)
+            sxe = sx[None].expand(b, *sx.shape) if sx.dim() == x.dim() else sx       # nw.py:277-279
+            scores = self.kernel(x.unsqueeze(1), sxe).squeeze(1)                      # nw.py:281-283
+            return ops.nw_aggregate(scores, sy, self.n_classes)
         return ops.nw_head(x, sx, sy, self.n_classes, self.kernel.kind, self.kernel._logit_scale(),
                            return_weights=return_weights, support_norm2=support_norm2,
                            support_cache=support_cache)

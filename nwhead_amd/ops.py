@@ -429,6 +429,47 @@ def bn_relu_train(x, bn, relu=True, residual=None, passthrough=False):
     return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, residual, bn, bool(relu), bool(passthrough))
 
 
+class _AggregateFn(torch.autograd.Function):
+    """softmax over supports -> label aggregation -> log(. + 1e-12) of a given score matrix (nw.py:285-289)."""
+
+    @staticmethod
+    def forward(ctx, scores, sy, n_classes):
+        lib = _lib.load()
+        sc = _f32c(scores)
+        syc = sy if (sy.dtype == torch.int64 and sy.is_contiguous()) else sy.detach().to(torch.int64).contiguous()
+        B, N = sc.shape
+        out = torch.empty(B, n_classes, dtype=torch.float32, device=sc.device)
+        lse = torch.empty(B, dtype=torch.float32, device=sc.device)
+        with torch.cuda.device(sc.device):
+            _lib.check(lib.nw_aggregate_f32(_ptr(sc), _ptr(syc), _ptr(out), _ptr(lse), None, B, N, n_classes,
+                                            int(syc.dim() == 2), _stream(sc)), "nw_aggregate_f32")
+        ctx.save_for_backward(sc, syc, lse, out)
+        ctx.C = n_classes
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        sc, syc, lse, out = ctx.saved_tensors
+        B, N = sc.shape
+        g = _f32c(gout)
+        gs = torch.empty_like(sc)
+        with torch.cuda.device(sc.device):
+            _lib.check(lib.nw_aggregate_bwd_f32(_ptr(sc), _ptr(syc), _ptr(lse), _ptr(out), _ptr(g), _ptr(gs), B, N, ctx.C,
+                                                int(syc.dim() == 2), _stream(sc)), "nw_aggregate_bwd_f32")
+        return gs, None, None
+
+
+def nw_aggregate(scores, sy, n_classes):
+    """(B,N) scores from ANY score function (on the device, possibly with a torch autograd history) + labels (N,) or
+    (B,N) -> (B,C) log-probabilities: the softmax / label aggregation / log tail of NWHead.forward, differentiable
+    with respect to the scores."""
+    _need_hip(scores, sy)
+    if scores.dim() != 2 or (sy.dim() == 1 and sy.shape[0] != scores.shape[1]) or (sy.dim() == 2 and sy.shape != scores.shape):
+        raise ValueError("scores must be (B,N) and labels (N,) or (B,N)")
+    return _AggregateFn.apply(scores, sy, int(n_classes))
+
+
 def nw_head_influence(q, s, sy, n_classes, qy, kind="euclidean", logit_scale=None, support_cache=None):
     """NWHead.forward plus util/metric.py:23-50 on its own outputs in one call (no grad): returns
     (out (B,C) log-probabilities, infl (B,N)) with infl[b,j] = log((p - p*w_bj) / (p - w_bj*[sy_j == qy_b])),

@@ -1,0 +1,103 @@
+// Host-only exercise of the C ABI's argument validation (include/nwhead_hip.h) under AddressSanitizer +
+// UndefinedBehaviorSanitizer.  Built by `make -C nwhead_amd/csrc sanitize` from the same sources
+// as libnwhead_hip.so with --cuda-host-only: no device code, no GPU needed -- every call here must be refused (or be a
+// pure host computation) BEFORE anything is launched, with the documented status and without a sanitizer report.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/nwhead_hip.h"
+
+static int failures = 0;
+#define EXPECT(call, want)                                                                  \
+    do {                                                                                    \
+        const long long got_ = (long long)(call);                                          \
+        if (got_ != (long long)(want)) {                                                    \
+            std::printf("FAIL %s:%d  %s = %lld, expected %s\n", __FILE__, __LINE__, #call, got_, #want); \
+            ++failures;                                                                     \
+        }                                                                                   \
+    } while (0)
+
+int main() {
+    std::vector<float> f(4096, 1.f);
+    std::vector<int64_t> y(64, 0);
+    float* F = f.data();
+    int64_t* Y = y.data();
+    char ws[256];
+    EXPECT(nw_abi_version(), NW_ABI_VERSION);
+    EXPECT(std::strcmp(nw_status_string(NW_OK), "ok"), 0);
+    EXPECT(nw_status_string(12345) != nullptr, 1);
+    // sizes: pure host arithmetic, monotone, no overflow for large shapes
+    EXPECT(nw_fwd_workspace_bytes(0, 10, 4, 3), 0);
+    EXPECT(nw_fwd_workspace_bytes(8, 0, 4, 3), 0);
+    EXPECT(nw_fwd_workspace_bytes(8, 64, 128, 10) > 0, 1);
+    EXPECT(nw_fwd_workspace_bytes(4096, 50000, 512, 200) >= (size_t)4096 * 50000 * 4, 1);
+    EXPECT(nw_fwd_workspace_bytes(1 << 20, 1 << 20, 512, 200) > ((size_t)1 << 40), 1);
+    EXPECT(nw_bwd_workspace_bytes(0, 5, 4, 3, 0, 0), 0);
+    EXPECT(nw_bwd_workspace_bytes(256, 10000, 512, 200, 0, 0) > 0, 1);
+    // scores
+    EXPECT(nw_scores_f32(F, F, F, -1, 4, 4, NW_SCORE_EUCLIDEAN, nullptr, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_scores_f32(F, F, F, 4, 4, 4, 99, nullptr, 0, nullptr), NW_ERR_UNSUPPORTED);
+    EXPECT(nw_scores_f32(F, F, F, 0, 4, 4, NW_SCORE_EUCLIDEAN, nullptr, 0, nullptr), NW_OK);
+    EXPECT(nw_scores_f32(nullptr, F, F, 4, 4, 4, NW_SCORE_EUCLIDEAN, nullptr, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_scores_f32(F, F, F, 4, 4, 4, NW_SCORE_CLIP, nullptr, 0, nullptr), NW_ERR_INVALID_ARG);
+    // forward
+    EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, -1, 4, 4, 3,
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3, -3,
+                      nullptr, 0, 0, nullptr), NW_ERR_UNSUPPORTED);
+    EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3,
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_fwd_f32(nullptr, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3,
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3,
+                      NW_SCORE_CLIP, nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3,
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 1, nullptr), NW_ERR_INVALID_ARG);   // batched labels, shared support
+    EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, nullptr, 0, 0, 4, 4, 3,
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_OK);                // B == 0
+    EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 8, 64, 16, 3,
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_WORKSPACE);     // fused path, workspace too small
+    EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, nullptr, 0, 8, 64, 16, 3,
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_WORKSPACE);
+    // partials / merge
+    EXPECT(nw_fwd_partial_f32(F, F, Y, nullptr, nullptr, nullptr, nullptr, F, F, ws, sizeof ws, 4, 4, 4, 3,
+                              NW_SCORE_EUCLIDEAN, nullptr, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_fwd_partial_f32(F, F, Y, nullptr, nullptr, nullptr, F, F, F, ws, 8, 8, 64, 16, 3, NW_SCORE_EUCLIDEAN,
+                              nullptr, nullptr), NW_ERR_WORKSPACE);
+    EXPECT(nw_merge_finalize_f32(F, F, F, F, -1, 4, 3, 4, 4, 12, nullptr, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_merge_finalize_f32(F, F, F, nullptr, 2, 4, 3, 4, 4, 12, nullptr, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_merge_finalize_f32(F, F, F, F, 2, 4, 3, 4, 4, 12, Y, 0, nullptr), NW_ERR_INVALID_ARG);  // window without width
+    EXPECT(nw_merge_finalize_f32(F, F, F, F, 2, 0, 3, 4, 4, 12, nullptr, 0, nullptr), NW_OK);
+    // backward
+    EXPECT(nw_bwd_f32(F, F, Y, F, F, F, F, F, F, nullptr, ws, sizeof ws, 4, 4, 4, 3, 77, nullptr, 0, 0, nullptr), NW_ERR_UNSUPPORTED);
+    EXPECT(nw_bwd_f32(F, F, Y, F, F, F, F, nullptr, F, nullptr, ws, sizeof ws, 4, 4, 4, 3, NW_SCORE_EUCLIDEAN, nullptr, 0, 0,
+                      nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bwd_f32(F, F, Y, F, F, F, F, F, F, nullptr, ws, 8, 4, 4, 4, 3, NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr),
+           NW_ERR_WORKSPACE);
+    EXPECT(nw_bwd_f32(F, F, Y, F, F, F, F, F, F, nullptr, ws, sizeof ws, 4, 4, 4, 3, NW_SCORE_CLIP, nullptr, 0, 0, nullptr),
+           NW_ERR_INVALID_ARG);
+    // split rows, norms, influence, top-k, aggregate
+    EXPECT(nw_split_rows_f16x2(F, F, F, F, 4, 48, nullptr), NW_ERR_UNSUPPORTED);      // d % 32 != 0
+    EXPECT(nw_split_rows_f16x2(F, F, F, F, -1, 32, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_split_rows_f16x2(nullptr, F, F, F, 4, 32, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_split_rows_f16x2(F + 1, F, F, F, 4, 32, nullptr), NW_ERR_INVALID_ARG);  // misaligned
+    EXPECT(nw_split_rows_f16x2(F, F, F, F, 0, 32, nullptr), NW_OK);
+    EXPECT(nw_row_norm2_f32(F, F, -2, 4, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_row_norm2_f32(nullptr, F, 2, 4, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_support_influence_f32(F, Y, F, Y, F, -1, 4, 3, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_support_influence_f32(F, Y, nullptr, Y, F, 2, 4, 3, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_support_influence_f32(F, Y, F, Y, F, 0, 4, 3, nullptr), NW_OK);
+    EXPECT(nw_fwd_influence_f32(F, F, Y, nullptr, nullptr, nullptr, nullptr, F, nullptr, F, ws, sizeof ws, 4, 8, 4, 3,
+                                NW_SCORE_EUCLIDEAN, nullptr, nullptr), NW_ERR_INVALID_ARG);   // no query labels
+    EXPECT(nw_fwd_influence_f32(F, F, Y, nullptr, nullptr, nullptr, Y, F, nullptr, F, ws, 8, 4, 8, 4, 3,
+                                NW_SCORE_EUCLIDEAN, nullptr, nullptr), NW_ERR_WORKSPACE);
+    EXPECT(nw_topk_f32(nullptr, Y, nullptr, 2, 8, 2, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_topk_f32(F, Y, nullptr, -1, 8, 2, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_aggregate_f32(nullptr, Y, F, nullptr, nullptr, 2, 8, 3, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_aggregate_f32(F, Y, F, nullptr, nullptr, -2, 8, 3, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_aggregate_bwd_f32(F, Y, F, F, F, nullptr, 2, 8, 3, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_aggregate_bwd_f32(F, Y, F, F, F, F, 2, 0, 3, 0, nullptr), NW_OK);
+    std::printf(failures ? "abi_args: %d FAILED\n" : "abi_args: all argument checks refused as documented\n", failures);
+    return failures ? 1 : 0;
+}

@@ -60,3 +60,16 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("the oracle", ""), f"{f} references oracle/"
+
+
+def test_argument_validation_under_address_and_ub_sanitizers():
+    """the C ABI's argument validation, built host-only from the library's own sources with
+    -fsanitize=address,undefined (`make -C nwhead_amd/csrc sanitize`; no device code, a HIP runtime stand-in that
+    answers "no device") and run: every malformed call is refused with its documented status, no sanitizer report."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "nwhead_amd", "csrc"), "sanitize", "-j4"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "all argument checks refused as documented" in r.stdout
+    assert "runtime error" not in r.stdout + r.stderr and "AddressSanitizer" not in r.stdout + r.stderr

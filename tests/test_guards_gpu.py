@@ -149,3 +149,35 @@ def test_rccl_two_ranks_sharded_predict():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count("rccl-ok") == 2
+
+
+def test_custom_kernel_module_runs_through_the_aggregation_kernels(dev):
+    """The reference's NWHead takes any callable kernel (nw.py:256-264).  A module that is not one of the built-in
+    score functions computes its scores with torch ops on the device; softmax, label aggregation and log -- and
+    their gradient -- run in HIP (nw_aggregate_f32 / nw_aggregate_bwd_f32)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from nwhead_amd.nwhead.nw import NWHead
+
+    class L1(nn.Module):
+        def forward(self, x, y):
+            return -torch.cdist(x, y, p=1.0)
+    g = torch.Generator().manual_seed(0)
+    for B, N, d, C, batched in ((7, 40, 16, 5, False), (6, 12, 8, 4, True), (300, 3000, 8, 11, False)):
+        x0 = torch.randn(B, d, generator=g)
+        s0 = torch.randn(B, N, d, generator=g) if batched else torch.randn(N, d, generator=g)
+        sy = torch.randint(0, C, (B, N) if batched else (N,), generator=g)
+        t = torch.randint(0, C, (B,), generator=g)
+        x64, s64 = x0.double().requires_grad_(True), s0.double().requires_grad_(True)
+        sc = -torch.cdist(x64[:, None], s64 if batched else s64[None].expand(B, N, d), p=1.0).squeeze(1)
+        oh = F.one_hot(sy, C).double()
+        p = torch.einsum("bn,bnc->bc", sc.softmax(-1), oh) if batched else sc.softmax(-1) @ oh
+        ref = torch.log(p + 1e-12)
+        F.nll_loss(ref, t).backward()
+        x, s = x0.to(dev).requires_grad_(True), s0.to(dev).requires_grad_(True)
+        out = NWHead(L1(), C)(x, s, sy.to(dev))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=3e-5)
+        F.nll_loss(out, t.to(dev)).backward()
+        for got, want in ((x.grad, x64.grad), (s.grad, s64.grad)):
+            scale = max(float(want.abs().max()), 1e-3)
+            np.testing.assert_allclose(got.cpu().numpy() / scale, want.numpy() / scale, rtol=1e-4, atol=1e-4)
