@@ -218,6 +218,32 @@ int nw_topk_f32(const float *scores, int64_t *idx_out, float *val_out,
 int nw_scale_shift_relu_f32(const float *x, const float *scale, const float *shift, float *out,
                             int64_t n, int64_t c, int64_t hw, int64_t x_batch_stride, int relu,
                             void *stream);
+/* The same followed by a 2x2 / stride-2 average pool (floor sizes): out (n, c, h/2, w/2).  The transitions of the
+ * DenseNets (norm - relu - conv 1x1 - avgpool, model/densenet.py:82-91, model/densenet3.py:25-35): the pool commutes
+ * with the bias-free 1x1 convolution, so the folded inference copy pools first and convolves a quarter of the pixels. */
+int nw_scale_shift_relu_avgpool2_f32(const float *x, const float *scale, const float *shift, float *out,
+                                     int64_t n, int64_t c, int64_t h, int64_t w, int64_t x_batch_stride,
+                                     int relu, void *stream);
+
+/* 1x1 convolution of the folded inference backbones with its neighbours fused in, on the fp32 matrix cores
+ * (v_mfma_f32_16x16x4_f32: exact fp32 multiply-adds).  Replaces, in DenseNet's dense layers and transitions
+ * (model/densenet.py:33-60 norm1-relu1-conv1-norm2-relu2, :82-91 norm-relu-conv) and CIFAR_DenseNet's
+ * (model/densenet3.py:10-35), the scale-shift-ReLU pass, the GEMM, the bias add and the ReLU pass:
+ *     out[n, co, p] = post( bias[co] + sum_ci W[co, ci] * pre(x[n, ci, p]) )
+ *   x          (n, >= cin, hw) fp32, plane contiguous, batch stride x_batch_stride floats (a channel prefix of a
+ *              dense-block slab is fine)
+ *   pre_scale / pre_shift  optional (cin,): pre(v) = a_ci v + b_ci (eval-mode BatchNorm), then max(., 0) if pre_relu
+ *   w_t        (cin rounded up to 16, cout) fp32: the weight TRANSPOSED, rows past cin ZERO (made once, when the
+ *              inference copy is folded); cout % 4 == 0.  cout % 128 == 0 and hw % 4 == 0 select the LDS-DMA kernel
+ *   workspace  nw_conv1x1_workspace_bytes(n, cin, cout, hw) bytes (partial tiles when K is split over workgroups:
+ *              small planes); may be NULL when that is 0
+ *   bias       optional (cout,) (the BatchNorm that FOLLOWS the convolution, folded); post_relu: max(., 0)
+ *   out        (n, cout, hw), batch stride out_batch_stride floats */
+size_t nw_conv1x1_workspace_bytes(int64_t n, int64_t cin, int64_t cout, int64_t hw);
+int nw_conv1x1_f32(const float *x, int64_t x_batch_stride, const float *pre_scale, const float *pre_shift,
+                   int pre_relu, const float *w_t, const float *bias, int post_relu, float *out,
+                   int64_t out_batch_stride, void *workspace, size_t workspace_bytes,
+                   int64_t n, int64_t cin, int64_t cout, int64_t hw, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ ReLU) in front of / behind the backbones' convolutions, forward and

@@ -37,6 +37,32 @@ __global__ __launch_bounds__(256) void nw_scale_shift_kernel(const float* __rest
     }
 }
 
+// max(a_c x + b_c, 0) followed by a 2x2 / stride-2 average pool, one output pixel per thread (two 8-byte reads).
+// In the transitions of the folded DenseNets (norm - relu - conv 1x1 - avgpool, model/densenet.py:82-91,
+// model/densenet3.py:25-35) the pool commutes with the bias-free 1x1 convolution, so it runs FIRST and the
+// convolution sees a quarter of the pixels.  Output (n, C, h/2, w/2) contiguous (floor, like torch's avg_pool2d).
+__global__ __launch_bounds__(256) void nw_scale_shift_relu_pool2_kernel(const float* __restrict__ x,
+                                                                         const float* __restrict__ scale,
+                                                                         const float* __restrict__ shift,
+                                                                         float* __restrict__ out, int64_t total, int C,
+                                                                         int h, int w, int64_t x_batch_stride, int relu) {
+    const int ho = h / 2, wo = w / 2;
+    const float lo = relu ? 0.f : -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int xo = (int)(i % wo);
+        const int64_t t = i / wo;
+        const int yo = (int)(t % ho);
+        const int64_t plane = t / ho;
+        const int64_t n = plane / C;
+        const int c = (int)(plane - n * C);
+        const float a = scale[c], b = shift[c];
+        const float* p = x + n * x_batch_stride + ((int64_t)c * h + 2 * yo) * w + 2 * xo;
+        const float v0 = fmaxf(__builtin_fmaf(p[0], a, b), lo), v1 = fmaxf(__builtin_fmaf(p[1], a, b), lo);
+        const float v2 = fmaxf(__builtin_fmaf(p[w], a, b), lo), v3 = fmaxf(__builtin_fmaf(p[w + 1], a, b), lo);
+        out[i] = ((v0 + v1) + (v2 + v3)) * 0.25f;
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // Training-mode BatchNorm2d (+ ReLU), forward and backward, one workgroup per channel.
@@ -235,6 +261,23 @@ extern "C" int nw_scale_shift_relu_f32(const float* x, const float* scale, const
     if (relu) { if (vec) NW_SS(true, true); else NW_SS(true, false); }
     else { if (vec) NW_SS(false, true); else NW_SS(false, false); }
 #undef NW_SS
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_scale_shift_relu_avgpool2_f32(const float* x, const float* scale, const float* shift, float* out,
+                                                int64_t n, int64_t c, int64_t h, int64_t w, int64_t x_batch_stride,
+                                                int relu, void* stream) {
+    using namespace nw;
+    if (n < 0 || c < 0 || h < 0 || w < 0 || x_batch_stride < c * h * w || c > 0x7fffffffLL || h > 0x7fffffffLL || w > 0x7fffffffLL)
+        return NW_ERR_INVALID_ARG;
+    const int64_t total = n * c * (h / 2) * (w / 2);
+    if (total == 0) return NW_OK;
+    if (!x || !scale || !shift || !out) return NW_ERR_INVALID_ARG;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(nw_scale_shift_relu_pool2_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       scale, shift, out, total, (int)c, (int)h, (int)w, x_batch_stride, relu);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

@@ -112,6 +112,7 @@ class ResNet(nn.Module):
 # ----------------------------------------------------------------------------- CIFAR pre-act ResNet
 DENSE_PASSTHROUGH = True        # the running concatenation passes through norm1's autograd node (see _DenseBlock.forward)
 DENSE_INCREMENTAL_CAT = True    # dense blocks extend one running concatenation (see _DenseBlock.forward)
+FUSED_CONV1X1 = True            # folded inference copies: 1x1 convolutions with their BatchNorm / ReLU neighbours as one kernel (Conv1x1Fused)
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
 
 
@@ -186,7 +187,9 @@ class _DenseLayer(nn.Sequential):
 
     def forward(self, x):
         # relu1 must not run in place on a slab/concat that later layers re-read
-        if isinstance(self.norm1, ScaleShiftReLU):       # folded inference copy (fold_batchnorm)
+        if isinstance(self.conv1, Conv1x1Fused):         # folded inference copy: norm1-relu1-conv1-norm2-relu2 in one kernel
+            return self.conv2(self.conv1(x))
+        if isinstance(self.norm1, ScaleShiftReLU):       # folded inference copy without the fused 1x1 (FUSED_CONV1X1 off)
             return self.conv2(self.relu2(self.conv1(self.norm1(x))))
         return self.after_norm1(_bn_relu(self.norm1, x))
 
@@ -241,6 +244,8 @@ class _Transition(nn.Sequential):
                                       ("conv", _conv(cin, cout, 1)), ("pool", nn.AvgPool2d(2, 2))]))
 
     def forward(self, x):
+        if isinstance(self.conv, Conv1x1Fused):          # folded inference copy: norm-relu-pool, then the 1x1 convolution
+            return self.pool(self.conv(x))                #   (the pool module is the identity when it ran first)
         return self.pool(self.conv(_bn_relu(self.norm, x)))
 
 
@@ -293,6 +298,54 @@ class ScaleShiftReLU(nn.Module):
         return F.relu(y) if self.relu else y
 
 
+class Conv1x1Fused(nn.Module):
+    """[eval-mode BatchNorm -> ReLU ->] 1x1 convolution [-> folded BatchNorm bias -> ReLU] as ONE kernel on the
+    MI355X (ops.conv1x1, csrc/conv1x1.hip: fp32 matrix cores); on CPU tensors the same torch ops the reference
+    backbone runs.  Built by fold_batchnorm for DenseNet's dense layers (norm1-relu1-conv1-norm2-relu2) and
+    transitions (norm-relu-conv) and their CIFAR counterparts.  Inference only."""
+
+    def __init__(self, conv, pre_bn=None, post_bn=None, post_relu=False, pool_first=False):
+        super().__init__()
+        # pool_first: the module is followed by a 2x2 average pool and has no bias, BatchNorm or ReLU behind the
+        # convolution (a DenseNet transition): pool and convolution commute, forward() returns avg_pool2d(conv(..), 2)
+        # computed as conv(avg_pool2d(..)) -- a quarter of the pixels in the matrix product
+        assert not pool_first or (post_bn is None and not post_relu and conv.bias is None and pre_bn is not None)
+        self.pool_first = pool_first
+        assert conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+        w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
+        b = conv.bias.detach() if conv.bias is not None else None
+        if post_bn is not None:                      # BatchNorm behind the convolution: into weight and bias
+            a = post_bn.weight.detach() * torch.rsqrt(post_bn.running_var.detach() + post_bn.eps)
+            w = w * a[:, None]
+            b = post_bn.bias.detach() + ((b if b is not None else 0) - post_bn.running_mean.detach()) * a
+        self.register_buffer("weight", w.contiguous().clone())            # (cout, cin): the CPU path
+        wt = w.t().contiguous()
+        pad = (-wt.shape[0]) % 16                    # the kernel's operand: (cin rounded up to 16, cout), zero rows behind
+        self.register_buffer("weight_t", torch.cat((wt, wt.new_zeros(pad, wt.shape[1]))).contiguous() if pad else wt.clone())
+        self.register_buffer("bias", None if b is None else b.clone())
+        if pre_bn is not None:
+            a = pre_bn.weight.detach() * torch.rsqrt(pre_bn.running_var.detach() + pre_bn.eps)
+            self.register_buffer("pre_scale", a.clone())
+            self.register_buffer("pre_shift", (pre_bn.bias.detach() - pre_bn.running_mean.detach() * a).clone())
+        else:
+            self.pre_scale = self.pre_shift = None
+        self.pre_relu, self.post_relu = pre_bn is not None, post_relu
+
+    def forward(self, x):
+        if x.is_cuda and self.weight_t.shape[1] % 4 == 0:
+            from .. import ops
+            if self.pool_first:
+                return ops.conv1x1(ops.scale_shift_relu_avgpool2(x, self.pre_scale, self.pre_shift), self.weight_t,
+                                   cin=self.weight.shape[1])
+            return ops.conv1x1(x, self.weight_t, self.bias, self.pre_scale, self.pre_shift, self.pre_relu, self.post_relu,
+                               cin=self.weight.shape[1])
+        if self.pre_scale is not None:
+            x = F.relu(x * self.pre_scale.view(1, -1, 1, 1) + self.pre_shift.view(1, -1, 1, 1))
+        y = F.conv2d(x, self.weight[:, :, None, None], self.bias)
+        y = F.relu(y) if self.post_relu else y
+        return F.avg_pool2d(y, 2) if self.pool_first else y
+
+
 # ----------------------------------------------------------------------------- CIFAR DenseNet
 class CifarBottleneck(nn.Module):
     """bn1-relu-conv1(1x1,4k)-bn2-relu-conv2(3x3,k), output = cat(new, x); densenet3.py:10-22."""
@@ -303,6 +356,8 @@ class CifarBottleneck(nn.Module):
         self.bn2, self.conv2 = nn.BatchNorm2d(4 * growth_rate), _conv(4 * growth_rate, growth_rate, 3, 1, 1)
 
     def forward(self, x):
+        if isinstance(self.conv1, Conv1x1Fused):         # folded inference copy: bn1-relu-conv1-bn2-relu in one kernel
+            return torch.cat([self.conv2(self.conv1(x)), x], 1)
         y = self.conv2(_bn_relu(self.bn2, self.conv1(_bn_relu(self.bn1, x))))
         return torch.cat([y, x], 1)
 
@@ -313,6 +368,9 @@ class CifarTransition(nn.Module):
         self.bn, self.conv = nn.BatchNorm2d(in_planes), _conv(in_planes, out_planes, 1)
 
     def forward(self, x):
+        if isinstance(self.conv, Conv1x1Fused):          # folded inference copy: bn-relu-pool, then the 1x1 convolution
+            y = self.conv(x)
+            return y if self.conv.pool_first else F.avg_pool2d(y, 2)
         return F.avg_pool2d(self.conv(_bn_relu(self.bn, x)), 2)
 
 
@@ -445,14 +503,29 @@ def fold_batchnorm(model):
             f = mod.features
             f.conv0, f.norm0 = _fold_pair(f.conv0, f.norm0), nn.Identity()
             f.norm5 = ScaleShiftReLU(f.norm5)   # DenseNet.forward's F.relu on top is then the identity
+        elif isinstance(mod, _DenseLayer) and FUSED_CONV1X1:
+            mod.conv1 = Conv1x1Fused(mod.conv1, pre_bn=mod.norm1, post_bn=mod.norm2, post_relu=True)
+            mod.norm1 = mod.relu1 = mod.norm2 = mod.relu2 = nn.Identity()
         elif isinstance(mod, _DenseLayer):
             mod.conv1, mod.norm2 = _fold_pair(mod.conv1, mod.norm2), nn.Identity()
             mod.norm1, mod.relu1 = ScaleShiftReLU(mod.norm1), nn.Identity()
+        elif isinstance(mod, _Transition) and FUSED_CONV1X1:
+            pool2 = isinstance(mod.pool, nn.AvgPool2d) and mod.pool.kernel_size in (2, (2, 2)) and mod.pool.stride in (2, (2, 2)) \
+                and mod.pool.padding in (0, (0, 0)) and not mod.pool.ceil_mode
+            mod.conv = Conv1x1Fused(mod.conv, pre_bn=mod.norm, pool_first=pool2 and mod.conv.bias is None)
+            mod.norm = mod.relu = nn.Identity()
+            if mod.conv.pool_first:
+                mod.pool = nn.Identity()
         elif isinstance(mod, _Transition):
             mod.norm, mod.relu = ScaleShiftReLU(mod.norm), nn.Identity()
+        elif isinstance(mod, CifarBottleneck) and FUSED_CONV1X1:
+            mod.conv1 = Conv1x1Fused(mod.conv1, pre_bn=mod.bn1, post_bn=mod.bn2, post_relu=True)
+            mod.bn1 = mod.bn2 = nn.Identity()
         elif isinstance(mod, (PreActBlock, CifarBottleneck)):
             mod.conv1, mod.bn2 = _fold_pair(mod.conv1, mod.bn2), nn.Identity()
             mod.bn1 = ScaleShiftReLU(mod.bn1)
+        elif isinstance(mod, CifarTransition) and FUSED_CONV1X1:
+            mod.conv, mod.bn = Conv1x1Fused(mod.conv, pre_bn=mod.bn, pool_first=mod.conv.bias is None), nn.Identity()
         elif isinstance(mod, (CifarTransition, CIFAR_DenseNet)):
             mod.bn = ScaleShiftReLU(mod.bn)
     for mod in m.modules():

@@ -344,6 +344,49 @@ def scale_shift_relu(x, scale, shift, relu=True):
     return out
 
 
+def scale_shift_relu_avgpool2(x, scale, shift, relu=True):
+    """avg_pool2d(max(x * scale[c] + shift[c], 0), 2) in one pass: (n, c, h, w) -> (n, c, h // 2, w // 2)."""
+    _need_hip(x, scale, shift)
+    x, bstride = _plane_view(x)
+    n, c, h, w = x.shape
+    out = torch.empty(n, c, h // 2, w // 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().nw_scale_shift_relu_avgpool2_f32(_ptr(x), _ptr(_f32c(scale)), _ptr(_f32c(shift)), _ptr(out), n, c, h, w,
+                                                                bstride, int(bool(relu)), _stream(x)),
+                   "nw_scale_shift_relu_avgpool2_f32")
+    return out
+
+
+def conv1x1(x, weight_t, bias=None, pre_scale=None, pre_shift=None, pre_relu=False, post_relu=False, cin=None):
+    """out = post(bias + W . pre(x)) for an (n, c, h, w) fp32 activation whose (c, h, w) part is contiguous (a channel
+    prefix of a wider slab is fine): pre = optional per-channel scale/shift (eval-mode BatchNorm) + ReLU, W given
+    transposed as weight_t (cin rounded up to 16 with zero rows, cout), post = optional ReLU.  One matrix-core
+    kernel (nw_conv1x1_f32)."""
+    _need_hip(x, weight_t, bias, pre_scale, pre_shift)
+    x, bstride = _plane_view(x)
+    n, c, h, w = x.shape
+    cin = c if cin is None else int(cin)
+    cout = weight_t.shape[1]
+    if c != cin or weight_t.shape[0] != (cin + 15) // 16 * 16 or not weight_t.is_contiguous():
+        raise ValueError(f"conv1x1: input has {c} channels, weight_t must be ({(c + 15) // 16 * 16}, cout) contiguous")
+    lib = _lib.load()
+    out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.nw_conv1x1_workspace_bytes(n, cin, cout, h * w)
+    ws = _workspace(ws_bytes, x.device) if ws_bytes else None
+    with torch.cuda.device(x.device):
+        _lib.check(lib.nw_conv1x1_f32(_ptr(x), bstride, _ptr(pre_scale), _ptr(pre_shift), int(bool(pre_relu)),
+                                      _ptr(weight_t), _ptr(bias), int(bool(post_relu)), _ptr(out), cout * h * w,
+                                      _ptr(ws), ws_bytes, n, cin, cout, h * w, _stream(x)), "nw_conv1x1_f32")
+    return out
+
+
+def pad_rows16(w_t):
+    """(cin, cout) -> (cin rounded up to 16, cout) with zero rows: the weight operand of conv1x1."""
+    cin = w_t.shape[0]
+    pad = (-cin) % 16
+    return w_t.contiguous() if pad == 0 else torch.cat((w_t, w_t.new_zeros(pad, w_t.shape[1]))).contiguous()
+
+
 def _plane_view(x):
     """(n, c, h, w) fp32 with a contiguous (c, h, w) part (batch stride free) -> (tensor, batch stride)."""
     n, c, h, w = x.shape

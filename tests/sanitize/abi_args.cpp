@@ -98,6 +98,22 @@ int main() {
     EXPECT(nw_aggregate_f32(F, Y, F, nullptr, nullptr, -2, 8, 3, 0, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_aggregate_bwd_f32(F, Y, F, F, F, nullptr, 2, 8, 3, 0, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_aggregate_bwd_f32(F, Y, F, F, F, F, 2, 0, 3, 0, nullptr), NW_OK);
+    // fused 1x1 convolution
+    EXPECT(nw_conv1x1_f32(F, 64, nullptr, nullptr, 0, F, nullptr, 0, F, 64, nullptr, 0, -1, 4, 4, 16, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_conv1x1_f32(nullptr, 64, nullptr, nullptr, 0, F, nullptr, 0, F, 64, nullptr, 0, 1, 4, 4, 16, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_conv1x1_f32(F, 64, F, nullptr, 1, F, nullptr, 0, F, 64, nullptr, 0, 1, 4, 4, 16, nullptr), NW_ERR_INVALID_ARG);  // scale without shift
+    EXPECT(nw_conv1x1_f32(F, 64, nullptr, nullptr, 0, F, nullptr, 0, F, 64, nullptr, 0, 1, 4, 6, 16, nullptr), NW_ERR_UNSUPPORTED);  // cout % 4
+    EXPECT(nw_conv1x1_f32(F, 8, nullptr, nullptr, 0, F, nullptr, 0, F, 64, nullptr, 0, 1, 4, 4, 16, nullptr), NW_ERR_INVALID_ARG);   // batch stride < c*hw
+    EXPECT(nw_conv1x1_f32(F, 64, nullptr, nullptr, 0, F, nullptr, 0, F, 64, nullptr, 0, 0, 4, 4, 16, nullptr), NW_OK);
+    EXPECT(nw_conv1x1_workspace_bytes(64, 992, 128, 49) > 0, 1);               // 7x7 planes: 49 column tiles, K split
+    EXPECT(nw_conv1x1_workspace_bytes(64, 992, 100, 49), 0);                   // cout % 128 != 0: the generic kernel, no K split
+    EXPECT(nw_scale_shift_relu_avgpool2_f32(F, F, F, F, 1, 4, 4, 4, 8, 1, nullptr), NW_ERR_INVALID_ARG);   // batch stride < c*h*w
+    EXPECT(nw_scale_shift_relu_avgpool2_f32(nullptr, F, F, F, 1, 4, 4, 4, 64, 1, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_scale_shift_relu_avgpool2_f32(F, F, F, F, 1, 4, 1, 4, 64, 1, nullptr), NW_OK);               // h / 2 == 0
+    EXPECT(nw_conv1x1_workspace_bytes(64, 992, 128, 196) > 0, 1);              // 14x14: K split, partial tiles
+    EXPECT(nw_conv1x1_workspace_bytes(64, 64, 128, 3136), 0);
+    EXPECT(nw_conv1x1_f32(F, 992 * 196, nullptr, nullptr, 0, F, nullptr, 0, F, 128 * 196, nullptr, 0, 2, 992, 128, 196, nullptr),
+           NW_ERR_WORKSPACE);
     std::printf(failures ? "abi_args: %d FAILED\n" : "abi_args: all argument checks refused as documented\n", failures);
     return failures ? 1 : 0;
 }

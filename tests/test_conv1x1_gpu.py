@@ -1,0 +1,73 @@
+"""The fused 1x1 convolution of the folded inference backbones (csrc/conv1x1.hip: eval-mode BatchNorm -> ReLU -> 1x1
+conv on the fp32 matrix cores -> folded BatchNorm bias -> ReLU) against the same torch ops in fp64 on the host, then
+the folded DenseNets against their plain eval-mode forward."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,slab,pre,bias,post", [
+    (3, 64, 128, 56, 56, 0, True, True, True),        # dense layer of block 1: wide tiles
+    (2, 100, 128, 14, 14, 28, True, True, True),      # cin % 16 != 0, channel prefix of a wider slab, narrow tiles
+    (5, 37, 40, 7, 7, 3, True, True, True),           # 7x7 planes (hw % 4 != 0: scalar loads), partial M tile
+    (2, 256, 128, 28, 28, 0, True, False, False),     # transition: no bias, no ReLU behind
+    (1, 16, 260, 8, 8, 0, False, True, False),        # plain 1x1 convolution, three M tiles (the last one partial)
+    (64, 992, 128, 7, 7, 32, True, True, True),       # last dense layer of DenseNet-121 at batch 64
+    (1, 3, 4, 1, 1, 0, False, False, True),
+    (64, 64, 128, 56, 56, 32, True, True, True),      # LDS-DMA kernel, 128-column tiles (first dense layer at batch 64)
+    (3, 200, 256, 12, 12, 8, True, True, False),      # LDS-DMA kernel: two M tiles, 64-column tiles spanning images, K split
+    (2, 17, 128, 6, 6, 0, False, False, False),       # one partial K stage, 72 columns
+    (1, 1000, 128, 2, 2, 0, True, True, True),        # a single 4-column tile, K split 15 ways
+])
+def test_conv1x1_against_torch_fp64(n, cin, cout, h, w, slab, pre, bias, post):
+    from nwhead_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n * 1000 + cin)
+    full = torch.randn(n, cin + slab, h, w, generator=g)
+    x = full[:, :cin]                                              # prefix view: batch stride (cin + slab) * h * w
+    wgt = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    a, s = (torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3) if pre else (None, None)
+    ref = x.double()
+    if pre:
+        ref = F.relu(ref * a.double().view(1, -1, 1, 1) + s.double().view(1, -1, 1, 1))
+    ref = F.conv2d(ref, wgt.double()[:, :, None, None], None if b is None else b.double())
+    if post:
+        ref = F.relu(ref)
+    mv = lambda t: None if t is None else t.to(dev)
+    out = ops.conv1x1(full.to(dev)[:, :cin], ops.pad_rows16(wgt.t().contiguous().to(dev)), mv(b), mv(a), mv(s), pre_relu=pre,
+                      post_relu=post)
+    assert out.shape == (n, cout, h, w)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-6 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("name,side,batch", [("densenet121", 64, 3), ("densenet121", 224, 2), ("CIFAR_DenseNet121", 32, 4)])
+def test_folded_densenet_with_fused_1x1(name, side, batch):
+    """fold_batchnorm builds Conv1x1Fused for every dense layer and transition; same features as the plain eval-mode
+    network (fp32 re-association only), and as the folded copy without the fused kernel."""
+    import nwhead_amd.model.backbones as bb
+    from nwhead_amd.model import fold_batchnorm, load_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = load_model(name).to(dev)
+    net.train()
+    with torch.no_grad():
+        net(torch.randn(4, 3, side, side, device=dev))              # move the running statistics off their init
+    net.eval()
+    x = torch.randn(batch, 3, side, side, device=dev)
+    folded = fold_batchnorm(net)
+    assert sum(isinstance(m, bb.Conv1x1Fused) for m in folded.modules()) >= 58
+    bb.FUSED_CONV1X1 = False
+    try:
+        plain_fold = fold_batchnorm(net)
+    finally:
+        bb.FUSED_CONV1X1 = True
+    with torch.no_grad():
+        want, got, got2 = net(x), folded(x), plain_fold(x)
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(got.cpu().numpy(), got2.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
