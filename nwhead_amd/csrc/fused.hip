@@ -422,7 +422,11 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
     // 32 queries x 16 tile lanes per workgroup when a query has few tiles (a shard of the bank), else 16 x 32;
     // below 512 queries one workgroup per query (T: 256 workgroups, one per CU)
     int mq = 1;
-    if (B >= 512 && !env_flag("NW_MERGE_PER_QUERY")) {
+    static const int force_mq = [] { const char* e = getenv("NW_MERGE_MQ"); return e ? atoi(e) : 0; }();   // timing experiments
+    if (force_mq == 1 || force_mq == 16 || force_mq == 32) {
+        mq = force_mq;
+        if (lds_bytes(mq, true) > cap) mq = 1;
+    } else if (B >= 512 && !env_flag("NW_MERGE_PER_QUERY")) {
         mq = n_stiles >= 128 ? 16 : 32;
         if (lds_bytes(mq, true) > cap) mq = 16;
         if (lds_bytes(mq, true) > cap) mq = 1;

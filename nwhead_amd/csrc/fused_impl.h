@@ -43,6 +43,11 @@ namespace {
 // MODE_F16Q: as MODE_F16, but q holds the caller's RAW fp32 rows: the consumer waves compute the row scales and
 //            norms in their prologue and split their query fragments in registers (tile_f16.h, QRAW) -- the
 //            one-workgroup-per-tile kernel of small grids (T) runs without a query-split launch in front
+//   (Measured and dropped, T shape: the query fragments RESIDENT in the consumer waves -- high halves in 64 VGPRs, low
+//    halves parked in LDS, only support rows in the stage ring, one set of support fragments refilled block by block.
+//    29 % fewer bytes through the loop's L2 -> LDS stream, but getting the rows into operand shape cost 11.5 k cycles
+//    per workgroup (fragment-shaped global loads, or sixteen 8 KB DMA steps each paying a third of the DMA latency)
+//    and the single-buffered loop ran 750 cycles per stage against 530: 18.5-19.4 us against 16.4.)
 enum { MODE_REG = 0, MODE_DMA = 1, MODE_DMA_SN = 2, MODE_F16 = 3, MODE_F16Q = 4 };
 constexpr bool mode_is_f16(int m) { return m == MODE_F16 || m == MODE_F16Q; }
 
