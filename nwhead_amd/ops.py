@@ -10,8 +10,47 @@ from . import _lib
 from ._lib import SCORE_KINDS, NWHipError
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor):
+    """The current HIP stream of t's device as the integer handle the C ABI takes (torch.cuda.current_stream builds
+    a Python Stream object per call: ~4 us; the raw getter is what it wraps)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _OnDevice:
+    """`with torch.cuda.device(dev)` only when `dev` is not already the current device (the context manager costs
+    several microseconds per call; the C ABI launches on the CURRENT device)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        idx = dev.index
+        self.ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
+_WS_BYTES = {}
+
+
+def _fwd_ws_bytes(lib, B, N, d, C):
+    key = (B, N, d, C)
+    v = _WS_BYTES.get(key)
+    if v is None:
+        if len(_WS_BYTES) > 4096:
+            _WS_BYTES.clear()
+        v = _WS_BYTES[key] = lib.nw_fwd_workspace_bytes(B, N, d, C)
+    return v
 
 
 def _ptr(t):
@@ -44,12 +83,12 @@ def _kind_id(kind):
 _WS_CACHE = {}
 
 
-def _workspace(nbytes, device):
+def _workspace(nbytes, device, stream=None):
     """Scratch for one call.  Cached per (device, stream) and only ever grown: work on one stream is
     ordered, so the next call may reuse it; another stream gets its own."""
     nbytes = max(int(nbytes), 1)
     key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+           stream if stream is not None else torch.cuda.current_stream(device).cuda_stream)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -195,13 +234,16 @@ class _NWHeadFn(torch.autograd.Function):
         lse = torch.empty(B, dtype=torch.float32, device=dev) if need_bwd else None
         weights = torch.empty(B, N, dtype=torch.float32, device=dev) if want_weights else None
         ls = None if logit_scale is None else _f32c(logit_scale)
-        ws_bytes = lib.nw_fwd_workspace_bytes(B, N, d, n_classes)
-        ws = _workspace(ws_bytes, dev) if ws_bytes else None
-        with torch.cuda.device(dev):
-            _lib.check(lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale), _ptr(out),
-                                      _ptr(scores), _ptr(lse),
-                                      _ptr(weights), _ptr(ws), ws_bytes, B, N, d, n_classes, kind_id,
-                                      _ptr(ls), int(sup_b), int(lab_b), _stream(qc)), "nw_fwd_f32")
+        ws_bytes = _fwd_ws_bytes(lib, B, N, d, n_classes)
+        st = _stream(qc)
+        ws = _workspace(ws_bytes, dev, st) if ws_bytes else None
+        with _OnDevice(dev):
+            rc = lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale), _ptr(out),
+                                _ptr(scores), _ptr(lse),
+                                _ptr(weights), _ptr(ws), ws_bytes, B, N, d, n_classes, kind_id,
+                                _ptr(ls), int(sup_b), int(lab_b), st)
+        if rc:
+            _lib.check(rc, "nw_fwd_f32")
         if need_bwd:
             ctx.save_for_backward(qc, sc, syc, scores, lse, out, ls if ls is not None else torch.empty(0, device=dev))
             ctx.meta = (B, N, d, n_classes, kind_id, sup_b, lab_b, ls is not None)
