@@ -239,6 +239,19 @@ int nw_scale_shift_relu_avgpool2_f32(const float *x, const float *scale, const f
  *              small planes); may be NULL when that is 0
  *   bias       optional (cout,) (the BatchNorm that FOLLOWS the convolution, folded); post_relu: max(., 0)
  *   out        (n, cout, hw), batch stride out_batch_stride floats */
+/* 3x3 convolution, stride 1, padding 1, as an implicit GEMM on the fp32 matrix cores with bias / residual / ReLU fused
+ * in; the output may be a channel window of a wider tensor (out_batch_stride), e.g. a DenseNet block's slab.  Replaces
+ * the 3x3 convolutions of the folded inference backbones (model/densenet.py:41-45 conv2, model/densenet3.py:10-22,
+ * model/resnet.py:31-66 BasicBlock conv + folded BatchNorm + ReLU [+ identity]).
+ *     out[n, co, y, x] = post( bias[co] + sum_{ci,ky,kx} W[co,ci,ky,kx] in[n, ci, y+ky-1, x+kx-1] [+ residual[n, co, y, x]] )
+ *   x         (n, >= cin, H, W) fp32, planes contiguous, batch stride x_batch_stride floats
+ *   w_t       (ceil(cin/8), 9, 8, cout) fp32: the weight re-laid out once at fold time,
+ *             w_t[c / 8][3 ky + kx][c % 8][co] = W[co][c][ky][kx], channels past cin ZERO; cout % 32 == 0
+ *   bias      optional (cout,); residual optional (n, cout, H, W) with its batch stride; post_relu: max(., 0) */
+int nw_conv3x3_f32(const float *x, int64_t x_batch_stride, const float *w_t, const float *bias,
+                   const float *residual, int64_t res_batch_stride, int post_relu, float *out,
+                   int64_t out_batch_stride, int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W, void *stream);
+
 size_t nw_conv1x1_workspace_bytes(int64_t n, int64_t cin, int64_t cout, int64_t hw);
 int nw_conv1x1_f32(const float *x, int64_t x_batch_stride, const float *pre_scale, const float *pre_shift,
                    int pre_relu, const float *w_t, const float *bias, int post_relu, float *out,

@@ -1,0 +1,275 @@
+// conv3x3.hip -- 3x3 convolution (stride 1, padding 1) of the backbones' inference path as an implicit GEMM on the
+// fp32 matrix cores, bias / ReLU / residual behind it fused in, output written in place into a channel window of a
+// wider tensor (a DenseNet block's slab) (gfx950 / MI355X only).
+//
+// Replaces, in the folded inference copies, the 3x3 convolutions of DenseNet's dense layers (model/densenet.py:41-45:
+// conv2, 128 -> 32 channels, 58 per forward, followed by a copy of its output into the block's slab), of
+// CIFAR_DenseNet (model/densenet3.py:10-22) and of ResNet's BasicBlock (model/resnet.py:31-66, conv -> folded
+// BatchNorm bias -> ReLU [+ identity]).
+//
+//     out[n, co, y, x] = post( bias[co] + sum_{ci, ky, kx} W[co, ci, ky, kx] * in[n, ci, y + ky - 1, x + kx - 1] [+ res] )
+//
+// Implicit GEMM: M = cout, N = pixels of ONE image plane (flattened y W + x), K = (ci, tap).  A workgroup computes
+// TM output channels x TN consecutive pixels.  Per stage of 8 input channels it needs, for every channel, the plane's
+// pixels [p0 - W - 1, p0 + TN + W + 1): ONE contiguous span serves all nine taps -- tap (ky, kx) of pixel p is the span
+// element p + (ky - 1) W + (kx - 1) -- so the span goes HBM/L2 -> LDS once (LDS-DMA, 16 bytes per lane when W % 4 == 0)
+// and the nine shifted B fragments are plain ds_read_b32 at nine constant offsets; image borders (and the columns of
+// a ragged last tile) are a 9-bit validity mask per lane and column, applied with one v_cndmask.
+// Weights are passed re-laid out once at fold time as Wt[cin/8][tap][8][cout] (k-major: k = tap * 8 + ci within a
+// stage, output channels contiguous), rows past cin zero, so a stage's weight rows are DMA'd as they lie.
+// MFMA: v_mfma_f32_16x16x4_f32, exact fp32 multiply-adds; four k per instruction = four input channels of one tap.
+// Wave tile 32 (M) x 64 (N): 2 x 4 blocks, 8 independent accumulators; four waves per workgroup as WMW x WNW.
+// Three-stage LDS ring, two stages in flight, every wave issues its share of the DMAs, one barrier per stage.
+#include "nw_internal.h"
+#include <cstdlib>
+
+namespace nw {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int C3K = 8;      // input channels per stage
+constexpr int C3NBUF = 3;
+
+template <int WMW, int WNW, bool VEC>
+struct C3Cfg {
+    static constexpr int TM = 32 * WMW, TN = 64 * WNW;
+    static constexpr int A_F = 9 * C3K * TM;                 // floats of weights per stage
+    static constexpr int A_DMA = (A_F * 4 + 1023) / 1024;    // 1 KB DMA instructions for them
+    static constexpr int A_PER = (A_DMA + 3) / 4;            // ... per wave (the surplus repeats the last piece)
+};
+
+// `lrow`: floats per channel row of the span in LDS (a whole number of DMA instructions + 32), `padl`: pixels staged in
+// front of the tile (W + 1, or W + 4 when 16-byte pieces need an aligned origin), `nb`: DMA instructions per row.
+template <int WMW, int WNW, bool VEC>
+__global__ __launch_bounds__(256, 2) void nw_conv3x3_kernel(
+    const float* __restrict__ x, int64_t x_bs, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ res, int64_t res_bs, int post_relu, float* __restrict__ out, int64_t out_bs,
+    int n_img, int cin, int cout, int H, int W, int tiles_per_img, int lrow, int padl, int nb) {
+    using Cfg = C3Cfg<WMW, WNW, VEC>;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_F = Cfg::A_F, A_DMA = Cfg::A_DMA, A_PER = Cfg::A_PER;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int stage_f = A_F + C3K * lrow;                      // floats per stage
+    float* ring = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - img * tiles_per_img) * TN;
+    const int m0 = blockIdx.y * TM;
+    const int HW = H * W;
+    const int wm = 32 * (wave / WNW), wn = 64 * (wave % WNW);
+    const int nst = (cin + C3K - 1) / C3K;
+    const float* ximg = x + (int64_t)img * x_bs;
+
+    // ---- validity of the nine taps for this lane's four columns (N-block e: column wn + 16 e + i), as 36 booleans:
+    // the compiler keeps a per-lane boolean as a wave-wide bit mask in a scalar register pair, so masking a loaded value
+    // is ONE v_cndmask (fp32 MFMAs do not overlap with vector ALU work on their SIMD: every VALU op in the loop is
+    // matrix time; bit-field masks in a VGPR cost three ops per value and 47 % of the loop)
+    // The 9 x 4 validities factor into 5 x 4 conditions (pixel inside the plane, not on the top / bottom row, not in
+    // the first / last column); a tap's mask is their AND, scalar ALU work.
+    bool pv[4], yt[4], yb[4], xl[4], xr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int p = p0 + wn + 16 * e + i;
+        const int yy = p / W, xx = p - yy * W;
+        pv[e] = p < HW;
+        yt[e] = yy >= 1;
+        yb[e] = yy <= H - 2;
+        xl[e] = xx >= 1;
+        xr[e] = xx <= W - 2;
+    }
+
+    // ---- DMA plans.  Weights: the stage's 9*8 rows of TM floats; when cout == TM they are one contiguous block,
+    // otherwise rows of TM*4 bytes at a stride of cout*4.  Piece t of 1 KB: rows (1024 / (4 TM)) t ...
+    constexpr int AROWS = 256 / TM;                 // weight rows per 1 KB instruction (8, 4 or 2)
+    constexpr int AL = TM / 4;                      // lanes per row
+    const char* asrc[A_PER];
+    int adst[A_PER];
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        int t = wave + 4 * u;
+        if (t > A_DMA - 1) t = A_DMA - 1;           // surplus slots repeat the last piece (same bytes, same place)
+        const int row = AROWS * t + lane / AL;      // k-row of the stage: tap * 8 + ci
+        asrc[u] = reinterpret_cast<const char*>(wt + (int64_t)row * cout + m0 + 4 * (lane % AL));
+        adst[u] = 256 * t;                          // floats from the stage's start
+    }
+    // Span: channel row c of the stage gets nb instructions; instruction b covers span elements [64 b, 64 b + 64)
+    // (float4 groups when VEC).  Per wave: 2 channels (8 per stage / 4 waves).
+    const int per_el = VEC ? 4 : 1;
+    auto span_pixel = [&](int b) {                  // clamped source pixel of this lane's piece of instruction b
+        int q = p0 - padl + (64 * b + lane) * per_el;
+        const int hi = HW - per_el;
+        q = q < 0 ? 0 : (q > hi ? hi : q);          // pieces outside the plane repeat a valid one (masked when read)
+        return q;
+    };
+    auto issue = [&](int s) {
+        float* st = ring + (unsigned)(s % C3NBUF) * stage_f;
+        const int64_t koff = (int64_t)s * 9 * C3K * cout * 4;    // bytes: the stage's first weight row
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[u] + koff),
+                                             (__attribute__((address_space(3))) void*)(st + adst[u]), 16, 0, 0);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int cl = 2 * wave + cc;           // channel row of the stage
+            const int ci = min(s * C3K + cl, cin - 1);   // rows past cin meet zero weights: any finite data will do
+            const float* plane = ximg + (int64_t)ci * HW;
+            float* drow = st + A_F + cl * lrow + 16 * (cl & 1);
+            for (int b = 0; b < nb; ++b) {
+                const float* src = plane + span_pixel(b);
+                if (VEC)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(drow + 256 * b), 16, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(drow + 64 * b), 4, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[a][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // two stages in flight; vmcnt cannot take a run-time count, so a stage is waited for by draining the queue
+    // down to one stage's worth with a loop over the (at most two) outstanding ones
+    issue(0);
+    if (nst > 1) issue(1);
+    const int per = A_PER + 2 * nb;                 // DMAs per wave and stage (wave-uniform)
+    auto wait_all_but = [&](int keep) {             // keep = 0 or `per`
+        if (keep == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else {
+            // per <= 5 + 2 * 8: enumerate
+            switch (per) {
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+                case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+                case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+                case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        }
+    };
+    wait_all_but(nst > 1 ? per : 0);
+    __syncthreads();
+
+    // B fragment of tap t, channel group kk (channels 4 kk + g of the stage), N-block e:
+    //   row (4 kk + g), element  wn + 16 e + i + padl + (ky - 1) W + (kx - 1)
+    const int bbase = wn + i + padl - W - 1;        // + 16 e + ky W + kx
+    for (int s = 0; s < nst; ++s) {
+        if (s + 2 < nst) issue(s + 2);              // into the buffer every wave left at the last barrier
+        const float* As = ring + (unsigned)(s % C3NBUF) * stage_f;
+        const float* Bs = As + A_F;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = (t / 3) * W + (t % 3);
+#pragma unroll
+            for (int kk = 0; kk < C3K / 4; ++kk) {
+                const int cl = 4 * kk + g;
+                const float* brow = Bs + cl * lrow + 16 * (cl & 1) + bbase + toff;
+                float bv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = brow[16 * e];
+                    const bool okv = pv[e] && (t / 3 == 0 ? yt[e] : (t / 3 == 2 ? yb[e] : true)) &&
+                                     (t % 3 == 0 ? xl[e] : (t % 3 == 2 ? xr[e] : true));
+                    bv[e] = okv ? v : 0.f;
+                }
+                const float2 a2 = *reinterpret_cast<const float2*>(As + (t * C3K + cl) * TM + wm + 2 * i);
+                const float av[2] = {a2.x, a2.y};
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[a][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[e], acc[a][e], 0, 0, 0);
+            }
+        }
+        wait_all_but(s + 2 < nst ? per : 0);        // stage s + 1 has landed (this wave's share)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- store: acc[a][e][r] of lane (i, g) = out[m0 + wm + 2 (4 g + r) + a][p0 + wn + 16 e + i]
+    const float lo = post_relu ? 0.f : -INFINITY;
+    float* oimg = out + (int64_t)img * out_bs;
+    const float* rimg = res ? res + (int64_t)img * res_bs : nullptr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int p = p0 + wn + 16 * e + i;
+        if (p >= HW) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int m = m0 + wm + 2 * (4 * g + r) + a;
+                if (m >= cout) continue;
+                float v = acc[a][e][r] + (bias ? bias[m] : 0.f);
+                if (rimg) v += rimg[(int64_t)m * HW + p];
+                oimg[(int64_t)m * HW + p] = fmaxf(v, lo);
+            }
+    }
+}
+
+}  // namespace
+}  // namespace nw
+
+// span geometry shared by the launcher and the kernel
+static void conv3x3_span(int tn, int W, bool vec, int* lrow, int* padl, int* nb) {
+    *padl = vec ? W + 4 : W + 1;
+    const int L = tn + *padl + W + 1;                          // span elements a tile can touch
+    const int per = vec ? 256 : 64;                            // floats per DMA instruction
+    *nb = (L + per - 1) / per;
+    *lrow = *nb * per + 32;                                    // + the 16-float stagger of odd rows
+}
+
+extern "C" int nw_conv3x3_f32(const float* x, int64_t x_batch_stride, const float* w_t, const float* bias,
+                              const float* residual, int64_t res_batch_stride, int post_relu, float* out,
+                              int64_t out_batch_stride, int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W,
+                              void* stream) {
+    using namespace nw;
+    if (n < 0 || cin < 0 || cout < 0 || H < 0 || W < 0) return NW_ERR_INVALID_ARG;
+    if (n == 0 || cout == 0 || H == 0 || W == 0) return NW_OK;
+    if (!x || !w_t || !out || cin == 0) return NW_ERR_INVALID_ARG;
+    if (cout % 32 != 0 || (reinterpret_cast<uintptr_t>(w_t) & 15) || (reinterpret_cast<uintptr_t>(x) & 3)) return NW_ERR_UNSUPPORTED;
+    const int64_t HW = H * W;
+    if (HW > 0x3fffffffLL || cin > 0x7fffffffLL || cout > 0x7fffffffLL || x_batch_stride < cin * HW || out_batch_stride < cout * HW ||
+        (residual && res_batch_stride < cout * HW))
+        return NW_ERR_INVALID_ARG;
+    if (HW < 4) return NW_ERR_UNSUPPORTED;
+    const bool vec = W % 4 == 0 && x_batch_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    // tile shape: 32 x 256 for narrow outputs on big planes, 64 x 128 otherwise, 128 x 64 for small planes
+    int wmw, wnw;
+    if (cout % 128 == 0 && HW <= 64) { wmw = 4; wnw = 1; }
+    else if (cout % 64 == 0) { wmw = 2; wnw = 2; }
+    else { wmw = 1; wnw = 4; }
+    const int tm = 32 * wmw, tn = 64 * wnw;
+    const int tiles = (int)((HW + tn - 1) / tn);
+    const int64_t gx = (int64_t)tiles * n;
+    if (gx > 0x7fffffffLL || cout / tm > 65535) return NW_ERR_INVALID_ARG;
+    int lrow, padl, nb;
+    conv3x3_span(tn, (int)W, vec, &lrow, &padl, &nb);
+    if (nb > 8) return NW_ERR_UNSUPPORTED;                       // very wide images: not a backbone shape
+    const size_t lds = (size_t)C3NBUF * (9 * C3K * tm + C3K * lrow) * sizeof(float);
+    if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)gx, (unsigned)(cout / tm));
+#define NW_C3(MW_, NW_, V_)                                                                                              \
+    hipLaunchKernelGGL((nw_conv3x3_kernel<MW_, NW_, V_>), grid, dim3(256), lds, st, x, x_batch_stride, w_t, bias, residual, \
+                       res_batch_stride, post_relu, out, out_batch_stride, (int)n, (int)cin, (int)cout, (int)H, (int)W, tiles, \
+                       lrow, padl, nb)
+    if (wmw == 1) { if (vec) NW_C3(1, 4, true); else NW_C3(1, 4, false); }
+    else if (wmw == 2) { if (vec) NW_C3(2, 2, true); else NW_C3(2, 2, false); }
+    else { if (vec) NW_C3(4, 1, true); else NW_C3(4, 1, false); }
+#undef NW_C3
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}

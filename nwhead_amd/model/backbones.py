@@ -112,6 +112,13 @@ class ResNet(nn.Module):
 # ----------------------------------------------------------------------------- CIFAR pre-act ResNet
 DENSE_PASSTHROUGH = True        # the running concatenation passes through norm1's autograd node (see _DenseBlock.forward)
 DENSE_INCREMENTAL_CAT = True    # dense blocks extend one running concatenation (see _DenseBlock.forward)
+# Folded inference copies: 3x3 convolutions as the implicit-GEMM kernel (Conv3x3Fused, csrc/conv3x3.hip).  OFF by default:
+# the kernel is parity-tested (tests/test_conv3x3_gpu.py) and writes straight into the dense-block slab, but a direct
+# convolution on the fp32 matrix cores (54-79 TFLOP/s measured, 157 peak) loses to MIOpen's Winograd kernels (72-101
+# TFLOP/s-equivalent: 2.25x fewer multiplies): DenseNet-121 over 64 images 6.48 ms with it, 6.10 ms without
+# (tools/conv3x3_time.py).  NW_OWN_CONV3X3=1 or backbones.FUSED_CONV3X3 = True turn it on.
+import os as _os
+FUSED_CONV3X3 = _os.environ.get("NW_OWN_CONV3X3") == "1"
 FUSED_CONV1X1 = True            # folded inference copies: 1x1 convolutions with their BatchNorm / ReLU neighbours as one kernel (Conv1x1Fused)
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
 
@@ -188,7 +195,7 @@ class _DenseLayer(nn.Sequential):
     def forward(self, x):
         # relu1 must not run in place on a slab/concat that later layers re-read
         if isinstance(self.conv1, Conv1x1Fused):         # folded inference copy: norm1-relu1-conv1-norm2-relu2 in one kernel
-            return self.conv2(self.conv1(x))
+            return self.conv2(self.conv1(x))              #   (conv2: Conv3x3Fused when FUSED_CONV3X3)
         if isinstance(self.norm1, ScaleShiftReLU):       # folded inference copy without the fused 1x1 (FUSED_CONV1X1 off)
             return self.conv2(self.relu2(self.conv1(self.norm1(x))))
         return self.after_norm1(_bn_relu(self.norm1, x))
@@ -233,7 +240,11 @@ class _DenseBlock(nn.Module):
         slab = x.new_empty(n, c + len(layers) * self.growth_rate, h, w)
         slab[:, :c] = x
         for layer in layers:
-            slab[:, c:c + self.growth_rate] = layer(slab[:, :c])
+            dst = slab[:, c:c + self.growth_rate]
+            if isinstance(layer.conv2, Conv3x3Fused) and isinstance(layer.conv1, Conv1x1Fused) and layer.drop_rate == 0:
+                layer.conv2(layer.conv1(slab[:, :c]), out=dst)     # the 3x3 kernel writes its channels into the slab
+            else:
+                slab[:, c:c + self.growth_rate] = layer(slab[:, :c])
             c += self.growth_rate
         return slab
 
@@ -344,6 +355,52 @@ class Conv1x1Fused(nn.Module):
         y = F.conv2d(x, self.weight[:, :, None, None], self.bias)
         y = F.relu(y) if self.post_relu else y
         return F.avg_pool2d(y, 2) if self.pool_first else y
+
+
+class Conv3x3Fused(nn.Module):
+    """3x3 convolution (stride 1, padding 1) [-> folded BatchNorm bias] [+ residual] [-> ReLU] as ONE kernel on the
+    MI355X (ops.conv3x3, csrc/conv3x3.hip: implicit GEMM on the fp32 matrix cores), written straight into `out` when
+    given (a channel window of a dense block's slab); on CPU tensors -- and for shapes that would leave most of the
+    chip idle (fewer than 192 workgroups: 7x7 and 14x14 planes of narrow layers) -- the same torch ops the reference
+    backbone runs.  Built by fold_batchnorm.  Inference only."""
+
+    def __init__(self, conv, post_bn=None, post_relu=False):
+        super().__init__()
+        assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == 1 \
+            and conv.dilation == (1, 1)
+        w = conv.weight.detach()
+        b = conv.bias.detach() if conv.bias is not None else None
+        if post_bn is not None:
+            a = post_bn.weight.detach() * torch.rsqrt(post_bn.running_var.detach() + post_bn.eps)
+            w = w * a[:, None, None, None]
+            b = post_bn.bias.detach() + ((b if b is not None else 0) - post_bn.running_mean.detach()) * a
+        from ..ops import conv3x3_weight
+        self.cin, self.cout = w.shape[1], w.shape[0]
+        self.register_buffer("weight", w.contiguous().clone())           # (cout, cin, 3, 3): the torch path
+        self.register_buffer("weight_t", conv3x3_weight(w))               # (ceil(cin / 8), 9, 8, cout): the kernel's operand
+        self.register_buffer("bias", None if b is None else b.clone())
+        self.post_relu = post_relu
+
+    def _use_kernel(self, x):
+        if not x.is_cuda or self.cout % 32 != 0 or x.dtype != torch.float32:
+            return False
+        n, _, h, w = x.shape
+        tm, tn = (128, 64) if (self.cout % 128 == 0 and h * w <= 64) else ((64, 128) if self.cout % 64 == 0 else (32, 256))
+        return h * w >= 4 and n * ((h * w + tn - 1) // tn) * (self.cout // tm) >= 192
+
+    def forward(self, x, out=None, residual=None):
+        if self._use_kernel(x):
+            from .. import ops
+            return ops.conv3x3(x, self.weight_t, self.cin, self.bias, residual, self.post_relu, out)
+        y = F.conv2d(x, self.weight, self.bias, padding=1)
+        if residual is not None:
+            y = y + residual
+        if self.post_relu:
+            y = F.relu(y)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
 
 # ----------------------------------------------------------------------------- CIFAR DenseNet
@@ -506,6 +563,8 @@ def fold_batchnorm(model):
         elif isinstance(mod, _DenseLayer) and FUSED_CONV1X1:
             mod.conv1 = Conv1x1Fused(mod.conv1, pre_bn=mod.norm1, post_bn=mod.norm2, post_relu=True)
             mod.norm1 = mod.relu1 = mod.norm2 = mod.relu2 = nn.Identity()
+            if FUSED_CONV3X3:
+                mod.conv2 = Conv3x3Fused(mod.conv2)
         elif isinstance(mod, _DenseLayer):
             mod.conv1, mod.norm2 = _fold_pair(mod.conv1, mod.norm2), nn.Identity()
             mod.norm1, mod.relu1 = ScaleShiftReLU(mod.norm1), nn.Identity()
@@ -521,6 +580,8 @@ def fold_batchnorm(model):
         elif isinstance(mod, CifarBottleneck) and FUSED_CONV1X1:
             mod.conv1 = Conv1x1Fused(mod.conv1, pre_bn=mod.bn1, post_bn=mod.bn2, post_relu=True)
             mod.bn1 = mod.bn2 = nn.Identity()
+            if FUSED_CONV3X3:
+                mod.conv2 = Conv3x3Fused(mod.conv2)
         elif isinstance(mod, (PreActBlock, CifarBottleneck)):
             mod.conv1, mod.bn2 = _fold_pair(mod.conv1, mod.bn2), nn.Identity()
             mod.bn1 = ScaleShiftReLU(mod.bn1)

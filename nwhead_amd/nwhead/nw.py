@@ -99,11 +99,11 @@ class NWNet(nn.Module):
         if rebuild or getattr(self, '_folded', None) is None or getattr(self, '_folded_sig', None) != sig:
             object.__setattr__(self, '_folded_sig', sig)
             from ..model import fold_batchnorm
-            from ..model.backbones import Conv1x1Fused, ScaleShiftReLU
+            from ..model.backbones import Conv1x1Fused, Conv3x3Fused, ScaleShiftReLU
             folded = fold_batchnorm(self.featurizer)
             # DenseNet's folded copy runs its BatchNorm -> ReLU pairs in an NCHW HIP kernel on channel
             # prefixes of the dense-block slab: it stays NCHW (11.2 -> 7.8 ms over 64 images @224)
-            if getattr(self, '_fold_cl', False) and not any(isinstance(m, (ScaleShiftReLU, Conv1x1Fused)) for m in folded.modules()):
+            if getattr(self, '_fold_cl', False) and not any(isinstance(m, (ScaleShiftReLU, Conv1x1Fused, Conv3x3Fused)) for m in folded.modules()):
                 folded = _ChannelsLast(folded)
             object.__setattr__(self, '_folded', folded)
         return self._folded

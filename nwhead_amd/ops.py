@@ -422,6 +422,42 @@ def conv1x1(x, weight_t, bias=None, pre_scale=None, pre_shift=None, pre_relu=Fal
     return out
 
 
+def conv3x3_weight(w):
+    """(cout, cin, 3, 3) -> the operand of conv3x3: (ceil(cin / 8), 9, 8, cout), channels past cin zero."""
+    cout, cin = w.shape[:2]
+    pad = (-cin) % 8
+    if pad:
+        w = torch.cat((w, w.new_zeros(cout, pad, 3, 3)), 1)
+    return w.reshape(cout, (cin + pad) // 8, 8, 9).permute(1, 3, 2, 0).contiguous()
+
+
+def conv3x3(x, weight_t, cin, bias=None, residual=None, post_relu=False, out=None):
+    """3x3 convolution, stride 1, padding 1, of an (n, c, h, w) fp32 activation whose (c, h, w) part is contiguous (a
+    channel prefix of a slab is fine), weight_t from conv3x3_weight; bias / residual / ReLU behind it in the same
+    kernel; `out`: an (n, cout, h, w) view with contiguous (cout, h, w) part to write into (a channel window of a slab)."""
+    _need_hip(x, weight_t, bias, residual, out)
+    x, bstride = _plane_view(x)
+    n, c, h, w = x.shape
+    cout = weight_t.shape[3]
+    if c != cin or tuple(weight_t.shape[:3]) != ((cin + 7) // 8, 9, 8) or not weight_t.is_contiguous():
+        raise ValueError("conv3x3: weight_t must be conv3x3_weight(w) of a (cout, cin, 3, 3) weight with cin = x's channels")
+    if out is None:
+        out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    elif out.shape != (n, cout, h, w) or out.dtype != torch.float32 or (out.numel() and (
+            out.stride(3) != 1 or out.stride(2) != w or out.stride(1) != h * w)):
+        raise ValueError("conv3x3: `out` must be (n, cout, h, w) fp32 with a contiguous (cout, h, w) part")
+    obs = out.stride(0) if n > 1 else cout * h * w
+    rbs = 0
+    if residual is not None:
+        residual, rbs = _plane_view(residual)
+        if residual.shape != (n, cout, h, w):
+            raise ValueError("conv3x3: residual must have the output's shape")
+    with _OnDevice(x.device):
+        _lib.check(_lib.load().nw_conv3x3_f32(_ptr(x), bstride, _ptr(weight_t), _ptr(bias), _ptr(residual), rbs, int(bool(post_relu)),
+                                              _ptr(out), obs, n, cin, cout, h, w, _stream(x)), "nw_conv3x3_f32")
+    return out
+
+
 def pad_rows16(w_t):
     """(cin, cout) -> (cin rounded up to 16, cout) with zero rows: the weight operand of conv1x1."""
     cin = w_t.shape[0]
