@@ -21,7 +21,17 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(src + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-pmc = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+def full_size_mean(v):
+    """Mean over the dispatches of the LARGEST launch shape (values within 10 % of the maximum): a run mixes launch
+    shapes of one kernel (warm-up, the single-call latency probe, the coalesced launches of the timed region)."""
+    top = max(v)
+    big = [x for x in v if x >= 0.9 * top] if top > 0 else v
+    return sum(big) / len(big)
+
+
+pmc = {k: {c: full_size_mean(v) for c, v in d.items()} for k, d in acc.items()}
+for k, d in acc.items():
+    pmc[k]["dispatches_all_shapes"] = max(len(v) for v in d.values())
 for k, d in pmc.items():
     if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
         # MI355X_MICROARCH.md, HBM section: FETCH_SIZE (KB) reports exactly half of a wide coalesced
@@ -45,9 +55,9 @@ with open(f"profiles/{name}_summary.md", "w") as fh:
             fh.write(f"\n`{stats[0]['kernel']}` launch by launch: first 5 = {', '.join(f'{x:.0f}' for x in d[:5])} us; "
                      f"last 20 average {sum(tail) / len(tail):.1f} us (min {min(tail):.1f}, max {max(tail):.1f}) -- "
                      f"the steady state `roofline.kernel_us` of the bench line is measured in.\n")
-    fh.write("\n## --pmc (separate passes; mean per dispatch)\n\n")
+    fh.write("\n## --pmc (separate passes; mean per dispatch of the kernel's largest launch shape)\n\n")
     for k, d in pmc.items():
-        fh.write(f"### `{k}`\n\n| counter | mean per dispatch |\n|---|---|\n")
+        fh.write(f"### `{k}`\n\n| counter | mean per full-size dispatch |\n|---|---|\n")
         for c, v in sorted(d.items()):
             fh.write(f"| {c} | {v:,.1f} |\n")
         fh.write("\n")

@@ -10,7 +10,8 @@ tail = rows[cut:]
 reps = int(sys.argv[2])
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in tail:
-    k = re.sub(r"\(.*", "", r["Kernel_Name"])[:90]
+    m = re.search(r"(nw_[a-z_0-9]+(<[^>]*>)?)", r["Kernel_Name"])
+    k = m.group(1) if m else re.sub(r"\(.*", "", r["Kernel_Name"])[:90]
     acc[k][0] += 1
     acc[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = sum(v[1] for v in acc.values())
