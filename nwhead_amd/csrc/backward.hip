@@ -11,12 +11,11 @@
 // Euclidean: df/ddot = 1/D, df/d|q|^2 = df/d|s|^2 = -1/(2D), all taken as 0 where D == 0 (torch's
 // cdist backward masks the zero distance the same way).
 #include "nw_internal.h"
+#include "tile_dma.h"
 #include <cstdlib>
 
 namespace nw {
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void nw_rownorm_kernel(const float* __restrict__ x,
                                                           float* __restrict__ n2, int64_t rows,
@@ -35,16 +34,21 @@ __global__ __launch_bounds__(256) void nw_rownorm_kernel(const float* __restrict
 // (t = sum_j W_j dW_j could be had without a pass over the supports, as sum_c g[c] (1 - 1e-12 exp(-out[c]));
 //  but for a class the support set lacks that is 1 - 1 computed through a rounded `out`, ~1e-6 g instead
 //  of the exact 0 the sum gives -- measured 26 us saved at B=256, N=10000, not taken.)
-template <int KIND>
+// SPLIT: A leaves as the split-row image A' of bwd_split.hip (row b scaled by 2^(E_b - e_j), s_scale[j] = 2^-e_j),
+// with ascale[b] = 2^-E_b and qv[b] = max_k |q[b,k]| 2^-E_b; the row is staged in LDS (ld floats) for that.
+template <int KIND, bool SPLIT = false>
 __global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
     const float* __restrict__ scores, const float* __restrict__ lse, const float* __restrict__ out,
     const float* __restrict__ gout, const int64_t* __restrict__ sy, int labels_batched,
     const float* __restrict__ qn2, const float* __restrict__ sn2, int sup_batched,
     const float* __restrict__ logit_scale, float* __restrict__ A, float* __restrict__ Rs,
-    float* __restrict__ rq, float* __restrict__ gls, int64_t N, int64_t C, int64_t ld) {
+    float* __restrict__ rq, float* __restrict__ gls, int64_t N, int64_t C, int64_t ld,
+    const float* __restrict__ q = nullptr, int64_t d = 0, const float* __restrict__ s_scale = nullptr,
+    float* __restrict__ ascale = nullptr, float* __restrict__ qv = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);
-    float* dP = red + 16;
+    float* rowbuf = red + 16;                       // SPLIT: ld floats (16-byte aligned), then dP
+    float* dP = SPLIT ? rowbuf + ld : red + 16;
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const float* row = scores + b * N;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
         nq = fmaxf(n, NW_NORM_EPS);
         inq2 = (n > NW_NORM_EPS) ? 1.f / (nq * nq) : 0.f;  // F.normalize clamps: no grad via |q|
     }
-    float rq_acc = 0.f, gls_acc = 0.f;
+    float rq_acc = 0.f, gls_acc = 0.f, amax = 0.f;
     for (int64_t j = tid; j < N; j += nthr) {
         const float sc = row[j];
         const int64_t y = lab[j];
@@ -103,7 +107,13 @@ __global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
             rq_acc += gc * (-0.5f * c * inq2);
             r = gc * (-0.5f * c * ins2);
         }
-        A[b * ld + j] = a;
+        if (SPLIT) {
+            const float ah = a * s_scale[j];
+            rowbuf[j] = ah;
+            amax = fmaxf(amax, fabsf(ah));
+        } else {
+            A[b * ld + j] = a;
+        }
         if (Rs) Rs[b * ld + j] = r;
     }
     rq_acc = block_sum(rq_acc, red);
@@ -111,6 +121,34 @@ __global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
     if (tid == 0 && rq) {
         rq[b] = rq_acc;
         gls[b] = gls_acc;
+    }
+    if (SPLIT) {
+        for (int64_t j = N + tid; j < ld; j += nthr) rowbuf[j] = 0.f;   // the K padding of the first product
+        amax = block_max(amax, red);
+        float qm = 0.f;
+        for (int64_t k = tid; k < d; k += nthr) qm = fmaxf(qm, fabsf(q[b * d + k]));
+        qm = block_max(qm, red);   // (its barriers also publish rowbuf)
+        const int E = split_exponent(amax);
+        const float up = __builtin_ldexpf(1.f, E), down = __builtin_ldexpf(1.f, -E);
+        if (tid == 0) {
+            ascale[b] = down;
+            qv[b] = qm * down;
+        }
+        _Float16* dst = reinterpret_cast<_Float16*>(A + b * ld);
+        for (int64_t u = tid; u < ld / 8; u += nthr) {   // eight coefficients -> 16 bytes of h + 16 bytes of l
+            const float4 v0 = *reinterpret_cast<const float4*>(rowbuf + 8 * u);
+            const float4 v1 = *reinterpret_cast<const float4*>(rowbuf + 8 * u + 4);
+            const float x[8] = {v0.x * up, v0.y * up, v0.z * up, v0.w * up, v1.x * up, v1.y * up, v1.z * up, v1.w * up};
+            half8 h, l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                h[k] = (_Float16)x[k];
+                l[k] = (_Float16)(x[k] - (float)h[k]);
+            }
+            const int64_t chunk = (8 * u) >> 5, within = (8 * u) & 31;
+            *reinterpret_cast<half8*>(dst + chunk * 64 + within) = h;
+            *reinterpret_cast<half8*>(dst + chunk * 64 + 32 + within) = l;
+        }
     }
 }
 
@@ -393,8 +431,10 @@ __global__ __launch_bounds__(256) void nw_sum_kernel(const float* __restrict__ x
 
 struct BwdWs {
     float *A, *Rs, *rq, *gls, *qn2, *sn2, *rs, *part, *cs_part;
-    int64_t ld;  // row stride of A and Rs: N, or N rounded up to 4 floats on the matrix-core path
-    bool mfma;
+    float *s_split, *s_scale, *q_split, *ascale, *qv, *gfac;   // split path (bwd_split.hip)
+    int64_t ld;    // row stride of A and Rs: N, N rounded up to 4 floats (fp32 matrix cores) or to 32 (split path)
+    int64_t Bpad;  // rows of q_split: B rounded up to 32, the rest zero
+    bool mfma, split;
 };
 // Shared support, float4-able rows and enough work to fill the chip: the two products run on the matrix cores.
 bool bwd_use_mfma(int64_t B, int64_t N, int64_t d, int sup_batched) {
@@ -402,8 +442,20 @@ bool bwd_use_mfma(int64_t B, int64_t N, int64_t d, int sup_batched) {
     return !off && !sup_batched && d % 4 == 0 && B * N * d >= (int64_t)1 << 22;
 }
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// The products on the fp16 matrix cores (bwd_split.hip): split rows need d % 32 == 0, the coefficient kernel stages a
+// row of A (N rounded up to 32 floats) next to the C class gradients in LDS, and the extra passes (splitting the
+// supports and the queries) have to pay: measured at B=256, N=10000, d=512 ... us against ... on the fp32 cores.
+bool bwd_use_split(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched) {
+    const char* env = getenv("NW_BWD_SPLIT");   // 0 off, 1 wherever possible; read per call (tests switch it)
+    const int mode = env ? atoi(env) : -1;
+    if (mode == 0 || !bwd_use_mfma(B, N, d, sup_batched) || d % 32 != 0) return false;
+    const int64_t ld = (N + 31) / 32 * 32;
+    if ((size_t)(16 + ld + C) * sizeof(float) > 150 * 1024) return false;
+    if (mode == 1) return true;
+    return B >= 64 && N >= 1024 && B * N * d >= (int64_t)1 << 27;
+}
 
-size_t bwd_layout(int64_t B, int64_t N, int64_t d, int sup_batched, char* base, BwdWs* ws) {
+size_t bwd_layout(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched, char* base, BwdWs* ws) {
     size_t off = 0;
     auto take = [&](size_t nfloat) {
         float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
@@ -412,19 +464,33 @@ size_t bwd_layout(int64_t B, int64_t N, int64_t d, int sup_batched, char* base, 
     };
     BwdWs w;
     w.mfma = bwd_use_mfma(B, N, d, sup_batched);
-    w.ld = w.mfma ? (N + 3) / 4 * 4 : N;
-    w.A = take((size_t)B * w.ld);
+    w.split = bwd_use_split(B, N, d, C, sup_batched);
+    w.ld = w.split ? (N + 31) / 32 * 32 : w.mfma ? (N + 3) / 4 * 4 : N;
+    w.Bpad = (B + 31) / 32 * 32;
+    w.A = take((size_t)B * w.ld + (w.split ? XGEMM_TAIL_BYTES / 4 : 0));
     w.Rs = take((size_t)B * w.ld);
     w.rq = take((size_t)B);
     w.gls = take((size_t)B);
     w.qn2 = take((size_t)B);
     w.sn2 = take(sup_batched ? (size_t)B * N : (size_t)N);
     w.rs = w.part = w.cs_part = nullptr;
+    w.s_split = w.s_scale = w.q_split = w.ascale = w.qv = w.gfac = nullptr;
     if (w.mfma) {
         w.rs = take((size_t)N);
         w.cs_part = take((size_t)CS_MAX_SLICES * w.ld);
-        const GemmPlan pq = gemm_plan(B, d, N), ps = gemm_plan(N, d, B);
-        const size_t nq = pq.nchunks > 1 ? (size_t)pq.nchunks * B * d : 0, ns = ps.nchunks > 1 ? (size_t)ps.nchunks * N * d : 0;
+        int cq, cs;
+        if (w.split) {
+            cq = xgemm_plan(B, d, N).nchunks, cs = xgemm_plan(N, d, B).nchunks;
+            w.s_split = take((size_t)N * d + XGEMM_TAIL_BYTES / 4);
+            w.s_scale = take((size_t)N);
+            w.q_split = take((size_t)w.Bpad * d + XGEMM_TAIL_BYTES / 4);
+            w.ascale = take((size_t)B);
+            w.qv = take((size_t)B);
+            w.gfac = take(1);
+        } else {
+            cq = gemm_plan(B, d, N).nchunks, cs = gemm_plan(N, d, B).nchunks;
+        }
+        const size_t nq = cq > 1 ? (size_t)cq * B * d : 0, ns = cs > 1 ? (size_t)cs * N * d : 0;
         w.part = take(nq > ns ? nq : ns);
     }
     if (ws) *ws = w;
@@ -445,9 +511,9 @@ int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStrea
 
 extern "C" size_t nw_bwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                                          int sup_batched) {
-    (void)C; (void)kind;
+    (void)kind;
     if (B <= 0 || N < 0) return 0;
-    return nw::bwd_layout(B, N, d, sup_batched, nullptr, nullptr);
+    return nw::bwd_layout(B, N, d, C, sup_batched, nullptr, nullptr);
 }
 
 extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, const float* scores,
@@ -471,21 +537,34 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
     if (!q || !s || !sy || !scores || !lse || !out || !gout || !gq || !gs) return NW_ERR_INVALID_ARG;
     if (B > 0x7fffffffLL || gs_rows > 0x7fffffffLL || (d + 255) / 256 > 65535) return NW_ERR_INVALID_ARG;
     BwdWs ws;
-    const size_t need = bwd_layout(B, N, d, sup_batched, static_cast<char*>(workspace), &ws);
+    const size_t need = bwd_layout(B, N, d, C, sup_batched, static_cast<char*>(workspace), &ws);
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
-    const size_t lds = (16 + (size_t)C) * sizeof(float);
+    const size_t lds = (16 + (size_t)C + (ws.split ? (size_t)ws.ld : 0)) * sizeof(float);
     const unsigned coeff_threads = N >= 2048 ? 1024 : 256;
     if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(s) |
+                           reinterpret_cast<uintptr_t>(gq) | reinterpret_cast<uintptr_t>(gs)) & 15) == 0;
+    if (ws.mfma && !aligned) return NW_ERR_INVALID_ARG;  // the layout (row stride of A) is already the matrix-core one
 
     const bool norms = (kind == NW_SCORE_HYPERSPHERE || kind == NW_SCORE_COSINE || kind == NW_SCORE_CLIP);
-    if (norms) {
-        hipLaunchKernelGGL(nw_rownorm_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, q, ws.qn2, B, d);
+    if (norms) hipLaunchKernelGGL(nw_rownorm_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, q, ws.qn2, B, d);
+    if (ws.split) {   // the supports as split rows (the forward's bank format); their squared norms come with it
+        const int rc = launch_split_rows(s, ws.s_split, ws.s_scale, ws.sn2, N, d, st);
+        if (rc != NW_OK) return rc;
+    } else if (norms) {
         hipLaunchKernelGGL(nw_rownorm_kernel, dim3((unsigned)((gs_rows + 3) / 4)), dim3(256), 0, st, s, ws.sn2, gs_rows, d);
     }
-#define NW_COEFF(K)                                                                              \
-    hipLaunchKernelGGL(nw_bwd_coeff_kernel<K>, dim3((unsigned)B), dim3(coeff_threads), lds, st, scores, lse, \
-                       out, gout, sy, labels_batched, ws.qn2, ws.sn2, sup_batched, logit_scale_dev, \
-                       ws.A, ws.Rs, ws.rq, ws.gls, N, C, ws.ld)
+#define NW_COEFF(K)                                                                                                      \
+    do {                                                                                                                 \
+        if (ws.split)                                                                                                    \
+            hipLaunchKernelGGL((nw_bwd_coeff_kernel<K, true>), dim3((unsigned)B), dim3(coeff_threads), lds, st, scores, lse, \
+                               out, gout, sy, labels_batched, ws.qn2, ws.sn2, sup_batched, logit_scale_dev, ws.A, ws.Rs,  \
+                               ws.rq, ws.gls, N, C, ws.ld, q, d, ws.s_scale, ws.ascale, ws.qv);                          \
+        else                                                                                                             \
+            hipLaunchKernelGGL((nw_bwd_coeff_kernel<K, false>), dim3((unsigned)B), dim3(coeff_threads), lds, st, scores, lse, \
+                               out, gout, sy, labels_batched, ws.qn2, ws.sn2, sup_batched, logit_scale_dev, ws.A, ws.Rs,  \
+                               ws.rq, ws.gls, N, C, ws.ld);                                                              \
+    } while (0)
     switch (kind) {
         case NW_SCORE_EUCLIDEAN: NW_COEFF(NW_SCORE_EUCLIDEAN); break;
         case NW_SCORE_HYPERSPHERE: NW_COEFF(NW_SCORE_HYPERSPHERE); break;
@@ -494,9 +573,6 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
         default: NW_COEFF(NW_SCORE_CLIP); break;
     }
 #undef NW_COEFF
-    const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(s) |
-                           reinterpret_cast<uintptr_t>(gq) | reinterpret_cast<uintptr_t>(gs)) & 15) == 0;
-    if (ws.mfma && !aligned) return NW_ERR_INVALID_ARG;  // the layout (row stride of A) is already the matrix-core one
     if (ws.mfma) {
         const int64_t cs_rows = colsum_rows(B);
         const int nslices = (int)((B + cs_rows - 1) / cs_rows);
@@ -504,10 +580,24 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
                            st, ws.Rs, ws.ld, ws.cs_part, B, cs_rows);
         hipLaunchKernelGGL(nw_colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, ws.cs_part, ws.ld,
                            nslices, ws.rs, N);
-        int rc = launch_bwd_gemm<true>(ws.A, ws.ld, s, ws.part, ws.rq, q, gq, B, d, N, st);   // gq = A s + 2 rq q
-        if (rc != NW_OK) return rc;
-        rc = launch_bwd_gemm<false>(ws.A, ws.ld, q, ws.part, ws.rs, s, gs, N, d, B, st);      // gs = A^T q + 2 rs s
-        if (rc != NW_OK) return rc;
+        int rc;
+        if (ws.split) {
+            rc = launch_bwd_qsplit(q, ws.ascale, ws.qv, ws.q_split, ws.gfac, B, ws.Bpad, d, st);
+            if (rc != NW_OK) return rc;
+            // gq = 2^-E_b (A' s') + 2 rq q: K = N runs along the rows of A' (zero past N), the rows of s' are clamped
+            rc = launch_xgemm(false, ws.A, ws.ld, B, ws.s_split, d, N, ws.part, ws.ascale, 0, nullptr, ws.rq, q, gq, B, d,
+                              N, st);
+            if (rc != NW_OK) return rc;
+            // gs = 2^(e_j - G) (A'^T q'') + 2 rs s: K = B runs across the rows of A' (clamped), q'' is zero past B
+            rc = launch_xgemm(true, ws.A, ws.ld, B, ws.q_split, d, ws.Bpad, ws.part, ws.s_scale, 1, ws.gfac, ws.rs, s, gs,
+                              N, d, B, st);
+            if (rc != NW_OK) return rc;
+        } else {
+            rc = launch_bwd_gemm<true>(ws.A, ws.ld, s, ws.part, ws.rq, q, gq, B, d, N, st);   // gq = A s + 2 rq q
+            if (rc != NW_OK) return rc;
+            rc = launch_bwd_gemm<false>(ws.A, ws.ld, q, ws.part, ws.rs, s, gs, N, d, B, st);      // gs = A^T q + 2 rs s
+            if (rc != NW_OK) return rc;
+        }
         if (glogit_scale) {
             if (kind == NW_SCORE_CLIP)
                 hipLaunchKernelGGL(nw_sum_kernel, dim3(1), dim3(256), 0, st, ws.gls, glogit_scale, B);

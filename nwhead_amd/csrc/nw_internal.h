@@ -37,6 +37,18 @@ int launch_influence(const float* probs_or_logp, const int64_t* qy, const float*
 // squared row norms of a (rows,d) matrix (backward.hip)
 int launch_rownorm2(const float* x, float* n2, int64_t rows, int64_t d, hipStream_t st);
 
+// bwd_split.hip: the backward's two products on the fp16 matrix cores (split-row operands)
+struct XgemmPlan {
+    int nchunks, k_chunk;
+};
+constexpr size_t XGEMM_TAIL_BYTES = 512;   // readable bytes every operand buffer needs past its last row
+XgemmPlan xgemm_plan(int64_t M, int64_t Nn, int64_t K);
+int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const float* Y, int64_t ldy, int64_t y_rows,
+                 float* part, const float* fac, int fac_inverse, const float* gfac, const float* rowscale,
+                 const float* Xo, float* out, int64_t M, int64_t Nn, int64_t K, hipStream_t st);
+int launch_bwd_qsplit(const float* q, const float* ascale, const float* qv, float* out, float* gfac, int64_t B,
+                      int64_t Bpad, int64_t d, hipStream_t st);
+
 // fused forward (fused.hip)
 int launch_topk(const float* scores, int64_t* idx, float* vals, int64_t B, int64_t N, int64_t k, hipStream_t st);  // topk.hip
 int tile_timer_enable(bool on);

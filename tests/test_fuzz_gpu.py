@@ -159,6 +159,58 @@ def test_backward_matrix_core_path(dev, ops, O, B, N, d, C, kind):
         np.testing.assert_allclose(ls.grad.item(), ls64.grad.item(), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,N,d,C", [(256, 10000, 512, 200), (200, 1037, 96, 10), (70, 1100, 32, 3), (129, 2500, 160, 7),
+                                       (64, 1024, 64, 5), (33, 4099, 64, 1000)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_backward_split_fp16_path(dev, ops, O, monkeypatch, B, N, d, C, kind):
+    """Both products of the backward on the fp16 matrix cores (bwd_split.hip: split-row operands, transposed LDS reads,
+    K split over workgroups for the first product): ragged M, N and K tiles, every kernel type; the same bar as the
+    fp32 matrix-core path.  NW_BWD_SPLIT=1 takes the path wherever the shape allows (d % 32 == 0), the first shape
+    (T) takes it by default."""
+    if (B, N) != (256, 10000):
+        monkeypatch.setenv("NW_BWD_SPLIT", "1")
+    g = torch.Generator().manual_seed(B + N)
+    q0, s0 = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+    if kind == "dotproduct":
+        q0, s0 = q0 * d ** -0.25, s0 * d ** -0.25
+    if (B, N) == (129, 2500):
+        s0 = s0 * torch.logspace(-3, 3, N).unsqueeze(1) if kind in ("cosine", "hypersphere", "clip") else s0 * 3.0
+    sy = torch.randint(0, C, (N,), generator=g)
+    t = torch.randint(0, C, (B,), generator=g)
+    q64, s64 = q0.double().requires_grad_(True), s0.double().requires_grad_(True)
+    ls64 = torch.tensor(LS0, dtype=torch.float64, requires_grad=True)
+    F.nll_loss(O.nw_head_f64(q64, s64, sy, C, kind, ls64) if kind != "clip" else _clip_head_f64(q64, s64, sy, C, ls64),
+               t).backward()
+    q, s = q0.to(dev).requires_grad_(True), s0.to(dev).requires_grad_(True)
+    ls = torch.tensor(LS0, device=dev, requires_grad=True) if kind == "clip" else None
+    F.nll_loss(ops.nw_head(q, s, sy.to(dev), C, kind, ls), t.to(dev)).backward()
+    for got, ref in ((q.grad, q64.grad), (s.grad, s64.grad)):
+        ref = ref.numpy()
+        assert torch.isfinite(got).all()
+        scale = max(float(np.abs(ref).max()), 1e-3)
+        np.testing.assert_allclose(got.cpu().numpy() / scale, ref / scale, rtol=1e-4, atol=1e-4)
+    if kind == "clip":
+        np.testing.assert_allclose(ls.grad.item(), ls64.grad.item(), rtol=1e-4, atol=1e-6)
+
+
+def test_backward_split_fp16_matches_fp32_matrix_core_path(dev, ops, monkeypatch):
+    """The two implementations of the products against each other, tighter than either against fp64 of the whole
+    head (whose error is the scores'): same coefficients in, 3e-6 of the largest gradient entry."""
+    B, N, d, C = 256, 10000, 512, 200
+    g = torch.Generator().manual_seed(3)
+    q0, s0 = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+    sy = (torch.arange(N) * C // N).to(dev)
+    t = torch.randint(0, C, (B,), generator=g).to(dev)
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NW_BWD_SPLIT", mode)
+        q, s = q0.to(dev).requires_grad_(True), s0.to(dev).requires_grad_(True)
+        F.nll_loss(ops.nw_head(q, s, sy, C, "euclidean"), t).backward()
+        grads[mode] = (q.grad.clone(), s.grad.clone())
+    for a, b in zip(grads["0"], grads["1"]):
+        assert ((a - b).abs().max() / a.abs().max()).item() < 3e-6
+
+
 def _clip_head_f64(q, s, sy, C, ls):
     """The oracle's fp64 head takes logit_scale by value; this keeps it in the graph (kernel.py:35-44)."""
     qn = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
