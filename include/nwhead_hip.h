@@ -156,6 +156,22 @@ int nw_bwd_f32(const float *q, const float *s, const int64_t *sy,
                int64_t B, int64_t N, int64_t d, int64_t C,
                int kind, const float *logit_scale_dev,
                int sup_batched, int labels_batched, void *stream);
+/* The same with the supports' bank as prepared for the forward (nw_split_rows_f16x2 of these very rows: s_split,
+ * s_scale, s_norm2; all three or none; shared (N,d) supports only).  On large shapes -- nw_bwd_uses_split(...) != 0:
+ * shared supports, d % 32 == 0, a row of N coefficients fits in LDS -- the two products of the backward
+ * (gq = A s + 2 rq q, gs = A^T q + 2 rs s) run on the fp16 matrix cores with split-row operands like the forward
+ * (three fp16 MFMAs per fp32 multiply-add, fp32 accumulation); without a bank the rows are split inside the call.
+ * A training step builds the bank once, hands it to nw_fwd_f32 (scores saved for the backward) and to this call. */
+int nw_bwd_uses_split(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched);
+int nw_bwd_bank_f32(const float *q, const float *s, const float *s_norm2, const float *s_split,
+                    const float *s_scale, const int64_t *sy,
+                    const float *scores, const float *lse, const float *out, const float *gout,
+                    float *gq, float *gs, float *glogit_scale,
+                    void *workspace, size_t workspace_bytes,
+                    int64_t B, int64_t N, int64_t d, int64_t C,
+                    int kind, const float *logit_scale_dev,
+                    int sup_batched, int labels_batched, void *stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * support_influence.  Replaces util/metric.py:23-50, vectorised over the query batch:

@@ -34,6 +34,8 @@ SIGNATURES = {
     "nw_merge_finalize_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     "nw_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int]),
     "nw_bwd_f32": (_int, [_p] * 10 + [_p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
+    "nw_bwd_uses_split": (_int, [_i64, _i64, _i64, _i64, _int]),
+    "nw_bwd_bank_f32": (_int, [_p] * 13 + [_p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
     "nw_support_influence_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "nw_aggregate_f32": (_int, [_p] * 5 + [_i64, _i64, _i64, _int, _p]),
     "nw_aggregate_bwd_f32": (_int, [_p] * 6 + [_i64, _i64, _i64, _int, _p]),

@@ -46,23 +46,43 @@ __global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
     const float* __restrict__ q = nullptr, int64_t d = 0, const float* __restrict__ s_scale = nullptr,
     float* __restrict__ ascale = nullptr, float* __restrict__ qv = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);
-    float* rowbuf = red + 16;                       // SPLIT: ld floats (16-byte aligned), then dP
-    float* dP = SPLIT ? rowbuf + ld : red + 16;
+    float* red = reinterpret_cast<float*>(smem);    // 16 floats for block_sum, 64 (redx) for the combined reduction
+    float* redx = red + 16;
+    float* rowbuf = red + 80;                       // SPLIT: ld floats (16-byte aligned), then dP
+    float* dP = SPLIT ? rowbuf + ld : red + 80;
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const float* row = scores + b * N;
     const int64_t* lab = sy + (labels_batched ? b * N : 0);
     const float l = lse[b];
+    float qm = 0.f;   // SPLIT: this thread's share of max_k |q[b,k]| (loads issued before anything waits)
+    if (SPLIT)
+        for (int64_t k = tid; k < d; k += nthr) qm = fmaxf(qm, fabsf(q[b * d + k]));
 
     for (int64_t c = tid; c < C; c += nthr) dP[c] = gout[b * C + c] * expf(-out[b * C + c]);
     __syncthreads();
 
+    // Both passes over the row take four elements per thread at a time, all loads first: a plain strided loop exposes
+    // one memory round trip per element (ten per thread at N = 10000), which was most of this kernel's time.
+    constexpr int U = 4;
     float t = 0.f;
-    for (int64_t j = tid; j < N; j += nthr) {
-        const int64_t y = lab[j];
-        const float dw = ((uint64_t)y < (uint64_t)C) ? dP[y] : 0.f;
-        t += expf(row[j] - l) * dw;
+    for (int64_t j0 = tid; j0 < N; j0 += (int64_t)U * nthr) {
+        float sc[U];
+        int64_t y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = min(j0 + (int64_t)u * nthr, N - 1);
+            sc[u] = row[j];
+            y[u] = lab[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = j0 + (int64_t)u * nthr;
+            if (j >= N) continue;
+            const float dw = ((uint64_t)y[u] < (uint64_t)C) ? dP[y[u]] : 0.f;
+            t += expf(sc[u] - l) * dw;
+            if (SPLIT) rowbuf[j] = sc[u];   // the second pass reads the scores from LDS (same thread, same j)
+        }
     }
     t = block_sum(t, red);
 
@@ -73,61 +93,98 @@ __global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
         nq = fmaxf(n, NW_NORM_EPS);
         inq2 = (n > NW_NORM_EPS) ? 1.f / (nq * nq) : 0.f;  // F.normalize clamps: no grad via |q|
     }
+    constexpr bool NORMS = (KIND == NW_SCORE_HYPERSPHERE || KIND == NW_SCORE_COSINE || KIND == NW_SCORE_CLIP);
     float rq_acc = 0.f, gls_acc = 0.f, amax = 0.f;
-    for (int64_t j = tid; j < N; j += nthr) {
-        const float sc = row[j];
-        const int64_t y = lab[j];
-        const float dw = ((uint64_t)y < (uint64_t)C) ? dP[y] : 0.f;
-        const float dS = expf(sc - l) * (dw - t);
-        float a, r;
-        if (KIND == NW_SCORE_DOT) {
-            a = dS;
-            r = 0.f;
-        } else if (KIND == NW_SCORE_EUCLIDEAN) {
-            const float D = -sc;
-            a = (D == 0.f) ? 0.f : dS / D;
-            r = -0.5f * a;
-            rq_acc += r;
-        } else {
-            const float sn = sqrtf(sn2[sup_batched ? b * N + j : j]);
-            const float ns = fmaxf(sn, NW_NORM_EPS);
-            const float ins2 = (sn > NW_NORM_EPS) ? 1.f / (ns * ns) : 0.f;
-            float fc, c;  // df/dcos and cos
-            if (KIND == NW_SCORE_HYPERSPHERE) {
+    for (int64_t j0 = tid; j0 < N; j0 += (int64_t)U * nthr) {
+        float scv[U], snv[U], ssc[U];
+        int64_t y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = min(j0 + (int64_t)u * nthr, N - 1);
+            scv[u] = SPLIT ? rowbuf[j] : row[j];
+            y[u] = lab[j];
+            snv[u] = NORMS ? sn2[sup_batched ? b * N + j : j] : 0.f;
+            ssc[u] = SPLIT ? s_scale[j] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = j0 + (int64_t)u * nthr;
+            if (j >= N) continue;
+            const float sc = scv[u];
+            const float dw = ((uint64_t)y[u] < (uint64_t)C) ? dP[y[u]] : 0.f;
+            const float dS = expf(sc - l) * (dw - t);
+            float a, r;
+            if (KIND == NW_SCORE_DOT) {
+                a = dS;
+                r = 0.f;
+            } else if (KIND == NW_SCORE_EUCLIDEAN) {
                 const float D = -sc;
-                fc = (D == 0.f) ? 0.f : 1.f / D;
-                c = 1.f - 0.5f * D * D;
+                a = (D == 0.f) ? 0.f : dS / D;
+                r = -0.5f * a;
+                rq_acc += r;
             } else {
-                fc = scale;
-                c = sc / scale;
-                gls_acc += dS * sc;  // d(e^ls cos)/d ls = score
+                const float sn = sqrtf(snv[u]);
+                const float ns = fmaxf(sn, NW_NORM_EPS);
+                const float ins2 = (sn > NW_NORM_EPS) ? 1.f / (ns * ns) : 0.f;
+                float fc, c;  // df/dcos and cos
+                if (KIND == NW_SCORE_HYPERSPHERE) {
+                    const float D = -sc;
+                    fc = (D == 0.f) ? 0.f : 1.f / D;
+                    c = 1.f - 0.5f * D * D;
+                } else {
+                    fc = scale;
+                    c = sc / scale;
+                    gls_acc += dS * sc;  // d(e^ls cos)/d ls = score
+                }
+                const float gc = dS * fc;
+                a = gc / (nq * ns);
+                rq_acc += gc * (-0.5f * c * inq2);
+                r = gc * (-0.5f * c * ins2);
             }
-            const float gc = dS * fc;
-            a = gc / (nq * ns);
-            rq_acc += gc * (-0.5f * c * inq2);
-            r = gc * (-0.5f * c * ins2);
+            if (SPLIT) {
+                const float ah = a * ssc[u];
+                rowbuf[j] = ah;
+                amax = fmaxf(amax, fabsf(ah));
+            } else {
+                A[b * ld + j] = a;
+            }
+            if (Rs) Rs[b * ld + j] = r;
         }
-        if (SPLIT) {
-            const float ah = a * s_scale[j];
-            rowbuf[j] = ah;
-            amax = fmaxf(amax, fabsf(ah));
-        } else {
-            A[b * ld + j] = a;
-        }
-        if (Rs) Rs[b * ld + j] = r;
     }
-    rq_acc = block_sum(rq_acc, red);
-    gls_acc = block_sum(gls_acc, red);
+    if (SPLIT)
+        for (int64_t j = N + tid; j < ld; j += nthr) rowbuf[j] = 0.f;   // the K padding of the first product
+    // the four block-wide results in ONE round (one barrier instead of eight; it also publishes rowbuf): per-wave
+    // values into the 4 x 16 table `redx`
+    rq_acc = wave_sum(rq_acc);
+    gls_acc = wave_sum(gls_acc);
+    amax = wave_max(amax);
+    qm = wave_max(qm);
+    {
+        const int w = tid >> 6;
+        if ((tid & 63) == 0) {
+            redx[w] = rq_acc;
+            redx[16 + w] = gls_acc;
+            redx[32 + w] = amax;
+            redx[48 + w] = qm;
+        }
+    }
+    __syncthreads();
+    {
+        const int nwv = (nthr + 63) >> 6;
+        rq_acc = gls_acc = 0.f;
+        amax = qm = 0.f;
+        for (int w = 0; w < nwv; ++w) {
+            rq_acc += redx[w];
+            gls_acc += redx[16 + w];
+            amax = fmaxf(amax, redx[32 + w]);
+            qm = fmaxf(qm, redx[48 + w]);
+        }
+    }
     if (tid == 0 && rq) {
         rq[b] = rq_acc;
         gls[b] = gls_acc;
     }
     if (SPLIT) {
-        for (int64_t j = N + tid; j < ld; j += nthr) rowbuf[j] = 0.f;   // the K padding of the first product
-        amax = block_max(amax, red);
-        float qm = 0.f;
-        for (int64_t k = tid; k < d; k += nthr) qm = fmaxf(qm, fabsf(q[b * d + k]));
-        qm = block_max(qm, red);   // (its barriers also publish rowbuf)
         const int E = split_exponent(amax);
         const float up = __builtin_ldexpf(1.f, E), down = __builtin_ldexpf(1.f, -E);
         if (tid == 0) {
@@ -344,42 +401,39 @@ __global__ __launch_bounds__(256) void nw_bwd_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(Cout + i * 4) = a;
 }
 
-// rs[j] = sum_b Rs[b*ld + j] in two deterministic stages.  Stage 1: a workgroup owns 256 columns (64
-// float4 lanes) x one slice of the rows, its four waves interleave the rows -> part[slice][j].
-constexpr int CS_MAX_SLICES = 8;
-inline int64_t colsum_rows(int64_t B) {  // rows per slice: >= 32, at most CS_MAX_SLICES slices
-    const int64_t r = (B + CS_MAX_SLICES - 1) / CS_MAX_SLICES;
-    return r < 32 ? 32 : r;
-}
-__global__ __launch_bounds__(256) void nw_colsum_part_kernel(const float* __restrict__ Rs, int64_t ld,
-                                                              float* __restrict__ part, int64_t B, int64_t rows) {
-    __shared__ float4 red[4][64];
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int64_t j = ((int64_t)blockIdx.x * 64 + c) * 4;  // ld % 4 == 0: whole float4s, pad columns included
-    const int64_t b0 = (int64_t)blockIdx.y * rows, b1 = b0 + rows < B ? b0 + rows : B;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < ld)
-        for (int64_t b = b0 + rl; b < b1; b += 4) {
+// rs[j] = sum_b Rs[b*ld + j], deterministic: a workgroup owns 64 columns (16 float4 lanes: 256 contiguous bytes per
+// row), its 16 row groups interleave the rows and are added in order through LDS.
+__global__ __launch_bounds__(256) void nw_colsum_kernel(const float* __restrict__ Rs, int64_t ld, float* __restrict__ rs,
+                                                         int64_t B, int64_t N) {
+    __shared__ float4 red[16][16];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int64_t j = ((int64_t)blockIdx.x * 16 + c) * 4;   // ld % 4 == 0: whole float4s, pad columns included
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a;
+    if (j < ld) {
+        int64_t b = rg;
+        for (; b + 16 < B; b += 32) {   // two independent loads in flight
+            const float4 v = *reinterpret_cast<const float4*>(Rs + b * ld + j);
+            const float4 w = *reinterpret_cast<const float4*>(Rs + (b + 16) * ld + j);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w;
+        }
+        if (b < B) {
             const float4 v = *reinterpret_cast<const float4*>(Rs + b * ld + j);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-    red[rl][c] = a;
-    __syncthreads();
-    if (rl == 0 && j < ld) {
-        const float4 p = red[1][c], q = red[2][c], r = red[3][c];
-        a.x = (a.x + p.x) + (q.x + r.x); a.y = (a.y + p.y) + (q.y + r.y);
-        a.z = (a.z + p.z) + (q.z + r.z); a.w = (a.w + p.w) + (q.w + r.w);
-        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * ld + j) = a;
+        a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
     }
-}
-// Stage 2: rs[j] = sum_slices part[slice][j]
-__global__ __launch_bounds__(256) void nw_colsum_final_kernel(const float* __restrict__ part, int64_t ld, int nslices,
-                                                               float* __restrict__ rs, int64_t N) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    float a = 0.f;
-    for (int sl = 0; sl < nslices; ++sl) a += part[(int64_t)sl * ld + j];
-    rs[j] = a;
+    red[rg][c] = a;
+    __syncthreads();
+    if (rg == 0 && j < N) {
+        for (int r = 1; r < 16; ++r) {
+            const float4 v = red[r][c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        const float o[4] = {a.x, a.y, a.z, a.w};
+        for (int e = 0; e < 4; ++e)
+            if (j + e < N) rs[j + e] = o[e];
+    }
 }
 
 struct GemmPlan {
@@ -430,7 +484,7 @@ __global__ __launch_bounds__(256) void nw_sum_kernel(const float* __restrict__ x
 }
 
 struct BwdWs {
-    float *A, *Rs, *rq, *gls, *qn2, *sn2, *rs, *part, *cs_part;
+    float *A, *Rs, *rq, *gls, *qn2, *sn2, *rs, *part;
     float *s_split, *s_scale, *q_split, *ascale, *qv, *gfac;   // split path (bwd_split.hip)
     int64_t ld;    // row stride of A and Rs: N, N rounded up to 4 floats (fp32 matrix cores) or to 32 (split path)
     int64_t Bpad;  // rows of q_split: B rounded up to 32, the rest zero
@@ -450,7 +504,7 @@ bool bwd_use_split(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched) 
     const int mode = env ? atoi(env) : -1;
     if (mode == 0 || !bwd_use_mfma(B, N, d, sup_batched) || d % 32 != 0) return false;
     const int64_t ld = (N + 31) / 32 * 32;
-    if ((size_t)(16 + ld + C) * sizeof(float) > 150 * 1024) return false;
+    if ((size_t)(80 + ld + C) * sizeof(float) > 150 * 1024) return false;
     if (mode == 1) return true;
     return B >= 64 && N >= 1024 && B * N * d >= (int64_t)1 << 27;
 }
@@ -473,11 +527,10 @@ size_t bwd_layout(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched, c
     w.gls = take((size_t)B);
     w.qn2 = take((size_t)B);
     w.sn2 = take(sup_batched ? (size_t)B * N : (size_t)N);
-    w.rs = w.part = w.cs_part = nullptr;
+    w.rs = w.part = nullptr;
     w.s_split = w.s_scale = w.q_split = w.ascale = w.qv = w.gfac = nullptr;
     if (w.mfma) {
         w.rs = take((size_t)N);
-        w.cs_part = take((size_t)CS_MAX_SLICES * w.ld);
         int cq, cs;
         if (w.split) {
             cq = xgemm_plan(B, d, N).nchunks, cs = xgemm_plan(N, d, B).nchunks;
@@ -516,13 +569,31 @@ extern "C" size_t nw_bwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_
     return nw::bwd_layout(B, N, d, C, sup_batched, nullptr, nullptr);
 }
 
+extern "C" int nw_bwd_uses_split(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched) {
+    if (B <= 0 || N <= 0 || d <= 0 || C < 0) return 0;
+    return nw::bwd_use_split(B, N, d, C, sup_batched) ? 1 : 0;
+}
+
 extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, const float* scores,
                           const float* lse, const float* out, const float* gout, float* gq,
                           float* gs, float* glogit_scale, void* workspace, size_t workspace_bytes,
                           int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                           const float* logit_scale_dev, int sup_batched, int labels_batched,
                           void* stream) {
+    return nw_bwd_bank_f32(q, s, nullptr, nullptr, nullptr, sy, scores, lse, out, gout, gq, gs, glogit_scale, workspace,
+                           workspace_bytes, B, N, d, C, kind, logit_scale_dev, sup_batched, labels_batched, stream);
+}
+
+extern "C" int nw_bwd_bank_f32(const float* q, const float* s, const float* s_norm2, const float* s_split,
+                               const float* s_scale, const int64_t* sy, const float* scores,
+                               const float* lse, const float* out, const float* gout, float* gq,
+                               float* gs, float* glogit_scale, void* workspace, size_t workspace_bytes,
+                               int64_t B, int64_t N, int64_t d, int64_t C, int kind,
+                               const float* logit_scale_dev, int sup_batched, int labels_batched,
+                               void* stream) {
     using namespace nw;
+    if ((s_split != nullptr) != (s_scale != nullptr) || (s_split && !s_norm2)) return NW_ERR_INVALID_ARG;
+    if (s_split && (sup_batched || d % 32 != 0 || (reinterpret_cast<uintptr_t>(s_split) & 15))) return NW_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (kind < NW_SCORE_EUCLIDEAN || kind > NW_SCORE_CLIP) return NW_ERR_UNSUPPORTED;
@@ -539,7 +610,7 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
     BwdWs ws;
     const size_t need = bwd_layout(B, N, d, C, sup_batched, static_cast<char*>(workspace), &ws);
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
-    const size_t lds = (16 + (size_t)C + (ws.split ? (size_t)ws.ld : 0)) * sizeof(float);
+    const size_t lds = (80 + (size_t)C + (ws.split ? (size_t)ws.ld : 0)) * sizeof(float);
     const unsigned coeff_threads = N >= 2048 ? 1024 : 256;
     if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
     const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(s) |
@@ -548,9 +619,15 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
 
     const bool norms = (kind == NW_SCORE_HYPERSPHERE || kind == NW_SCORE_COSINE || kind == NW_SCORE_CLIP);
     if (norms) hipLaunchKernelGGL(nw_rownorm_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, q, ws.qn2, B, d);
-    if (ws.split) {   // the supports as split rows (the forward's bank format); their squared norms come with it
+    if (ws.split && s_split) {   // the forward's bank: split rows, scales and norms of these very supports
+        ws.s_split = const_cast<float*>(s_split);
+        ws.s_scale = const_cast<float*>(s_scale);
+        ws.sn2 = const_cast<float*>(s_norm2);
+    } else if (ws.split) {   // the supports as split rows (the bank format); their squared norms come with it
         const int rc = launch_split_rows(s, ws.s_split, ws.s_scale, ws.sn2, N, d, st);
         if (rc != NW_OK) return rc;
+    } else if (norms && s_norm2 && !sup_batched) {
+        ws.sn2 = const_cast<float*>(s_norm2);
     } else if (norms) {
         hipLaunchKernelGGL(nw_rownorm_kernel, dim3((unsigned)((gs_rows + 3) / 4)), dim3(256), 0, st, s, ws.sn2, gs_rows, d);
     }
@@ -574,12 +651,7 @@ extern "C" int nw_bwd_f32(const float* q, const float* s, const int64_t* sy, con
     }
 #undef NW_COEFF
     if (ws.mfma) {
-        const int64_t cs_rows = colsum_rows(B);
-        const int nslices = (int)((B + cs_rows - 1) / cs_rows);
-        hipLaunchKernelGGL(nw_colsum_part_kernel, dim3((unsigned)((ws.ld / 4 + 63) / 64), (unsigned)nslices), dim3(256), 0,
-                           st, ws.Rs, ws.ld, ws.cs_part, B, cs_rows);
-        hipLaunchKernelGGL(nw_colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, ws.cs_part, ws.ld,
-                           nslices, ws.rs, N);
+        hipLaunchKernelGGL(nw_colsum_kernel, dim3((unsigned)((ws.ld / 4 + 15) / 16)), dim3(256), 0, st, ws.Rs, ws.ld, ws.rs, B, N);
         int rc;
         if (ws.split) {
             rc = launch_bwd_qsplit(q, ws.ascale, ws.qv, ws.q_split, ws.gfac, B, ws.Bpad, d, st);
@@ -634,7 +706,7 @@ extern "C" int nw_aggregate_bwd_f32(const float* scores, const int64_t* sy, cons
     if (B == 0 || N == 0) return NW_OK;
     if (!scores || !sy || !lse || !out || !gout || !gscores) return NW_ERR_INVALID_ARG;
     if (B > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
-    const size_t lds = (16 + (size_t)C) * sizeof(float);
+    const size_t lds = (80 + (size_t)C) * sizeof(float);
     if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
     const unsigned threads = N >= 2048 ? 1024 : 256;
     hipLaunchKernelGGL(nw_bwd_coeff_kernel<NW_SCORE_DOT>, dim3((unsigned)B), dim3(threads), lds, st, scores, lse, out, gout,

@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256, 2) void nw_conv1x1_kernel(
 // ---------------------------------------------------------------------------------------------------------------
 // The main kernel (cout % 128 == 0, hw % 4 == 0): LDS-DMA pipeline, no register staging.
 //   * both operand tiles go HBM/L2 -> LDS by global_load_lds_dwordx4 into a four-stage ring ([k][128] weight rows,
-//     [k][TN] activation rows, 16 k per stage), three stages ahead, counted vmcnt + one raw barrier per stage; every
-//     wave issues its share (4 DMAs per stage) between its own MFMAs -- no loader waves, two workgroups per CU.
+//     [k][TN] activation rows, 16 k per stage), three stages ahead, counted vmcnt + one raw barrier per stage.
+//     Waves 0-3 multiply, waves 4-7 only issue the DMAs (4 per wave and stage): a wave with LDS-DMAs in flight gets
+//     an s_waitcnt vmcnt(0) from hipcc in front of its LDS reads (it cannot tell the pending LDS write from the
+//     buffer being read), i.e. the ring would drain at every stage.  Two workgroups per CU.
 //   * fragments by ds_read_b128: lane (i, g) takes FOUR consecutive rows (columns) of k-row 4 kk + g and uses them
 //     as the operand of four MFMA blocks -- the block's row (column) index i then stands for row 4 i + e; the
 //     output tile is read back through the same map, which gives every lane four consecutive pixels per output
@@ -170,7 +172,7 @@ constexpr int DK = 16, DNBUF = 4;
 // B4: planes whose size is not a multiple of 4 (7x7): the activation rows go by 4-byte DMAs, one column per lane
 // (a 16-byte piece could straddle two images), and the results are stored one by one.  TN = 64 only.
 template <int TN, bool B4 = false>
-__global__ __launch_bounds__(256, 2) void nw_conv1x1_dma_kernel(
+__global__ __launch_bounds__(512, 2) void nw_conv1x1_dma_kernel(
     const float* __restrict__ x, int64_t x_bs, const float* __restrict__ pre_a, const float* __restrict__ pre_b,
     int pre_relu, const float* __restrict__ wt, const float* __restrict__ bias, int post_relu,
     float* __restrict__ out, int64_t out_bs, float* __restrict__ part, int n_img, int cin, int cout, int hw,
@@ -184,14 +186,15 @@ __global__ __launch_bounds__(256, 2) void nw_conv1x1_dma_kernel(
     float4* ring = reinterpret_cast<float4*>(smem);
     float2* pre = reinterpret_cast<float2*>(smem + (size_t)DNBUF * ST_F4 * 16);   // [k_chunk] (a, b) of channel kb + k
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;   // index within the role (consumer 0-3 / loader 0-3)
     const int m0 = blockIdx.y * 128;
     const int64_t col0 = (int64_t)blockIdx.x * TN, ncols = (int64_t)n_img * hw;
     const int kb = blockIdx.z * k_chunk, ke = min(cin, kb + k_chunk);
     const int nst = (ke - kb + DK - 1) / DK;
     const int wm = (TN == 128) ? (wave >> 1) * 64 : wave * 32, wn = (TN == 128) ? (wave & 1) * 64 : 0;
 
-    for (int k = tid; k < nst * DK; k += 256) {
+    for (int k = tid; k < nst * DK; k += 512) {
         const int kc = min(kb + k, cin - 1);
         pre[k] = pre_a ? make_float2(pre_a[kc], pre_b[kc]) : make_float2(1.f, 0.f);
     }
@@ -246,16 +249,28 @@ __global__ __launch_bounds__(256, 2) void nw_conv1x1_dma_kernel(
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: three stages in flight, the first one landed
+    if (wave8 >= 4) {
+        // loader waves.  prologue: three stages in flight, the first one landed
 #pragma unroll
-    for (int s = 0; s < DNBUF - 1; ++s)
-        if (s < nst) issue(s);
-    if (nst >= DNBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // (also publishes `pre`)
+        for (int s = 0; s < DNBUF - 1; ++s)
+            if (s < nst) issue(s);
+        if (nst >= DNBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's share of `pre`)
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nst; ++s) {
+            if (s + DNBUF - 1 < nst) issue(s + DNBUF - 1);   // into the buffer the consumers left at the last barrier
+            // stage s + 1 of this wave has landed once at most the two youngest stages are in flight
+            if (s + DNBUF - 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // stage 0 has landed, `pre` is published
 
     for (int s = 0; s < nst; ++s) {
-        if (s + DNBUF - 1 < nst) issue(s + DNBUF - 1);   // into the buffer every wave left at the last barrier
         const float4* As = ring + (unsigned)(s % DNBUF) * ST_F4;
         const float4* Bs = As + A_F4;
 #pragma unroll
@@ -280,9 +295,6 @@ __global__ __launch_bounds__(256, 2) void nw_conv1x1_dma_kernel(
                 for (int b = 0; b < NB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
-        // stage s + 1 of this wave has landed once at most the two youngest stages are in flight
-        if (s + DNBUF - 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -430,7 +442,7 @@ extern "C" int nw_conv1x1_f32(const float* x, int64_t x_batch_stride, const floa
         const size_t lds = DNBUF * stage + (size_t)k_chunk * 8;
         const dim3 grid((unsigned)gx, (unsigned)(cout / 128), (unsigned)nz);
 #define NW_C1D(TN_, B4_)                                                                                                  \
-    hipLaunchKernelGGL((nw_conv1x1_dma_kernel<TN_, B4_>), grid, dim3(256), lds, st, x, x_batch_stride, pre_scale, pre_shift, \
+    hipLaunchKernelGGL((nw_conv1x1_dma_kernel<TN_, B4_>), grid, dim3(512), lds, st, x, x_batch_stride, pre_scale, pre_shift, \
                        pre_relu, w_t, bias, post_relu, out, out_batch_stride, part, (int)n, (int)cin, (int)cout, (int)hw, k_chunk)
         if (!v16) NW_C1D(64, true);
         else if (tn == 128) NW_C1D(128, false);

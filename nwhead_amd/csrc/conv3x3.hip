@@ -19,7 +19,10 @@
 // stage, output channels contiguous), rows past cin zero, so a stage's weight rows are DMA'd as they lie.
 // MFMA: v_mfma_f32_16x16x4_f32, exact fp32 multiply-adds; four k per instruction = four input channels of one tap.
 // Wave tile 32 (M) x 64 (N): 2 x 4 blocks, 8 independent accumulators; four waves per workgroup as WMW x WNW.
-// Three-stage LDS ring, two stages in flight, every wave issues its share of the DMAs, one barrier per stage.
+// Three-stage LDS ring, two stages in flight, one barrier per stage; the four multiplying waves are fed by four
+// loader waves that only issue the DMAs (a wave with LDS-DMAs in flight gets an s_waitcnt vmcnt(0) from hipcc in
+// front of its LDS reads -- it cannot tell the pending LDS write from the buffer being read -- so a wave that did
+// both would wait for the stage it has just requested).
 #include "nw_internal.h"
 #include <cstdlib>
 
@@ -41,7 +44,7 @@ struct C3Cfg {
 // `lrow`: floats per channel row of the span in LDS (a whole number of DMA instructions + 32), `padl`: pixels staged in
 // front of the tile (W + 1, or W + 4 when 16-byte pieces need an aligned origin), `nb`: DMA instructions per row.
 template <int WMW, int WNW, bool VEC>
-__global__ __launch_bounds__(256, 2) void nw_conv3x3_kernel(
+__global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     const float* __restrict__ x, int64_t x_bs, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ res, int64_t res_bs, int post_relu, float* __restrict__ out, int64_t out_bs,
     int n_img, int cin, int cout, int H, int W, int tiles_per_img, int lrow, int padl, int nb) {
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void nw_conv3x3_kernel(
     const int stage_f = A_F + C3K * lrow;                      // floats per stage
     float* ring = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;   // index within the role: consumer waves 0-3, loader waves 4-7
     const int img = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - img * tiles_per_img) * TN;
     const int m0 = blockIdx.y * TM;
     const int HW = H * W;
@@ -133,9 +137,7 @@ __global__ __launch_bounds__(256, 2) void nw_conv3x3_kernel(
 
     // two stages in flight; vmcnt cannot take a run-time count, so a stage is waited for by draining the queue
     // down to one stage's worth with a loop over the (at most two) outstanding ones
-    issue(0);
-    if (nst > 1) issue(1);
-    const int per = A_PER + 2 * nb;                 // DMAs per wave and stage (wave-uniform)
+    const int per = A_PER + 2 * nb;                 // DMAs per loader wave and stage (wave-uniform)
     auto wait_all_but = [&](int keep) {             // keep = 0 or `per`
         if (keep == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else {
@@ -159,14 +161,24 @@ __global__ __launch_bounds__(256, 2) void nw_conv3x3_kernel(
             }
         }
     };
-    wait_all_but(nst > 1 ? per : 0);
-    __syncthreads();
+    if (wave8 >= 4) {
+        issue(0);
+        if (nst > 1) issue(1);
+        wait_all_but(nst > 1 ? per : 0);
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nst; ++s) {
+            if (s + 2 < nst) issue(s + 2);              // into the buffer the consumers left at the last barrier
+            wait_all_but(s + 2 < nst ? per : 0);        // stage s + 1 has landed (this wave's share)
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    __builtin_amdgcn_s_barrier();                   // stage 0 has landed
 
     // B fragment of tap t, channel group kk (channels 4 kk + g of the stage), N-block e:
     //   row (4 kk + g), element  wn + 16 e + i + padl + (ky - 1) W + (kx - 1)
     const int bbase = wn + i + padl - W - 1;        // + 16 e + ky W + kx
     for (int s = 0; s < nst; ++s) {
-        if (s + 2 < nst) issue(s + 2);              // into the buffer every wave left at the last barrier
         const float* As = ring + (unsigned)(s % C3NBUF) * stage_f;
         const float* Bs = As + A_F;
 #pragma unroll
@@ -193,7 +205,6 @@ __global__ __launch_bounds__(256, 2) void nw_conv3x3_kernel(
                         acc[a][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[e], acc[a][e], 0, 0, 0);
             }
         }
-        wait_all_but(s + 2 < nst ? per : 0);        // stage s + 1 has landed (this wave's share)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -263,7 +274,7 @@ extern "C" int nw_conv3x3_f32(const float* x, int64_t x_batch_stride, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)gx, (unsigned)(cout / tm));
 #define NW_C3(MW_, NW_, V_)                                                                                              \
-    hipLaunchKernelGGL((nw_conv3x3_kernel<MW_, NW_, V_>), grid, dim3(256), lds, st, x, x_batch_stride, w_t, bias, residual, \
+    hipLaunchKernelGGL((nw_conv3x3_kernel<MW_, NW_, V_>), grid, dim3(512), lds, st, x, x_batch_stride, w_t, bias, residual, \
                        res_batch_stride, post_relu, out, out_batch_stride, (int)n, (int)cin, (int)cout, (int)H, (int)W, tiles, \
                        lrow, padl, nb)
     if (wmw == 1) { if (vec) NW_C3(1, 4, true); else NW_C3(1, 4, false); }

@@ -408,7 +408,7 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
         // 62.4 / 62.3: raw up to 1.5 workgroups per CU.  NW_SPLIT_QUERIES=1 / 0 forces either.
         static const int force_split = [] { const char* e = getenv("NW_SPLIT_QUERIES"); return e ? atoi(e) : -1; }();
         const bool raw_ok = force_split == 0 || (force_split < 0 && 2 * grid <= 3 * device_cu_count());
-        if (scores || persistent || !raw_ok) {
+        if (persistent || !raw_ok) {
             float *qr, *qsc, *qn;
             const int rc = split_queries_into_workspace(q, workspace, workspace_bytes, B, N, d, C, &qr, &qsc, &qn, st);
             if (rc != NW_OK) return rc;
@@ -420,7 +420,7 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
     const int timer_slot = tile_timer_start(st);
     if (s_scale) {
         if (!q_scale) {
-            NW_LAUNCH(false, MODE_F16Q, lds_dma);
+            if (scores) NW_LAUNCH(true, MODE_F16Q, lds_dma); else NW_LAUNCH(false, MODE_F16Q, lds_dma);
         } else if (scores) {
             NW_LAUNCH(true, MODE_F16, lds_dma);
         } else if (persistent) {

@@ -229,6 +229,15 @@ class _NWHeadFn(torch.autograd.Function):
         N = sc.shape[-2]
         dev = qc.device
         need_bwd = any(ctx.needs_input_grad[:2]) or (logit_scale is not None and ctx.needs_input_grad[3])
+        if (need_bwd and ssplit is None and not sup_b and N > 0
+                and lib.nw_bwd_uses_split(B, N, d, n_classes, 0)):
+            # a training step at a size where the backward's products run on split rows: split the supports once,
+            # for this forward (fp16 matrix cores instead of fp32) and for the backward
+            ssplit, sscale = torch.empty_like(sc), torch.empty(N, dtype=torch.float32, device=dev)
+            sn2 = torch.empty(N, dtype=torch.float32, device=dev)
+            with _OnDevice(dev):
+                _lib.check(lib.nw_split_rows_f16x2(_ptr(sc), _ptr(ssplit), _ptr(sscale), _ptr(sn2), N, d, _stream(qc)),
+                           "nw_split_rows_f16x2")
         out = torch.empty(B, n_classes, dtype=torch.float32, device=dev)
         scores = torch.empty(B, N, dtype=torch.float32, device=dev) if need_bwd else None
         lse = torch.empty(B, dtype=torch.float32, device=dev) if need_bwd else None
@@ -247,6 +256,8 @@ class _NWHeadFn(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(qc, sc, syc, scores, lse, out, ls if ls is not None else torch.empty(0, device=dev))
             ctx.meta = (B, N, d, n_classes, kind_id, sup_b, lab_b, ls is not None)
+            # the bank of these supports, if there is one (a SplitBank's tensors are never written again)
+            ctx.bank = (sn2, ssplit, sscale) if (ssplit is not None and not sup_b) else (None, None, None)
         if want_weights:
             ctx.mark_non_differentiable(weights)
             return out, weights
@@ -264,11 +275,13 @@ class _NWHeadFn(torch.autograd.Function):
         gls = torch.empty((), dtype=torch.float32, device=dev) if has_ls else None
         ws_bytes = lib.nw_bwd_workspace_bytes(B, N, d, C, kind_id, int(sup_b))
         ws = _workspace(ws_bytes, dev)
+        bn2, bsplit, bscale = ctx.bank
         with torch.cuda.device(dev):
-            _lib.check(lib.nw_bwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(scores), _ptr(lse), _ptr(out),
-                                      _ptr(g), _ptr(gq), _ptr(gs), _ptr(gls), _ptr(ws), ws_bytes,
-                                      B, N, d, C, kind_id, _ptr(ls) if has_ls else None,
-                                      int(sup_b), int(lab_b), _stream(qc)), "nw_bwd_f32")
+            _lib.check(lib.nw_bwd_bank_f32(_ptr(qc), _ptr(sc), _ptr(bn2), _ptr(bsplit), _ptr(bscale), _ptr(syc),
+                                           _ptr(scores), _ptr(lse), _ptr(out),
+                                           _ptr(g), _ptr(gq), _ptr(gs), _ptr(gls), _ptr(ws), ws_bytes,
+                                           B, N, d, C, kind_id, _ptr(ls) if has_ls else None,
+                                           int(sup_b), int(lab_b), _stream(qc)), "nw_bwd_bank_f32")
         return gq, gs, None, gls, None, None, None, None, None
 
 
