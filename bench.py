@@ -107,9 +107,11 @@ def measure_shape(B, N, d, C, dev, iters):
 
 
 def measure_train_head(B, N, d, C, dev, iters=30):
-    """A4 at a large shape: nll_loss(NWHead(x, sx, sy)).backward() with gradients for queries and supports
-    (scores written by the forward, coefficients, two fp32-MFMA products).  Event time of the whole
-    Python-driven step, so torch's autograd bookkeeping (~0.15 ms) is inside it."""
+    """A4 at a large shape: nll_loss(NWHead(x, sx, sy)).backward() with gradients for queries and supports (the
+    supports split once for the forward and the backward, scores written by the forward, coefficients, the two
+    products on the fp16 matrix cores).  Two figures: the Python-driven step (torch's autograd bookkeeping and ~15
+    launches: bound by the host) and the same step captured once as a HIP graph (torch.cuda.CUDAGraph) and
+    replayed: bound by the kernels."""
     import torch.nn.functional as F
     from nwhead_amd import ops
     q, s, sy = make_inputs(B, N, d, C, dev)
@@ -121,8 +123,29 @@ def measure_train_head(B, N, d, C, dev, iters=30):
         q.grad = s.grad = None
         F.nll_loss(ops.nw_head(q, s, sy, C), t).backward()
     dt = time_kernel_events(step, iters)
-    return {"B": B, "N": N, "d": d, "C": C, "ms_per_fwd_bwd": dt * 1e3,
-            "TFLOPs_fwd_plus_bwd_products": 6 * B * N * d / dt / 1e12}
+    res = {"B": B, "N": N, "d": d, "C": C, "ms_per_fwd_bwd": dt * 1e3,
+           "TFLOPs_fwd_plus_bwd_products": 6 * B * N * d / dt / 1e12}
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        gq_ref, gs_ref = q.grad.clone(), s.grad.clone()
+        graph = torch.cuda.CUDAGraph()
+        q.grad = s.grad = None
+        with torch.cuda.graph(graph):
+            F.nll_loss(ops.nw_head(q, s, sy, C), t).backward()
+        graph.replay()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(q.grad, gq_ref) and torch.equal(s.grad, gs_ref))
+        dg = time_kernel_events(graph.replay, iters)
+        res.update({"ms_per_fwd_bwd_hip_graph": dg * 1e3, "TFLOPs_fwd_plus_bwd_products_hip_graph": 6 * B * N * d / dg / 1e12,
+                    "hip_graph_gradients_equal_eager": same})
+    except Exception as e:   # a graph that cannot be captured is a finding, not a crash of the bench
+        res["hip_graph_error"] = repr(e)[:200]
+    return res
 
 
 def measure_shuffled(B, N, d, C, dev, iters=20):

@@ -82,16 +82,6 @@ __global__ __launch_bounds__(512, XNBUF <= 3 ? 2 : 1) void nw_xgemm_kernel(
         const int ltid = tid - 256;
         float4 xo[8];
         float ff[8], rs2[8], gf = 1.f;
-        if (FUSE) {   // loads only: nothing here may wait for a result before the DMAs are on their way
-            if (gfac) gf = *gfac;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int m = min(m0 + 16 * t + (ltid >> 4), M - 1), n = n0 + 4 * (ltid & 15);
-                xo[t] = *reinterpret_cast<const float4*>(Xo + (int64_t)m * Nn + (n < Nn ? n : 0));
-                ff[t] = fac[m];
-                rs2[t] = rowscale[m];
-            }
-        }
         // DMA sources (per lane; a stage advances them by 32 k).  X: 16 instructions per stage, loader wave lw issues
         // t = 4 lw .. 4 lw + 3; Y: 8 instructions (4 k-rows of 256 bytes each), t = 2 lw, 2 lw + 1
         const char* xsrc[4];
@@ -143,6 +133,18 @@ __global__ __launch_bounds__(512, XNBUF <= 3 ? 2 : 1) void nw_xgemm_kernel(
 #pragma unroll
         for (int s = 0; s < XNBUF - 1; ++s)
             if (s < nst) issue(s);
+        // the rank-one term's operands, behind the first DMAs: loads return in order, so the counted waits below
+        // cover them too (the first barrier waits for them: they arrive with the first stages, not in front of them)
+        if (FUSE) {   // loads only: nothing here may wait for a result before the DMAs are on their way
+            if (gfac) gf = *gfac;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int m = min(m0 + 16 * t + (ltid >> 4), M - 1), n = n0 + 4 * (ltid & 15);
+                xo[t] = *reinterpret_cast<const float4*>(Xo + (int64_t)m * Nn + (n < Nn ? n : 0));
+                ff[t] = fac[m];
+                rs2[t] = rowscale[m];
+            }
+        }
         if (nst >= XNBUF - 1) wait_vmcnt<FLY>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
