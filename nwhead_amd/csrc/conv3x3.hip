@@ -13,8 +13,13 @@
 // TM output channels x TN consecutive pixels.  Per stage of 8 input channels it needs, for every channel, the plane's
 // pixels [p0 - W - 1, p0 + TN + W + 1): ONE contiguous span serves all nine taps -- tap (ky, kx) of pixel p is the span
 // element p + (ky - 1) W + (kx - 1) -- so the span goes HBM/L2 -> LDS once (LDS-DMA, 16 bytes per lane when W % 4 == 0)
-// and the nine shifted B fragments are plain ds_read_b32 at nine constant offsets; image borders (and the columns of
-// a ragged last tile) are a 9-bit validity mask per lane and column, applied with one v_cndmask.
+// and the nine shifted B fragments are plain ds_read_b32 at nine constant offsets.  Image borders cost nothing in the
+// loop (fp32 MFMAs do not overlap with vector ALU work on their SIMD: a v_cndmask per loaded value was a third of the
+// loop's time): the span lies in LDS with the image's rows `pitch` = W + gap floats apart (gap = 4 with 16-byte DMA
+// pieces, else 1) and every piece that is not a pixel of the plane -- the gap behind each row, the rows above the
+// first and below the last -- comes from a buffer of ZEROS (the DMA source is chosen per lane).  Tap (ky, kx) of
+// pixel (y, x) is LDS element y pitch + x + (ky-1) pitch + (kx-1): column -1 and column W are the gap, rows -1 and H
+// are zero rows.  No masks, one accumulator set.
 // Weights are passed re-laid out once at fold time as Wt[cin/8][tap][8][cout] (k-major: k = tap * 8 + ci within a
 // stage, output channels contiguous), rows past cin zero, so a stage's weight rows are DMA'd as they lie.
 // MFMA: v_mfma_f32_16x16x4_f32, exact fp32 multiply-adds; four k per instruction = four input channels of one tap.
@@ -30,6 +35,7 @@ namespace nw {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __attribute__((aligned(16))) float nw_c3_zeros[4];   // source of the DMA pieces outside the plane
 constexpr int C3K = 8;      // input channels per stage
 constexpr int C3NBUF = 3;
 
@@ -41,13 +47,13 @@ struct C3Cfg {
     static constexpr int A_PER = (A_DMA + 3) / 4;            // ... per wave (the surplus repeats the last piece)
 };
 
-// `lrow`: floats per channel row of the span in LDS (a whole number of DMA instructions + 32), `padl`: pixels staged in
-// front of the tile (W + 1, or W + 4 when 16-byte pieces need an aligned origin), `nb`: DMA instructions per row.
+// `lrow`: floats per channel row of the span in LDS (a whole number of DMA instructions + 32), `nb`: DMA instructions
+// per channel row.  LDS coordinate of pixel p = (y, x): L(p) = y pitch + x; the span starts at L(p0) - pitch - gap.
 template <int WMW, int WNW, bool VEC>
 __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     const float* __restrict__ x, int64_t x_bs, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ res, int64_t res_bs, int post_relu, float* __restrict__ out, int64_t out_bs,
-    int n_img, int cin, int cout, int H, int W, int tiles_per_img, int lrow, int padl, int nb) {
+    int n_img, int cin, int cout, int H, int W, int tiles_per_img, int lrow, int nb) {
     using Cfg = C3Cfg<WMW, WNW, VEC>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, A_F = Cfg::A_F, A_DMA = Cfg::A_DMA, A_PER = Cfg::A_PER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,24 +68,6 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     const int wm = 32 * (wave / WNW), wn = 64 * (wave % WNW);
     const int nst = (cin + C3K - 1) / C3K;
     const float* ximg = x + (int64_t)img * x_bs;
-
-    // ---- validity of the nine taps for this lane's four columns (N-block e: column wn + 16 e + i), as 36 booleans:
-    // the compiler keeps a per-lane boolean as a wave-wide bit mask in a scalar register pair, so masking a loaded value
-    // is ONE v_cndmask (fp32 MFMAs do not overlap with vector ALU work on their SIMD: every VALU op in the loop is
-    // matrix time; bit-field masks in a VGPR cost three ops per value and 47 % of the loop)
-    // The 9 x 4 validities factor into 5 x 4 conditions (pixel inside the plane, not on the top / bottom row, not in
-    // the first / last column); a tap's mask is their AND, scalar ALU work.
-    bool pv[4], yt[4], yb[4], xl[4], xr[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int p = p0 + wn + 16 * e + i;
-        const int yy = p / W, xx = p - yy * W;
-        pv[e] = p < HW;
-        yt[e] = yy >= 1;
-        yb[e] = yy <= H - 2;
-        xl[e] = xx >= 1;
-        xr[e] = xx <= W - 2;
-    }
 
     // ---- DMA plans.  Weights: the stage's 9*8 rows of TM floats; when cout == TM they are one contiguous block,
     // otherwise rows of TM*4 bytes at a stride of cout*4.  Piece t of 1 KB: rows (1024 / (4 TM)) t ...
@@ -97,13 +85,19 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     }
     // Span: channel row c of the stage gets nb instructions; instruction b covers span elements [64 b, 64 b + 64)
     // (float4 groups when VEC).  Per wave: 2 channels (8 per stage / 4 waves).
-    const int per_el = VEC ? 4 : 1;
-    auto span_pixel = [&](int b) {                  // clamped source pixel of this lane's piece of instruction b
-        int q = p0 - padl + (64 * b + lane) * per_el;
-        const int hi = HW - per_el;
-        q = q < 0 ? 0 : (q > hi ? hi : q);          // pieces outside the plane repeat a valid one (masked when read)
-        return q;
-    };
+    constexpr int per_el = VEC ? 4 : 1, GAP = VEC ? 4 : 1;
+    const int pitch = W + GAP;
+    const int y0 = p0 / W;
+    const int origin = y0 * pitch + (p0 - y0 * W) - pitch - GAP;   // LDS coordinate of the span's first element (VEC: % 4 == 0)
+    // source of this lane's piece of instruction b, as an offset into the plane; -1: not a pixel (gap, outside rows)
+    int soff[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int lc = origin + (64 * b + lane) * per_el;
+        const int r = (lc + pitch) / pitch - 1;     // floor(lc / pitch) for lc >= -pitch (the origin is at least that)
+        const int c = lc - r * pitch;
+        soff[b] = (r < 0 || r >= H || c >= W) ? -1 : r * W + c;
+    }
     auto issue = [&](int s) {
         float* st = ring + (unsigned)(s % C3NBUF) * stage_f;
         const int64_t koff = (int64_t)s * 9 * C3K * cout * 4;    // bytes: the stage's first weight row
@@ -117,8 +111,10 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
             const int ci = min(s * C3K + cl, cin - 1);   // rows past cin meet zero weights: any finite data will do
             const float* plane = ximg + (int64_t)ci * HW;
             float* drow = st + A_F + cl * lrow + 16 * (cl & 1);
-            for (int b = 0; b < nb; ++b) {
-                const float* src = plane + span_pixel(b);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b >= nb) break;
+                const float* src = soff[b] < 0 ? nw_c3_zeros : plane + soff[b];
                 if (VEC)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(drow + 256 * b), 16, 0, 0);
@@ -175,27 +171,28 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     }
     __builtin_amdgcn_s_barrier();                   // stage 0 has landed
 
-    // B fragment of tap t, channel group kk (channels 4 kk + g of the stage), N-block e:
-    //   row (4 kk + g), element  wn + 16 e + i + padl + (ky - 1) W + (kx - 1)
-    const int bbase = wn + i + padl - W - 1;        // + 16 e + ky W + kx
+    // B fragment of tap t, channel group kk (channels 4 kk + g of the stage), N-block e: row (4 kk + g), element
+    //   L(p) - origin + (ky - 1) pitch + (kx - 1),  p = p0 + wn + 16 e + i  (columns past the plane repeat its last pixel)
+    int bidx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int p = min(p0 + wn + 16 * e + i, HW - 1);
+        const int yy = p / W;
+        bidx[e] = yy * pitch + (p - yy * W) - origin - pitch - 1;   // + ky pitch + kx
+    }
     for (int s = 0; s < nst; ++s) {
         const float* As = ring + (unsigned)(s % C3NBUF) * stage_f;
         const float* Bs = As + A_F;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int toff = (t / 3) * W + (t % 3);
+            const int toff = (t / 3) * pitch + (t % 3);
 #pragma unroll
             for (int kk = 0; kk < C3K / 4; ++kk) {
                 const int cl = 4 * kk + g;
-                const float* brow = Bs + cl * lrow + 16 * (cl & 1) + bbase + toff;
+                const float* brow = Bs + cl * lrow + 16 * (cl & 1) + toff;
                 float bv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = brow[16 * e];
-                    const bool okv = pv[e] && (t / 3 == 0 ? yt[e] : (t / 3 == 2 ? yb[e] : true)) &&
-                                     (t % 3 == 0 ? xl[e] : (t % 3 == 2 ? xr[e] : true));
-                    bv[e] = okv ? v : 0.f;
-                }
+                for (int e = 0; e < 4; ++e) bv[e] = brow[bidx[e]];
                 const float2 a2 = *reinterpret_cast<const float2*>(As + (t * C3K + cl) * TM + wm + 2 * i);
                 const float av[2] = {a2.x, a2.y};
 #pragma unroll
@@ -233,10 +230,11 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
 }  // namespace
 }  // namespace nw
 
-// span geometry shared by the launcher and the kernel
-static void conv3x3_span(int tn, int W, bool vec, int* lrow, int* padl, int* nb) {
-    *padl = vec ? W + 4 : W + 1;
-    const int L = tn + *padl + W + 1;                          // span elements a tile can touch
+// span geometry: rows `pitch` = W + gap apart in LDS; a tile of tn pixels starts at most W - 1 into a row
+static void conv3x3_span(int tn, int W, bool vec, int* lrow, int* nb) {
+    const int gap = vec ? 4 : 1, pitch = W + gap;
+    const int rows = (tn + W - 2) / W + 1;                      // image rows a tile can touch
+    const int L = rows * pitch + 2 * pitch + 2 * gap;          // + the row above and below, + the corners
     const int per = vec ? 256 : 64;                            // floats per DMA instruction
     *nb = (L + per - 1) / per;
     *lrow = *nb * per + 32;                                    // + the 16-float stagger of odd rows
@@ -266,8 +264,8 @@ extern "C" int nw_conv3x3_f32(const float* x, int64_t x_batch_stride, const floa
     const int tiles = (int)((HW + tn - 1) / tn);
     const int64_t gx = (int64_t)tiles * n;
     if (gx > 0x7fffffffLL || cout / tm > 65535) return NW_ERR_INVALID_ARG;
-    int lrow, padl, nb;
-    conv3x3_span(tn, (int)W, vec, &lrow, &padl, &nb);
+    int lrow, nb;
+    conv3x3_span(tn, (int)W, vec, &lrow, &nb);
     if (nb > 8) return NW_ERR_UNSUPPORTED;                       // very wide images: not a backbone shape
     const size_t lds = (size_t)C3NBUF * (9 * C3K * tm + C3K * lrow) * sizeof(float);
     if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
@@ -276,7 +274,7 @@ extern "C" int nw_conv3x3_f32(const float* x, int64_t x_batch_stride, const floa
 #define NW_C3(MW_, NW_, V_)                                                                                              \
     hipLaunchKernelGGL((nw_conv3x3_kernel<MW_, NW_, V_>), grid, dim3(512), lds, st, x, x_batch_stride, w_t, bias, residual, \
                        res_batch_stride, post_relu, out, out_batch_stride, (int)n, (int)cin, (int)cout, (int)H, (int)W, tiles, \
-                       lrow, padl, nb)
+                       lrow, nb)
     if (wmw == 1) { if (vec) NW_C3(1, 4, true); else NW_C3(1, 4, false); }
     else if (wmw == 2) { if (vec) NW_C3(2, 2, true); else NW_C3(2, 2, false); }
     else { if (vec) NW_C3(4, 1, true); else NW_C3(4, 1, false); }

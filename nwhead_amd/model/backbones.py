@@ -112,13 +112,15 @@ class ResNet(nn.Module):
 # ----------------------------------------------------------------------------- CIFAR pre-act ResNet
 DENSE_PASSTHROUGH = True        # the running concatenation passes through norm1's autograd node (see _DenseBlock.forward)
 DENSE_INCREMENTAL_CAT = True    # dense blocks extend one running concatenation (see _DenseBlock.forward)
-# Folded inference copies: 3x3 convolutions as the implicit-GEMM kernel (Conv3x3Fused, csrc/conv3x3.hip).  OFF by default:
-# the kernel is parity-tested (tests/test_conv3x3_gpu.py) and writes straight into the dense-block slab, but a direct
-# convolution on the fp32 matrix cores (54-79 TFLOP/s measured, 157 peak) loses to MIOpen's Winograd kernels (72-101
-# TFLOP/s-equivalent: 2.25x fewer multiplies): DenseNet-121 over 64 images 6.48 ms with it, 6.10 ms without
-# (tools/conv3x3_time.py).  NW_OWN_CONV3X3=1 or backbones.FUSED_CONV3X3 = True turn it on.
+# Folded inference copies: the dense layers' 3x3 convolutions as the implicit-GEMM kernel (Conv3x3Fused,
+# csrc/conv3x3.hip), which writes straight into the dense-block slab.  A direct convolution on the fp32 matrix cores
+# (80-88 TFLOP/s on the big planes since the loop lost its border masks and its vmcnt(0) stalls; MIOpen's Winograd
+# kernels, 2.25x fewer multiplies, reach 80-93 on NCHW and 90-99 on channels_last tensors): on DenseNet-121's shapes
+# (128 -> 32 channels) it is ahead of MIOpen's NCHW kernels at 56x56 and 28x28 (169 vs 186 us, 53 vs 61) and the
+# small planes stay on MIOpen (Conv3x3Fused._use_kernel: too few workgroups); DenseNet-121 over 64 images 5.63 ms
+# with it, 5.70 without (tools/fold_time.py, same box).  NW_OWN_CONV3X3=0 turns it off.
 import os as _os
-FUSED_CONV3X3 = _os.environ.get("NW_OWN_CONV3X3") == "1"
+FUSED_CONV3X3 = _os.environ.get("NW_OWN_CONV3X3", "1") != "0"
 FUSED_CONV1X1 = True            # folded inference copies: 1x1 convolutions with their BatchNorm / ReLU neighbours as one kernel (Conv1x1Fused)
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
 
