@@ -77,6 +77,21 @@ int main() {
            NW_ERR_WORKSPACE);
     EXPECT(nw_bwd_f32(F, F, Y, F, F, F, F, F, F, nullptr, ws, sizeof ws, 4, 4, 4, 3, NW_SCORE_CLIP, nullptr, 0, 0, nullptr),
            NW_ERR_INVALID_ARG);
+    // ... with the supports' bank: all three pieces or none, shared supports and d % 32 == 0 only
+    EXPECT(nw_bwd_bank_f32(F, F, F, F, nullptr, Y, F, F, F, F, F, F, nullptr, ws, sizeof ws, 4, 4, 32, 3, NW_SCORE_EUCLIDEAN,
+                           nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bwd_bank_f32(F, F, nullptr, F, F, Y, F, F, F, F, F, F, nullptr, ws, sizeof ws, 4, 4, 32, 3, NW_SCORE_EUCLIDEAN,
+                           nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bwd_bank_f32(F, F, F, F, F, Y, F, F, F, F, F, F, nullptr, ws, sizeof ws, 4, 4, 48, 3, NW_SCORE_EUCLIDEAN,
+                           nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bwd_bank_f32(F, F, F, F, F, Y, F, F, F, F, F, F, nullptr, ws, sizeof ws, 4, 4, 32, 3, NW_SCORE_EUCLIDEAN,
+                           nullptr, 1, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bwd_uses_split(256, 10000, 512, 200, 0), 1);
+    EXPECT(nw_bwd_uses_split(256, 10000, 512, 200, 1), 0);     // per-query supports
+    EXPECT(nw_bwd_uses_split(256, 10000, 500, 200, 0), 0);     // d % 32 != 0
+    EXPECT(nw_bwd_uses_split(32, 10, 1024, 10, 0), 0);         // a training episode: small
+    EXPECT(nw_bwd_uses_split(256, 60000, 512, 200, 0), 0);     // a row of coefficients does not fit in LDS
+    EXPECT(nw_bwd_uses_split(-1, 10, 32, 10, 0), 0);
     // split rows, norms, influence, top-k, aggregate
     EXPECT(nw_split_rows_f16x2(F, F, F, F, 4, 48, nullptr), NW_ERR_UNSUPPORTED);      // d % 32 != 0
     EXPECT(nw_split_rows_f16x2(F, F, F, F, -1, 32, nullptr), NW_ERR_INVALID_ARG);
