@@ -103,7 +103,6 @@ __device__ __forceinline__ void tile_dots_f16x2(const float* __restrict__ q, con
 #endif
         }
         // split this lane's raw query fragment (k = 8g .. 8g+7 of its row) into fp16 halves, in place
-        // split this lane's raw query fragment (k = 8g .. 8g+7 of its row) into fp16 halves, in place
         auto split_q = [&](Frag& f) {
 #ifdef NW_ABL_NOCVT   // timing ablation only (tools/bench_fused.hip): wrong results
             return;

@@ -90,6 +90,7 @@ int main() {
     EXPECT(nw_bwd_uses_split(256, 10000, 512, 200, 1), 0);     // per-query supports
     EXPECT(nw_bwd_uses_split(256, 10000, 500, 200, 0), 0);     // d % 32 != 0
     EXPECT(nw_bwd_uses_split(32, 10, 1024, 10, 0), 0);         // a training episode: small
+    EXPECT(nw_bwd_uses_split(16, 256, 1024, 10, 0), 1);
     EXPECT(nw_bwd_uses_split(256, 60000, 512, 200, 0), 0);     // a row of coefficients does not fit in LDS
     EXPECT(nw_bwd_uses_split(-1, 10, 32, 10, 0), 0);
     // split rows, norms, influence, top-k, aggregate

@@ -135,9 +135,11 @@ def test_backward_random_shapes(dev, ops, O, i):
 @pytest.mark.parametrize("B,N,d,C", [(64, 1000, 512, 200), (200, 1037, 96, 10), (1000, 150, 64, 5), (37, 4099, 32, 3),
                                        (129, 257, 132, 7)])
 @pytest.mark.parametrize("kind", KINDS)
-def test_backward_matrix_core_path(dev, ops, O, B, N, d, C, kind):
+def test_backward_matrix_core_path(dev, ops, O, monkeypatch, B, N, d, C, kind):
     """Shapes past the B*N*d >= 2^22 threshold: both products of the backward run in nw_bwd_gemm_kernel
-    (ragged M, N and K; K split over workgroups for the tall and the wide case)."""
+    (ragged M, N and K; K split over workgroups for the tall and the wide case).  NW_BWD_SPLIT=0 keeps the shapes
+    with d % 32 == 0 on this fp32 path (by default they take the split-row products, tested below)."""
+    monkeypatch.setenv("NW_BWD_SPLIT", "0")
     g = torch.Generator().manual_seed(B + N)
     q0, s0 = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
     if kind == "dotproduct":
@@ -165,10 +167,10 @@ def test_backward_matrix_core_path(dev, ops, O, B, N, d, C, kind):
 def test_backward_split_fp16_path(dev, ops, O, monkeypatch, B, N, d, C, kind):
     """Both products of the backward on the fp16 matrix cores (bwd_split.hip: split-row operands, transposed LDS reads,
     K split over workgroups for the first product): ragged M, N and K tiles, every kernel type; the same bar as the
-    fp32 matrix-core path.  NW_BWD_SPLIT=1 takes the path wherever the shape allows (d % 32 == 0), the first shape
-    (T) takes it by default."""
-    if (B, N) != (256, 10000):
-        monkeypatch.setenv("NW_BWD_SPLIT", "1")
+    fp32 matrix-core path.  The path is the default from B >= 16, N >= 256, B N d >= 2^22 with d % 32 == 0;
+    NW_BWD_SPLIT=1 takes it wherever the shape allows."""
+    if B < 64:
+        monkeypatch.setenv("NW_BWD_SPLIT", "1")   # (the others take the path by default)
     g = torch.Generator().manual_seed(B + N)
     q0, s0 = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
     if kind == "dotproduct":
