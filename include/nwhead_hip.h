@@ -139,6 +139,18 @@ int nw_merge_finalize_f32(const float *m, const float *den, const float *num, fl
                           int64_t stride_m, int64_t stride_den, int64_t stride_num,
                           const int64_t *class_lo, int64_t C_local, void *stream);
 
+/* Run tables of a RESIDENT bank (labels that do not change between calls).  On large launches the forward walks the
+ * bank in tiles of 128 supports and needs, per tile, the runs of equal consecutive labels; it builds these tables in
+ * its workspace on every call (~5 us + a kernel boundary) unless the caller has built them once:
+ *     tables = malloc(nw_bank_tables_bytes(N));  nw_bank_tables_build(sy, N, C, tables, bytes, stream);
+ *     ... per call:  nw_bank_tables_hint(tables, bytes, sy, N, C);  nw_fwd_f32(...) / nw_fwd_partial_f32(...)
+ * The hint names the tables for the NEXT forward call of the calling thread only (thread-local, dropped when that
+ * call returns, used only if sy / N / C are the ones it is called with); passing tables == NULL drops it. */
+size_t nw_bank_tables_bytes(int64_t N);
+int nw_bank_tables_build(const int64_t *sy, int64_t N, int64_t C, void *tables, size_t tables_bytes, void *stream);
+int nw_bank_tables_hint(const void *tables, size_t tables_bytes, const int64_t *sy, int64_t N, int64_t C);
+
+
 /* ---------------------------------------------------------------------------------------------
  * Backward.  Replaces the autograd graph the reference builds through nwhead/nw.py:276-289 and
  * nwhead/kernel.py:13-44 (loss.backward(), train.py:414), including torch's zero sub-gradient at

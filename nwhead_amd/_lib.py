@@ -32,6 +32,9 @@ SIGNATURES = {
     "nw_fwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
     "nw_fwd_partial_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _p]),
     "nw_merge_finalize_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),
+    "nw_bank_tables_bytes": (_sz, [_i64]),
+    "nw_bank_tables_build": (_int, [_p, _i64, _i64, _p, _sz, _p]),
+    "nw_bank_tables_hint": (_int, [_p, _sz, _p, _i64, _i64]),
     "nw_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int]),
     "nw_bwd_f32": (_int, [_p] * 10 + [_p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
     "nw_bwd_uses_split": (_int, [_i64, _i64, _i64, _i64, _int]),

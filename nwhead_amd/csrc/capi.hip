@@ -72,11 +72,18 @@ extern "C" int nw_row_norm2_f32(const float* x, float* n2, int64_t rows, int64_t
     return nw::launch_rownorm2(x, n2, rows, d, static_cast<hipStream_t>(stream));
 }
 
+namespace {
+struct HintGuard {   // the run-table hint names tables for ONE forward call
+    ~HintGuard() { nw::bank_tables_drop(); }
+};
+}  // namespace
+
 extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
                           const float* s_split, const float* s_scale, float* out, float* scores_out, float* lse_out, float* weights_out, void* workspace,
                           size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C,
                           int kind, const float* logit_scale_dev, int sup_batched,
                           int labels_batched, void* stream) {
+    HintGuard hint_guard;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (bad_kind(kind)) return NW_ERR_UNSUPPORTED;
@@ -126,6 +133,7 @@ extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t*
                                   float* m, float* den, float* num, void* workspace, size_t workspace_bytes,
                                   int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                                   const float* logit_scale_dev, void* stream) {
+    HintGuard hint_guard;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (bad_kind(kind)) return NW_ERR_UNSUPPORTED;
@@ -179,6 +187,7 @@ extern "C" int nw_fwd_influence_f32(const float* q, const float* s, const int64_
                                     float* lse_out, float* infl_out, void* workspace, size_t workspace_bytes,
                                     int64_t B, int64_t N, int64_t d, int64_t C, int kind,
                                     const float* logit_scale_dev, void* stream) {
+    HintGuard hint_guard;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (B == 0) return NW_OK;

@@ -412,6 +412,48 @@ int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_
     return NW_OK;
 }
 
+// A resident bank's run tables, built once (nw_bank_tables_build) instead of once per forward.  They depend on the
+// labels, N, C and the tile height only; the persistent kernel's tile is 128 supports.  The caller names them for ITS
+// NEXT forward call on this thread (nw_bank_tables_hint); the forward takes them if they are the tables of the very
+// label array, N and C it was given, and every forward entry point drops the hint when it returns.
+constexpr int BANK_BS = 128;
+struct BankTablesHint {
+    const char* base = nullptr;
+    size_t bytes = 0;
+    const int64_t* sy = nullptr;
+    int64_t N = 0, C = 0;
+};
+thread_local BankTablesHint tl_hint;
+
+size_t bank_tables_layout(int64_t n_stiles, char* base, FusedWs* ws) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += al256(bytes);
+        return p;
+    };
+    int* nrun = reinterpret_cast<int*>(take((size_t)n_stiles * 4));
+    int* lab = reinterpret_cast<int*>(take((size_t)n_stiles * BANK_BS * 4));
+    int* runid = reinterpret_cast<int*>(take(((size_t)n_stiles * BANK_BS + 64) * 4));
+    int* bnd = reinterpret_cast<int*>(take((size_t)n_stiles * 2 * 4));
+    if (ws) {
+        ws->nrun = nrun;
+        ws->lab = lab;
+        ws->runid = runid;
+        ws->bnd = bnd;
+    }
+    return off;
+}
+
+bool bank_tables_take(const int64_t* sy, int N, int C, int n_stiles, int BS, FusedWs* ws) {
+    const BankTablesHint h = tl_hint;
+    if (!h.base || BS != BANK_BS || h.sy != sy || h.N != N || h.C != C) return false;
+    if (h.bytes < bank_tables_layout(n_stiles, nullptr, nullptr)) return false;
+    bank_tables_layout(n_stiles, const_cast<char*>(h.base), ws);
+    return true;
+}
+void bank_tables_drop() { tl_hint = BankTablesHint(); }
+
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st) {
     // LDS: reduction scratch + per-class tables (count, first / last tile, MENT entries) + res[class][query]
@@ -523,3 +565,33 @@ int launch_fused(const float* q, const float* s, const int64_t* sy, const float*
 }
 
 }  // namespace nw
+
+extern "C" size_t nw_bank_tables_bytes(int64_t N) {
+    if (N <= 0 || N > 0x7fffffffLL) return 0;
+    return nw::bank_tables_layout((N + nw::BANK_BS - 1) / nw::BANK_BS, nullptr, nullptr);
+}
+
+extern "C" int nw_bank_tables_build(const int64_t* sy, int64_t N, int64_t C, void* tables, size_t tables_bytes,
+                                    void* stream) {
+    using namespace nw;
+    if (N < 0 || C < 0 || N > 0x7fffffffLL || C > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    if (N == 0) return NW_OK;
+    if (!sy || !tables || (reinterpret_cast<uintptr_t>(tables) & 15)) return NW_ERR_INVALID_ARG;
+    const int64_t n_stiles = (N + BANK_BS - 1) / BANK_BS;
+    FusedWs ws;
+    if (tables_bytes < bank_tables_layout(n_stiles, static_cast<char*>(tables), &ws)) return NW_ERR_WORKSPACE;
+    return launch_run_tables(ws, sy, (int)N, (int)C, (int)n_stiles, BANK_BS, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int nw_bank_tables_hint(const void* tables, size_t tables_bytes, const int64_t* sy, int64_t N, int64_t C) {
+    nw::bank_tables_drop();
+    if (!tables) return NW_OK;
+    if (!sy || N <= 0 || C < 0 || tables_bytes < nw_bank_tables_bytes(N)) return NW_ERR_INVALID_ARG;
+    nw::tl_hint.base = static_cast<const char*>(tables);
+    nw::tl_hint.bytes = tables_bytes;
+    nw::tl_hint.sy = sy;
+    nw::tl_hint.N = N;
+    nw::tl_hint.C = C;
+    return NW_OK;
+}
+

@@ -21,6 +21,8 @@ struct FusedWs {  // views into the caller's workspace
 };
 size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws);
 int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st);
+bool bank_tables_take(const int64_t* sy, int N, int C, int n_stiles, int BS, FusedWs* ws);   // the caller's cached tables, if named for this call
+void bank_tables_drop();
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st);
 // split form of the query batch in the tail of the forward workspace (fused.hip)
@@ -397,8 +399,10 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
     const bool persistent = s_scale && !scores && RS > 5 && (RS == 8 || env_flag("NW_PERSISTENT_ANY_RS")) &&
                             grid >= 4 * device_cu_count() && d >= 3 * BK && !env_flag("NW_NO_PERSISTENT");
     if (persistent) {  // runs of equal labels per support tile: once per launch (ws.runid / nrun / lab / bnd)
-        const int rc = launch_run_tables(ws, sy, N, C, n_stiles, 16 * RS, st);
-        if (rc != NW_OK) return rc;
+        if (!bank_tables_take(sy, N, C, n_stiles, 16 * RS, &ws)) {
+            const int rc = launch_run_tables(ws, sy, N, C, n_stiles, 16 * RS, st);
+            if (rc != NW_OK) return rc;
+        }
     }
     if (s_scale) {  // split-fp16 operands (the caller has checked d % 32 == 0 and supplied the bank's norms)
         if (!dma || !s_norm2) return NW_ERR_INVALID_ARG;

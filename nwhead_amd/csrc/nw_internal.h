@@ -50,6 +50,7 @@ int launch_bwd_qsplit(const float* q, const float* ascale, const float* qv, floa
                       int64_t Bpad, int64_t d, hipStream_t st);
 
 // fused forward (fused.hip)
+void bank_tables_drop();   // forget the caller's run-table hint (nw_bank_tables_hint): every forward entry point, on return
 int launch_topk(const float* scores, int64_t* idx, float* vals, int64_t B, int64_t N, int64_t k, hipStream_t st);  // topk.hip
 int tile_timer_enable(bool on);
 int tile_timer_read(double* total_us, int64_t* launches);

@@ -183,6 +183,32 @@ class SplitBank:
                                                    N, d, _stream(sc)), "nw_split_rows_f16x2")
         else:
             self.norm2 = row_norm2(sc)
+        self.tables = self._tables_src = None
+        if labels is not None and labels.dim() == 1 and self.split is not None:
+            self.build_tables(self.sorted_labels if self.sorted_labels is not None else labels)
+
+    def build_tables(self, labels):
+        """Run tables of this bank under ``labels`` (nw_bank_tables_build): the forward then skips building them on
+        every large launch.  They are used only for calls that pass this very label tensor, unmodified."""
+        lib = _lib.load()
+        lab = labels.detach()
+        lab64 = lab if (lab.dtype == torch.int64 and lab.is_contiguous()) else lab.to(torch.int64).contiguous()
+        N = self.shape[0]
+        if lab64.dim() != 1 or lab64.numel() != N or N == 0 or not lab64.is_cuda:
+            return
+        nbytes = lib.nw_bank_tables_bytes(N)
+        tables = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=lab64.device)
+        with torch.cuda.device(lab64.device):
+            # C: any bound above the labels gives the same tables (nw_head refuses labels >= n_classes)
+            _lib.check(lib.nw_bank_tables_build(_ptr(lab64), N, 0x7fffffff, _ptr(tables), nbytes, _stream(lab64)),
+                       "nw_bank_tables_build")
+        self.tables, self._tables_src = tables, (labels.data_ptr(), tuple(labels.shape), labels._version)
+
+    def hint_tables(self, lib, sy, syc, n_classes):
+        """Name the cached run tables for the forward call that follows, if ``sy`` is the label tensor they were built
+        from (``syc``: the int64 contiguous form handed to the library)."""
+        if self.tables is not None and (sy.data_ptr(), tuple(sy.shape), sy._version) == self._tables_src:
+            lib.nw_bank_tables_hint(_ptr(self.tables), self.tables.numel(), _ptr(syc), self.shape[0], int(n_classes))
 
     def matches(self, s):
         """True when `s` is the very tensor (storage, shape, no in-place update since) this bank was prepared from."""
@@ -246,6 +272,8 @@ class _NWHeadFn(torch.autograd.Function):
         ws_bytes = _fwd_ws_bytes(lib, B, N, d, n_classes)
         st = _stream(qc)
         ws = _workspace(ws_bytes, dev, st) if ws_bytes else None
+        if cache is not None:
+            cache.hint_tables(lib, sy, syc, n_classes)
         with _OnDevice(dev):
             rc = lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale), _ptr(out),
                                 _ptr(scores), _ptr(lse),
@@ -354,6 +382,7 @@ def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_sca
             raise ValueError("this SplitBank holds a class-sorted copy of its support: pass cache.sorted_rows / "
                              "cache.sorted_labels (or call nw_partials, which does)")
         sn2, ssplit, sscale = cache.norm2, cache.split, cache.scale
+        cache.hint_tables(lib, syc, syc, C)
     with torch.cuda.device(qc.device):
         _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale),
                                           _ptr(m), _ptr(den), _ptr(num),

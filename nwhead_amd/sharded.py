@@ -67,6 +67,8 @@ class ShardedBank:
         # the shard never changes: prepare it once (squared norms + split-fp16 rows, ops.SplitBank)
         self.cache = ops.SplitBank(self.feat) if (partial_fn is None and self.feat.is_cuda) else None
         self.norm2 = self.cache.norm2 if self.cache is not None else None
+        if self.cache is not None and self.cache.split is not None:
+            self.cache.build_tables(self.y_local)   # the labels every call of this shard passes (self.y when there is one rank)
 
     # ---- HIP compute hooks (the product path)
     def _hip_partial(self, packed_row, q):

@@ -181,3 +181,24 @@ def test_custom_kernel_module_runs_through_the_aggregation_kernels(dev):
         for got, want in ((x.grad, x64.grad), (s.grad, s64.grad)):
             scale = max(float(want.abs().max()), 1e-3)
             np.testing.assert_allclose(got.cpu().numpy() / scale, want.numpy() / scale, rtol=1e-4, atol=1e-4)
+
+
+def test_cached_run_tables_give_the_same_output_and_follow_the_labels(dev):
+    """A SplitBank built with labels keeps the bank's run tables (nw_bank_tables_build) and names them for the large
+    launches (persistent kernel); the output equals the one with tables built inside the call, bit for bit; labels
+    modified in place afterwards are no longer the tables' labels: the hint is not given and the result follows them."""
+    from nwhead_amd import ops
+    torch.manual_seed(0)
+    B, N, d, C = 2048, 20000, 128, 50
+    q, s = torch.randn(B, d, device=dev), torch.randn(N, d, device=dev)
+    sy = (torch.arange(N, device=dev) * C // N)
+    plain = ops.SplitBank(s)                      # no labels: tables are built in every call
+    withtab = ops.SplitBank(s, labels=sy)
+    assert withtab.tables is not None
+    a = ops.nw_head(q, s, sy, C, support_cache=plain)
+    b = ops.nw_head(q, s, sy, C, support_cache=withtab)
+    assert torch.equal(a, b)
+    sy[: N // 2] = sy[: N // 2].flip(0)           # in place: another labelling (still valid classes)
+    a2 = ops.nw_head(q, s, sy, C, support_cache=plain)
+    b2 = ops.nw_head(q, s, sy, C, support_cache=withtab)
+    assert torch.equal(a2, b2) and not torch.equal(a, a2)
