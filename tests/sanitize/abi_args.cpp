@@ -23,7 +23,7 @@ int main() {
     std::vector<int64_t> y(64, 0);
     float* F = f.data();
     int64_t* Y = y.data();
-    char ws[256];
+    alignas(16) char ws[256];
     EXPECT(nw_abi_version(), NW_ABI_VERSION);
     EXPECT(std::strcmp(nw_status_string(NW_OK), "ok"), 0);
     EXPECT(nw_status_string(12345) != nullptr, 1);
@@ -93,6 +93,15 @@ int main() {
     EXPECT(nw_bwd_uses_split(16, 256, 1024, 10, 0), 1);
     EXPECT(nw_bwd_uses_split(256, 60000, 512, 200, 0), 0);     // a row of coefficients does not fit in LDS
     EXPECT(nw_bwd_uses_split(-1, 10, 32, 10, 0), 0);
+    // run tables of a resident bank
+    EXPECT(nw_bank_tables_bytes(0), 0);
+    EXPECT(nw_bank_tables_bytes(50000) >= (size_t)2 * 50000 * 4, 1);
+    EXPECT(nw_bank_tables_build(nullptr, 10, 5, ws, sizeof ws, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bank_tables_build(Y, 10, 5, ws, 8, nullptr), NW_ERR_WORKSPACE);
+    EXPECT(nw_bank_tables_build(Y, 0, 5, nullptr, 0, nullptr), NW_OK);
+    EXPECT(nw_bank_tables_hint(ws, 8, Y, 10, 5), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bank_tables_hint(ws, sizeof ws, nullptr, 10, 5), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bank_tables_hint(nullptr, 0, nullptr, 0, 0), NW_OK);
     // split rows, norms, influence, top-k, aggregate
     EXPECT(nw_split_rows_f16x2(F, F, F, F, 4, 48, nullptr), NW_ERR_UNSUPPORTED);      // d % 32 != 0
     EXPECT(nw_split_rows_f16x2(F, F, F, F, -1, 32, nullptr), NW_ERR_INVALID_ARG);
