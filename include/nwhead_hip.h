@@ -276,9 +276,18 @@ int nw_scale_shift_relu_avgpool2_f32(const float *x, const float *scale, const f
  *   w_t       (ceil(cin/8), 9, 8, cout) fp32: the weight re-laid out once at fold time,
  *             w_t[c / 8][3 ky + kx][c % 8][co] = W[co][c][ky][kx], channels past cin ZERO; cout % 32 == 0
  *   bias      optional (cout,); residual optional (n, cout, H, W) with its batch stride; post_relu: max(., 0) */
+size_t nw_conv3x3_workspace_bytes(int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W);
 int nw_conv3x3_f32(const float *x, int64_t x_batch_stride, const float *w_t, const float *bias,
                    const float *residual, int64_t res_batch_stride, int post_relu, float *out,
-                   int64_t out_batch_stride, int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W, void *stream);
+                   int64_t out_batch_stride, void *workspace, size_t workspace_bytes,
+                   int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W, void *stream);
+/* Workgroups nw_conv3x3_f32 launches for a shape (0: unsupported): 32-256 pixels x 32-128 output channels per
+ * workgroup, 32 x 64 tiles with the K range shared by the workgroup's waves when the larger tiles would leave the
+ * chip idle (small planes), their K range split over up to 8 workgroups when there are many input channels (7x7
+ * planes: partial tiles in `workspace`, nw_conv3x3_workspace_bytes, added in order by a second kernel).  The folded
+ * backbones keep MIOpen below 192. */
+int64_t nw_conv3x3_workgroups(int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W);
+
 
 size_t nw_conv1x1_workspace_bytes(int64_t n, int64_t cin, int64_t cout, int64_t hw);
 int nw_conv1x1_f32(const float *x, int64_t x_batch_stride, const float *pre_scale, const float *pre_shift,

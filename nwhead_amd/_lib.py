@@ -46,7 +46,9 @@ SIGNATURES = {
     "nw_topk_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "nw_scale_shift_relu_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "nw_scale_shift_relu_avgpool2_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),
-    "nw_conv3x3_f32": (_int, [_p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "nw_conv3x3_workgroups": (_i64, [_i64, _i64, _i64, _i64, _i64]),
+    "nw_conv3x3_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
+    "nw_conv3x3_f32": (_int, [_p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p, _sz, _i64, _i64, _i64, _i64, _i64, _p]),
     "nw_conv1x1_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "nw_conv1x1_f32": (_int, [_p, _i64, _p, _p, _int, _p, _p, _int, _p, _i64, _p, _sz, _i64, _i64, _i64, _i64, _p]),
     "nw_bn_relu_train_fwd_f32": (_int, [_p] * 10 + [_i64, _i64, _i64, _i64, C.c_float, C.c_float, _int, _p]),

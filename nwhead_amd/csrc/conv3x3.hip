@@ -40,7 +40,7 @@ constexpr int C3K = 8;      // input channels per stage
 constexpr int C3NBUF = 3;
 
 template <int WMW, int WNW, bool VEC>
-struct C3Cfg {
+struct C3Cfg {   // (the K-split form is WMW = WNW = 1: one 32 x 64 tile, the four multiplying waves share its K range)
     static constexpr int TM = 32 * WMW, TN = 64 * WNW;
     static constexpr int A_F = 9 * C3K * TM;                 // floats of weights per stage
     static constexpr int A_DMA = (A_F * 4 + 1023) / 1024;    // 1 KB DMA instructions for them
@@ -49,11 +49,15 @@ struct C3Cfg {
 
 // `lrow`: floats per channel row of the span in LDS (a whole number of DMA instructions + 32), `nb`: DMA instructions
 // per channel row.  LDS coordinate of pixel p = (y, x): L(p) = y pitch + x; the span starts at L(p0) - pitch - gap.
-template <int WMW, int WNW, bool VEC>
+// KS (small planes: a 32 x 256 tile per image would leave most CUs idle): the workgroup computes ONE 32 x 64 tile, its
+// four multiplying waves take the 18 (tap, channel group) pairs of a stage in turn and their partial tiles are added
+// through LDS after the loop (fixed order: deterministic).
+template <int WMW, int WNW, bool VEC, bool KS = false>
 __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     const float* __restrict__ x, int64_t x_bs, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ res, int64_t res_bs, int post_relu, float* __restrict__ out, int64_t out_bs,
-    int n_img, int cin, int cout, int H, int W, int tiles_per_img, int lrow, int nb) {
+    float* __restrict__ part, int n_img, int cin, int cout, int H, int W, int tiles_per_img, int lrow, int nb,
+    int st_chunk) {
     using Cfg = C3Cfg<WMW, WNW, VEC>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, A_F = Cfg::A_F, A_DMA = Cfg::A_DMA, A_PER = Cfg::A_PER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,8 +69,11 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     const int img = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - img * tiles_per_img) * TN;
     const int m0 = blockIdx.y * TM;
     const int HW = H * W;
-    const int wm = 32 * (wave / WNW), wn = 64 * (wave % WNW);
-    const int nst = (cin + C3K - 1) / C3K;
+    const int wm = KS ? 0 : 32 * (wave / WNW), wn = KS ? 0 : 64 * (wave % WNW);
+    // K may be split over blockIdx.z (KS form only: small planes with many input channels): this workgroup's stages
+    const int nst_all = (cin + C3K - 1) / C3K;
+    const int s_lo = KS ? blockIdx.z * st_chunk : 0;
+    const int nst = KS ? min(nst_all - s_lo, st_chunk) : nst_all;
     const float* ximg = x + (int64_t)img * x_bs;
 
     // ---- DMA plans.  Weights: the stage's 9*8 rows of TM floats; when cout == TM they are one contiguous block,
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     }
     auto issue = [&](int s) {
         float* st = ring + (unsigned)(s % C3NBUF) * stage_f;
-        const int64_t koff = (int64_t)s * 9 * C3K * cout * 4;    // bytes: the stage's first weight row
+        const int64_t koff = (int64_t)(s_lo + s) * 9 * C3K * cout * 4;    // bytes: the stage's first weight row
 #pragma unroll
         for (int u = 0; u < A_PER; ++u)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[u] + koff),
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int cl = 2 * wave + cc;           // channel row of the stage
-            const int ci = min(s * C3K + cl, cin - 1);   // rows past cin meet zero weights: any finite data will do
+            const int ci = min((s_lo + s) * C3K + cl, cin - 1);   // rows past cin meet zero weights: any finite data will do
             const float* plane = ximg + (int64_t)ci * HW;
             float* drow = st + A_F + cl * lrow + 16 * (cl & 1);
 #pragma unroll
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
             wait_all_but(s + 2 < nst ? per : 0);        // stage s + 1 has landed (this wave's share)
             __builtin_amdgcn_s_barrier();
         }
+        if (KS) __builtin_amdgcn_s_barrier();           // (the consumers' reduction barrier)
         return;
     }
     __builtin_amdgcn_s_barrier();                   // stage 0 has landed
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
             const int toff = (t / 3) * pitch + (t % 3);
 #pragma unroll
             for (int kk = 0; kk < C3K / 4; ++kk) {
+                if (KS && ((2 * t + kk) & 3) != wave) continue;   // this pair belongs to another wave
                 const int cl = 4 * kk + g;
                 const float* brow = Bs + cl * lrow + 16 * (cl & 1) + toff;
                 float bv[4];
@@ -210,21 +219,71 @@ __global__ __launch_bounds__(512, 2) void nw_conv3x3_kernel(
     const float lo = post_relu ? 0.f : -INFINITY;
     float* oimg = out + (int64_t)img * out_bs;
     const float* rimg = res ? res + (int64_t)img * res_bs : nullptr;
+    if (KS) {
+        // the four partial tiles meet in LDS (the ring is free: the loop's last barrier is behind every wave); wave w
+        // then owns N-block e = w: value [e][r][a] of lane l from wave v sits at ((v * 4 + e) * 8 + 2 r + a) * 64 + l
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) ring[((wave * 4 + e) * 8 + 2 * r + a) * 64 + lane] = acc[a][e][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += ring[((w * 4 + wave) * 8 + 2 * r + a) * 64 + lane];
+                acc[a][0][r] = v;
+            }
+    }
+#pragma unroll
+    for (int e0 = 0; e0 < 4; ++e0) {
+        if (KS && e0 > 0) break;
+        const int e = KS ? wave : e0;
         const int p = p0 + wn + 16 * e + i;
         if (p >= HW) continue;
+        if (KS && gridDim.z > 1) {   // raw partial sums [z][img][m][p]; nw_conv3x3_reduce_kernel finishes
+            float* pz = part + (((int64_t)blockIdx.z * n_img + img) * cout) * HW;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) pz[(int64_t)(m0 + 2 * (4 * g + r) + a) * HW + p] = acc[a][0][r];
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int m = m0 + wm + 2 * (4 * g + r) + a;
                 if (m >= cout) continue;
-                float v = acc[a][e][r] + (bias ? bias[m] : 0.f);
+                float v = acc[a][KS ? 0 : e0][r] + (bias ? bias[m] : 0.f);
                 if (rimg) v += rimg[(int64_t)m * HW + p];
                 oimg[(int64_t)m * HW + p] = fmaxf(v, lo);
             }
     }
+}
+
+// out[n, m, p] = post(bias[m] + sum_z part[z][n][m][p] [+ res]), in z order (deterministic)
+__global__ __launch_bounds__(256) void nw_conv3x3_reduce_kernel(const float* __restrict__ part, int nz,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ res, int64_t res_bs,
+                                                                 int post_relu, float* __restrict__ out, int64_t out_bs,
+                                                                 int n_img, int cout, int HW) {
+    const int64_t per_img = (int64_t)cout * HW, total = per_img * n_img;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int img = (int)(idx / per_img);
+    const int64_t rem = idx - (int64_t)img * per_img;
+    const int m = (int)(rem / HW);
+    float v = part[idx];
+    for (int z = 1; z < nz; ++z) v += part[(int64_t)z * total + idx];
+    if (bias) v += bias[m];
+    if (res) v += res[(int64_t)img * res_bs + rem];
+    out[(int64_t)img * out_bs + rem] = post_relu ? fmaxf(v, 0.f) : v;
 }
 
 }  // namespace
@@ -240,10 +299,57 @@ static void conv3x3_span(int tn, int W, bool vec, int* lrow, int* nb) {
     *lrow = *nb * per + 32;                                    // + the 16-float stagger of odd rows
 }
 
+// Tile form for a shape.  32 x 256 for narrow outputs on big planes, 64 x 128 otherwise, 128 x 64 for small planes; when
+// that leaves fewer than three quarters of the CUs with a workgroup: 32 x 64 tiles whose K range is shared by the
+// workgroup's four multiplying waves (ks), and if even those are too few and there are enough input channels, the K
+// range is also split over `zs` workgroups whose partial tiles a second kernel adds in order.
+struct Conv3x3Plan {
+    int wmw, wnw, zs, st_chunk;
+    bool ks;
+    int64_t workgroups;
+};
+static Conv3x3Plan conv3x3_plan(int64_t n, int64_t cin, int64_t cout, int64_t HW) {
+    Conv3x3Plan p;
+    if (cout % 128 == 0 && HW <= 64) { p.wmw = 4; p.wnw = 1; }
+    else if (cout % 64 == 0) { p.wmw = 2; p.wnw = 2; }
+    else { p.wmw = 1; p.wnw = 4; }
+    p.zs = 1;
+    const int64_t nst = (cin + nw::C3K - 1) / nw::C3K;
+    p.st_chunk = (int)nst;
+    p.workgroups = ((HW + 64 * p.wnw - 1) / (64 * p.wnw)) * n * (cout / (32 * p.wmw));
+    p.ks = p.workgroups < 192;
+    if (p.ks) {
+        p.wmw = p.wnw = 1;
+        p.workgroups = ((HW + 63) / 64) * n * (cout / 32);
+        if (p.workgroups < 192 && nst >= 8) {
+            int64_t zs = (255 + p.workgroups) / p.workgroups;      // towards one workgroup per CU
+            if (zs > 8) zs = 8;
+            if (zs > nst / 4) zs = nst / 4;                         // at least four stages each
+            const int64_t chunk = (nst + zs - 1) / zs;
+            p.st_chunk = (int)chunk;
+            p.zs = (int)((nst + chunk - 1) / chunk);
+            p.workgroups *= p.zs;
+        }
+    }
+    return p;
+}
+
+extern "C" size_t nw_conv3x3_workspace_bytes(int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W) {
+    if (n <= 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0 || cout % 32 != 0) return 0;
+    const Conv3x3Plan p = conv3x3_plan(n, cin, cout, H * W);
+    return p.zs > 1 ? (size_t)p.zs * n * cout * H * W * sizeof(float) : 0;
+}
+
+// workgroups nw_conv3x3_f32 launches for this shape (callers keep MIOpen for shapes that leave the chip idle)
+extern "C" int64_t nw_conv3x3_workgroups(int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W) {
+    if (n <= 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0 || cout % 32 != 0) return 0;
+    return conv3x3_plan(n, cin, cout, H * W).workgroups;
+}
+
 extern "C" int nw_conv3x3_f32(const float* x, int64_t x_batch_stride, const float* w_t, const float* bias,
                               const float* residual, int64_t res_batch_stride, int post_relu, float* out,
-                              int64_t out_batch_stride, int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W,
-                              void* stream) {
+                              int64_t out_batch_stride, void* workspace, size_t workspace_bytes, int64_t n, int64_t cin,
+                              int64_t cout, int64_t H, int64_t W, void* stream) {
     using namespace nw;
     if (n < 0 || cin < 0 || cout < 0 || H < 0 || W < 0) return NW_ERR_INVALID_ARG;
     if (n == 0 || cout == 0 || H == 0 || W == 0) return NW_OK;
@@ -255,30 +361,37 @@ extern "C" int nw_conv3x3_f32(const float* x, int64_t x_batch_stride, const floa
         return NW_ERR_INVALID_ARG;
     if (HW < 4) return NW_ERR_UNSUPPORTED;
     const bool vec = W % 4 == 0 && x_batch_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    // tile shape: 32 x 256 for narrow outputs on big planes, 64 x 128 otherwise, 128 x 64 for small planes
-    int wmw, wnw;
-    if (cout % 128 == 0 && HW <= 64) { wmw = 4; wnw = 1; }
-    else if (cout % 64 == 0) { wmw = 2; wnw = 2; }
-    else { wmw = 1; wnw = 4; }
-    const int tm = 32 * wmw, tn = 64 * wnw;
+    const Conv3x3Plan pl = conv3x3_plan(n, cin, cout, HW);
+    if (pl.zs > 1 && (!workspace || workspace_bytes < nw_conv3x3_workspace_bytes(n, cin, cout, H, W) ||
+                      (reinterpret_cast<uintptr_t>(workspace) & 15)))
+        return NW_ERR_WORKSPACE;
+    const int tm = 32 * pl.wmw, tn = 64 * pl.wnw;
     const int tiles = (int)((HW + tn - 1) / tn);
     const int64_t gx = (int64_t)tiles * n;
-    if (gx > 0x7fffffffLL || cout / tm > 65535) return NW_ERR_INVALID_ARG;
+    if (gx > 0x7fffffffLL || cout / tm > 65535 || n * cout * HW > 0x7fffffffffLL) return NW_ERR_INVALID_ARG;
     int lrow, nb;
     conv3x3_span(tn, (int)W, vec, &lrow, &nb);
     if (nb > 8) return NW_ERR_UNSUPPORTED;                       // very wide images: not a backbone shape
-    const size_t lds = (size_t)C3NBUF * (9 * C3K * tm + C3K * lrow) * sizeof(float);
+    size_t lds = (size_t)C3NBUF * (9 * C3K * tm + C3K * lrow) * sizeof(float);
+    if (pl.ks && lds < 32 * 1024) lds = 32 * 1024;               // the reduction of the four partial tiles
     if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)gx, (unsigned)(cout / tm));
-#define NW_C3(MW_, NW_, V_)                                                                                              \
-    hipLaunchKernelGGL((nw_conv3x3_kernel<MW_, NW_, V_>), grid, dim3(512), lds, st, x, x_batch_stride, w_t, bias, residual, \
-                       res_batch_stride, post_relu, out, out_batch_stride, (int)n, (int)cin, (int)cout, (int)H, (int)W, tiles, \
-                       lrow, nb)
-    if (wmw == 1) { if (vec) NW_C3(1, 4, true); else NW_C3(1, 4, false); }
-    else if (wmw == 2) { if (vec) NW_C3(2, 2, true); else NW_C3(2, 2, false); }
-    else { if (vec) NW_C3(4, 1, true); else NW_C3(4, 1, false); }
+    const dim3 grid((unsigned)gx, (unsigned)(cout / tm), (unsigned)pl.zs);
+    float* part = static_cast<float*>(workspace);
+#define NW_C3(MW_, NW_, V_, KS_)                                                                                         \
+    hipLaunchKernelGGL((nw_conv3x3_kernel<MW_, NW_, V_, KS_>), grid, dim3(512), lds, st, x, x_batch_stride, w_t, bias, residual, \
+                       res_batch_stride, post_relu, out, out_batch_stride, part, (int)n, (int)cin, (int)cout, (int)H, (int)W, \
+                       tiles, lrow, nb, pl.st_chunk)
+    if (pl.ks) { if (vec) NW_C3(1, 1, true, true); else NW_C3(1, 1, false, true); }
+    else if (pl.wmw == 1) { if (vec) NW_C3(1, 4, true, false); else NW_C3(1, 4, false, false); }
+    else if (pl.wmw == 2) { if (vec) NW_C3(2, 2, true, false); else NW_C3(2, 2, false, false); }
+    else { if (vec) NW_C3(4, 1, true, false); else NW_C3(4, 1, false, false); }
 #undef NW_C3
+    if (pl.zs > 1) {
+        const int64_t total = n * cout * HW;
+        hipLaunchKernelGGL(nw_conv3x3_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, pl.zs, bias,
+                           residual, res_batch_stride, post_relu, out, out_batch_stride, (int)n, (int)cout, (int)HW);
+    }
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

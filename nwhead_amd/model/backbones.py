@@ -113,12 +113,10 @@ class ResNet(nn.Module):
 DENSE_PASSTHROUGH = True        # the running concatenation passes through norm1's autograd node (see _DenseBlock.forward)
 DENSE_INCREMENTAL_CAT = True    # dense blocks extend one running concatenation (see _DenseBlock.forward)
 # Folded inference copies: the dense layers' 3x3 convolutions as the implicit-GEMM kernel (Conv3x3Fused,
-# csrc/conv3x3.hip), which writes straight into the dense-block slab.  A direct convolution on the fp32 matrix cores
-# (80-88 TFLOP/s on the big planes since the loop lost its border masks and its vmcnt(0) stalls; MIOpen's Winograd
-# kernels, 2.25x fewer multiplies, reach 80-93 on NCHW and 90-99 on channels_last tensors): on DenseNet-121's shapes
-# (128 -> 32 channels) it is ahead of MIOpen's NCHW kernels at 56x56 and 28x28 (169 vs 186 us, 53 vs 61) and the
-# small planes stay on MIOpen (Conv3x3Fused._use_kernel: too few workgroups); DenseNet-121 over 64 images 5.63 ms
-# with it, 5.70 without (tools/fold_time.py, same box).  NW_OWN_CONV3X3=0 turns it off.
+# csrc/conv3x3.hip), which writes straight into the dense-block slab.  On DenseNet-121's shape (128 -> 32 channels,
+# batch 64) it draws level with MIOpen's Winograd kernels on the 56x56 and 28x28 planes (165 vs 156 us, 52 vs 51) and
+# is 2-3x ahead on 14x14 and 7x7 (23 vs 47 us, 16 vs 47: 32 x 64 tiles, K range shared inside / split over workgroups);
+# DenseNet-121 over 64 images 5.29 ms with it, 5.72 without (tools/fold_time.py, same box).  NW_OWN_CONV3X3=0: off.
 import os as _os
 FUSED_CONV3X3 = _os.environ.get("NW_OWN_CONV3X3", "1") != "0"
 FUSED_CONV1X1 = True            # folded inference copies: 1x1 convolutions with their BatchNorm / ReLU neighbours as one kernel (Conv1x1Fused)
@@ -387,8 +385,10 @@ class Conv3x3Fused(nn.Module):
         if not x.is_cuda or self.cout % 32 != 0 or x.dtype != torch.float32:
             return False
         n, _, h, w = x.shape
-        tm, tn = (128, 64) if (self.cout % 128 == 0 and h * w <= 64) else ((64, 128) if self.cout % 64 == 0 else (32, 256))
-        return h * w >= 4 and n * ((h * w + tn - 1) // tn) * (self.cout // tm) >= 192
+        from .. import _lib
+        # enough workgroups for the chip (small planes run 32 x 64 tiles with the K range shared inside the workgroup
+        # and, with many input channels, split over workgroups)
+        return h * w >= 4 and _lib.load().nw_conv3x3_workgroups(n, self.cin, self.cout, h, w) >= 192
 
     def forward(self, x, out=None, residual=None):
         if self._use_kernel(x):

@@ -494,9 +494,12 @@ def conv3x3(x, weight_t, cin, bias=None, residual=None, post_relu=False, out=Non
         residual, rbs = _plane_view(residual)
         if residual.shape != (n, cout, h, w):
             raise ValueError("conv3x3: residual must have the output's shape")
+    lib = _lib.load()
+    ws_bytes = lib.nw_conv3x3_workspace_bytes(n, cin, cout, h, w)   # partial tiles when K is split over workgroups (7x7 planes)
+    ws = _workspace(ws_bytes, x.device) if ws_bytes else None
     with _OnDevice(x.device):
-        _lib.check(_lib.load().nw_conv3x3_f32(_ptr(x), bstride, _ptr(weight_t), _ptr(bias), _ptr(residual), rbs, int(bool(post_relu)),
-                                              _ptr(out), obs, n, cin, cout, h, w, _stream(x)), "nw_conv3x3_f32")
+        _lib.check(lib.nw_conv3x3_f32(_ptr(x), bstride, _ptr(weight_t), _ptr(bias), _ptr(residual), rbs, int(bool(post_relu)),
+                                      _ptr(out), obs, _ptr(ws), ws_bytes, n, cin, cout, h, w, _stream(x)), "nw_conv3x3_f32")
     return out
 
 

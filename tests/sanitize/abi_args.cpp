@@ -140,12 +140,17 @@ int main() {
     EXPECT(nw_conv1x1_f32(F, 992 * 196, nullptr, nullptr, 0, F, nullptr, 0, F, 128 * 196, nullptr, 0, 2, 992, 128, 196, nullptr),
            NW_ERR_WORKSPACE);
     // 3x3 convolution
-    EXPECT(nw_conv3x3_f32(F, 64, F, nullptr, nullptr, 0, 0, F, 64, 1, 4, 32, -1, 4, nullptr), NW_ERR_INVALID_ARG);
-    EXPECT(nw_conv3x3_f32(nullptr, 64, F, nullptr, nullptr, 0, 0, F, 512, 1, 4, 32, 4, 4, nullptr), NW_ERR_INVALID_ARG);
-    EXPECT(nw_conv3x3_f32(F, 64, F, nullptr, nullptr, 0, 0, F, 512, 1, 4, 24, 4, 4, nullptr), NW_ERR_UNSUPPORTED);   // cout % 32
-    EXPECT(nw_conv3x3_f32(F, 8, F, nullptr, nullptr, 0, 0, F, 512, 1, 4, 32, 4, 4, nullptr), NW_ERR_INVALID_ARG);     // batch stride < cin*H*W
-    EXPECT(nw_conv3x3_f32(F, 64, F, nullptr, F, 8, 0, F, 512, 1, 4, 32, 4, 4, nullptr), NW_ERR_INVALID_ARG);         // residual stride
-    EXPECT(nw_conv3x3_f32(F, 64, F, nullptr, nullptr, 0, 0, F, 512, 0, 4, 32, 4, 4, nullptr), NW_OK);
+    EXPECT(nw_conv3x3_f32(F, 64, F, nullptr, nullptr, 0, 0, F, 64, nullptr, 0, 1, 4, 32, -1, 4, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_conv3x3_f32(nullptr, 64, F, nullptr, nullptr, 0, 0, F, 512, nullptr, 0, 1, 4, 32, 4, 4, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_conv3x3_f32(F, 64, F, nullptr, nullptr, 0, 0, F, 512, nullptr, 0, 1, 4, 24, 4, 4, nullptr), NW_ERR_UNSUPPORTED);   // cout % 32
+    EXPECT(nw_conv3x3_f32(F, 8, F, nullptr, nullptr, 0, 0, F, 512, nullptr, 0, 1, 4, 32, 4, 4, nullptr), NW_ERR_INVALID_ARG);     // batch stride < cin*H*W
+    EXPECT(nw_conv3x3_f32(F, 64, F, nullptr, F, 8, 0, F, 512, nullptr, 0, 1, 4, 32, 4, 4, nullptr), NW_ERR_INVALID_ARG);         // residual stride
+    EXPECT(nw_conv3x3_f32(F, 64, F, nullptr, nullptr, 0, 0, F, 512, nullptr, 0, 0, 4, 32, 4, 4, nullptr), NW_OK);
+    EXPECT(nw_conv3x3_workspace_bytes(64, 512, 32, 7, 7) > 0, 1);                 // K split over workgroups
+    EXPECT(nw_conv3x3_workspace_bytes(64, 128, 32, 56, 56), 0);
+    EXPECT(nw_conv3x3_f32(F, 25088, F, nullptr, nullptr, 0, 0, F, 1568, nullptr, 0, 64, 512, 32, 7, 7, nullptr), NW_ERR_WORKSPACE);
+    EXPECT(nw_conv3x3_workgroups(64, 512, 32, 7, 7) >= 192, 1);
+    EXPECT(nw_conv3x3_workgroups(1, 8, 32, 7, 7), 1);
     std::printf(failures ? "abi_args: %d FAILED\n" : "abi_args: all argument checks refused as documented\n", failures);
     return failures ? 1 : 0;
 }

@@ -16,6 +16,16 @@ pytestmark = pytest.mark.gpu
     (2, 40, 128, 12, 12, 0, True, False, True, False),       # two M tiles of 64, one full + one ragged N tile
     (5, 24, 256, 7, 7, 0, True, True, True, False),          # 7x7 planes, 128 x 64 tiles, W % 4 != 0
     (1, 3, 32, 5, 9, 0, False, False, False, False),         # tiny: every column on a border somewhere
+    # (few images: the cases above run 32 x 64 tiles with the K range shared by the workgroup's waves, like the small
+    #  planes of a real batch; the ones below have enough tiles for the large-tile forms)
+    (16, 16, 32, 56, 56, 8, False, False, False, True),      # 32 x 256 tiles (208 workgroups), into a slab
+    (28, 16, 64, 28, 28, 0, True, True, True, False),        # 64 x 128 tiles (196 workgroups), ragged last tile
+    (96, 8, 256, 7, 7, 0, True, False, True, False),         # 128 x 64 tiles (192 workgroups), 4-byte DMAs
+    (64, 128, 32, 14, 14, 32, False, False, False, True),    # DenseNet block 3 at batch 64: K-split tiles, W % 4 != 0, slab
+    (20, 72, 32, 16, 16, 0, True, False, True, False),       # K-split tiles with 16-byte DMAs, nine stages
+    (64, 520, 32, 7, 7, 24, False, False, False, True),      # DenseNet block 4 at batch 64: K also split over 4 workgroups, slab
+    (8, 250, 32, 7, 7, 0, True, True, True, False),          # ... ragged last K chunk, bias + residual + ReLU in the reduce kernel
+    (64, 128, 32, 7, 7, 0, False, False, False, True),       # DenseNet's own 7x7 shape: four chunks of four stages
 ])
 def test_conv3x3_against_torch_fp64(n, cin, cout, h, w, slab_in, bias, res, relu, into_slab):
     from nwhead_amd import ops

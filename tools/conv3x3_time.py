@@ -6,7 +6,7 @@ import bench
 from nwhead_amd import ops
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-shapes = [(64, 128, 32, 56), (64, 128, 32, 28), (64, 128, 32, 14), (64, 64, 64, 56), (64, 128, 128, 28), (64, 256, 256, 14), (64, 512, 512, 7)]
+shapes = [(64, 128, 32, 56), (64, 128, 32, 28), (64, 128, 32, 14), (64, 128, 32, 7), (64, 512, 32, 7), (64, 64, 64, 56), (64, 128, 128, 28), (64, 256, 256, 14), (64, 512, 512, 7)]
 for n, cin, cout, side in shapes:
     x = torch.randn(n, cin, side, side, generator=g).to(dev)
     w = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dev)
