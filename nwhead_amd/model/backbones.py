@@ -45,6 +45,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if isinstance(self.conv2, Conv3x3Fused):     # folded inference copy with FUSED_RESNET_CONV3X3: bias, identity and
+            y = self.conv1(x) if isinstance(self.conv1, Conv3x3Fused) else F.relu(self.conv1(x))   # ReLU in the kernels
+            return self.conv2(y, residual=x if self.downsample is None else self.downsample(x))
         y = self.conv2(_bn_relu(self.bn1, self.conv1(x)))
         return _bn_relu(self.bn2, y, x if self.downsample is None else self.downsample(x))
 
@@ -119,6 +122,10 @@ DENSE_INCREMENTAL_CAT = True    # dense blocks extend one running concatenation 
 # DenseNet-121 over 64 images 5.29 ms with it, 5.72 without (tools/fold_time.py, same box).  NW_OWN_CONV3X3=0: off.
 import os as _os
 FUSED_CONV3X3 = _os.environ.get("NW_OWN_CONV3X3", "1") != "0"
+# ResNet's BasicBlocks in the folded copies: stride-1 3x3 convolutions through the same kernel with the folded BatchNorm
+# bias, the identity and the ReLU in its store (NCHW; the stem, the strided convolutions and the 1x1 projections stay on
+# MIOpen).  Measured against the channels_last MIOpen path (tools/fold_time.py): see DESIGN.md 4.7e; NW_RESNET_OWN_CONV3X3.
+FUSED_RESNET_CONV3X3 = _os.environ.get("NW_RESNET_OWN_CONV3X3", "0") == "1"
 FUSED_CONV1X1 = True            # folded inference copies: 1x1 convolutions with their BatchNorm / ReLU neighbours as one kernel (Conv1x1Fused)
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
 
@@ -592,6 +599,10 @@ def fold_batchnorm(model):
         elif isinstance(mod, (CifarTransition, CIFAR_DenseNet)):
             mod.bn = ScaleShiftReLU(mod.bn)
     for mod in m.modules():
+        if isinstance(mod, BasicBlock) and FUSED_RESNET_CONV3X3 and isinstance(mod.conv2, nn.Conv2d) and mod.conv2.out_channels % 32 == 0:
+            if mod.conv1.stride == (1, 1):
+                mod.conv1, mod.bn1 = Conv3x3Fused(mod.conv1, mod.bn1, post_relu=True), nn.Identity()
+            mod.conv2, mod.bn2 = Conv3x3Fused(mod.conv2, mod.bn2, post_relu=True), nn.Identity()
         if isinstance(mod, (BasicBlock, Bottleneck, ResNet)) or (isinstance(mod, CIFAR_ResNet) and hasattr(mod, "bn1")):
             k = 1
             while hasattr(mod, f"conv{k}") and hasattr(mod, f"bn{k}"):

@@ -67,13 +67,40 @@ def test_folded_densenets_with_fused_3x3():
             net(torch.randn(4, 3, side, side, device=dev))
         net.eval()
         x = torch.randn(batch, 3, side, side, device=dev)
-        bb.FUSED_CONV3X3 = True                      # (off by default: MIOpen's Winograd kernels are faster, backbones.py)
+        was = bb.FUSED_CONV3X3
+        bb.FUSED_CONV3X3 = True                      # (the default; NW_OWN_CONV3X3=0 in the environment turns it off)
         try:
             folded = fold_batchnorm(net)
         finally:
-            bb.FUSED_CONV3X3 = False
+            bb.FUSED_CONV3X3 = was
         assert sum(isinstance(m, bb.Conv3x3Fused) for m in folded.modules()) == 58
         with torch.no_grad():
             want, got = net(x), folded(x)
         scale = float(want.abs().max())
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+
+
+def test_folded_resnet_with_fused_3x3_blocks():
+    """backbones.FUSED_RESNET_CONV3X3 (off by default: MIOpen's channels_last kernels are ahead on these shapes): the
+    stride-1 3x3 convolutions of the BasicBlocks with bias, identity and ReLU in the kernel's store."""
+    import nwhead_amd.model.backbones as bb
+    from nwhead_amd.model import fold_batchnorm, load_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = load_model("resnet18").to(dev)
+    net.train()
+    with torch.no_grad():
+        net(torch.randn(4, 3, 96, 96, device=dev))
+    net.eval()
+    x = torch.randn(16, 3, 96, 96, device=dev)
+    was = bb.FUSED_RESNET_CONV3X3
+    bb.FUSED_RESNET_CONV3X3 = True
+    try:
+        folded = fold_batchnorm(net)
+    finally:
+        bb.FUSED_RESNET_CONV3X3 = was
+    assert sum(isinstance(m, bb.Conv3x3Fused) for m in folded.modules()) == 13     # 16 3x3 convolutions, 3 of them strided
+    with torch.no_grad():
+        want, got = net(x), folded(x)
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)

@@ -10,6 +10,9 @@ arch = sys.argv[2] if len(sys.argv) > 2 else "densenet121"
 net = load_model(arch).to(dev).eval()
 folded = fold_batchnorm(net)
 x = torch.randn(64, 3, 224, 224, device=dev)
+if len(sys.argv) > 3 and sys.argv[3] == "cl":   # what NWNet.enable_bn_folding(channels_last=True) runs for the ResNets
+    folded = folded.to(memory_format=torch.channels_last)
+    x = x.contiguous(memory_format=torch.channels_last)
 with torch.no_grad():
     for _ in range(12):
         folded(x)

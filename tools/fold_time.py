@@ -12,9 +12,12 @@ torch.manual_seed(0)
 m = load_model(arch).to(dev).eval()
 f = fold_batchnorm(m)
 x = torch.randn(n, 3, side, side, device=dev)
+if os.environ.get("CL") == "1":   # the channels_last form NWNet.enable_bn_folding gives the all-MIOpen ResNets
+    f = f.to(memory_format=torch.channels_last)
+    x = x.contiguous(memory_format=torch.channels_last)
 with torch.no_grad():
     ref = m(x); got = f(x)
     err = ((got - ref).abs().max() / ref.abs().max()).item()
     t = bench.time_kernel_events(lambda: f(x), 10, warmup=3, min_warm_ms=50)
-print(f"{arch} n={n} {side}x{side} NW_OWN_CONV3X3={os.environ.get('NW_OWN_CONV3X3', '0')}: folded forward {t * 1e3:.3f} ms, "
+print(f"{arch} n={n} {side}x{side} NW_OWN_CONV3X3={os.environ.get('NW_OWN_CONV3X3', '1')} NW_RESNET_OWN_CONV3X3={os.environ.get('NW_RESNET_OWN_CONV3X3', '0')} CL={os.environ.get('CL', '0')}: folded forward {t * 1e3:.3f} ms, "
       f"max |folded - plain| / max |plain| = {err:.1e}", flush=True)
