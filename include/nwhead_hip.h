@@ -253,6 +253,12 @@ int nw_scale_shift_relu_avgpool2_f32(const float *x, const float *scale, const f
                                      int64_t n, int64_t c, int64_t h, int64_t w, int64_t x_batch_stride,
                                      int relu, void *stream);
 
+/* out[r][c] = act(x[r][c] + bias[c] [+ residual[r][c]]) for a channels-last (NHWC) activation seen as (rows = n h w,
+ * c): the folded BatchNorm bias, the identity of a ResNet block (model/resnet.py:58-66) and the ReLU behind a bias-free
+ * convolution in one pass; c % 4 == 0, 16-byte aligned pointers, in place allowed (out == x). */
+int nw_bias_act_nhwc_f32(const float *x, const float *bias, const float *residual, int relu, float *out,
+                         int64_t rows, int64_t c, void *stream);
+
 /* 1x1 convolution of the folded inference backbones with its neighbours fused in, on the fp32 matrix cores
  * (v_mfma_f32_16x16x4_f32: exact fp32 multiply-adds).  Replaces, in DenseNet's dense layers and transitions
  * (model/densenet.py:33-60 norm1-relu1-conv1-norm2-relu2, :82-91 norm-relu-conv) and CIFAR_DenseNet's

@@ -45,6 +45,7 @@ SIGNATURES = {
     "nw_fwd_influence_f32": (_int, [_p] * 11 + [_sz, _i64, _i64, _i64, _i64, _int, _p, _p]),
     "nw_topk_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "nw_scale_shift_relu_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),
+    "nw_bias_act_nhwc_f32": (_int, [_p, _p, _p, _int, _p, _i64, _i64, _p]),
     "nw_scale_shift_relu_avgpool2_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "nw_conv3x3_workgroups": (_i64, [_i64, _i64, _i64, _i64, _i64]),
     "nw_conv3x3_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),

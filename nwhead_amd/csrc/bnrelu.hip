@@ -239,6 +239,29 @@ __global__ __launch_bounds__(1024) void nw_bn_train_bwd_kernel(
 
 inline unsigned channel_threads(int64_t per_channel) { return per_channel >= 16384 ? 1024u : per_channel >= 2048 ? 512u : 256u; }
 
+// out[r][c] = act(x[r][c] + bias[c] [+ res[r][c]]) for a channels-last activation seen as (rows = n h w, C): what follows
+// a bias-free convolution in the folded channels_last ResNets (bias add, identity add and ReLU in ONE pass instead of
+// three element-wise launches).  float4 along C (C % 4 == 0); in place allowed.
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void nw_bias_act_rows_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                               const float* __restrict__ res, float* __restrict__ out,
+                                                               int64_t total4, int c4) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % c4);
+        float4 v = reinterpret_cast<const float4*>(x)[idx];
+        const float4 b = reinterpret_cast<const float4*>(bias)[c];
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (RES) {
+            const float4 r = reinterpret_cast<const float4*>(res)[idx];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        reinterpret_cast<float4*>(out)[idx] = v;
+    }
+}
+
 }  // namespace
 }  // namespace nw
 
@@ -352,3 +375,28 @@ extern "C" int nw_bn_relu_train_bwd_f32(const float* x, const float* residual, c
     NW_CHECK_LAUNCH();
     return NW_OK;
 }
+
+extern "C" int nw_bias_act_nhwc_f32(const float* x, const float* bias, const float* residual, int relu, float* out,
+                                    int64_t rows, int64_t c, void* stream) {
+    using namespace nw;
+    if (rows < 0 || c < 0) return NW_ERR_INVALID_ARG;
+    if (rows == 0 || c == 0) return NW_OK;
+    if (!x || !bias || !out) return NW_ERR_INVALID_ARG;
+    if (c % 4 != 0 || c / 4 > 0x7fffffffLL) return NW_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) |
+         reinterpret_cast<uintptr_t>(residual)) & 15)
+        return NW_ERR_INVALID_ARG;
+    const int64_t total4 = rows * (c / 4);
+    int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NW_BA(R_, S_)                                                                                                 \
+    hipLaunchKernelGGL((nw_bias_act_rows_kernel<R_, S_>), dim3((unsigned)blocks), dim3(256), 0, st, x, bias, residual, out, \
+                       total4, (int)(c / 4))
+    if (relu) { if (residual) NW_BA(true, true); else NW_BA(true, false); }
+    else { if (residual) NW_BA(false, true); else NW_BA(false, false); }
+#undef NW_BA
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+

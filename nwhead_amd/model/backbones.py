@@ -48,6 +48,8 @@ class BasicBlock(nn.Module):
         if isinstance(self.conv2, Conv3x3Fused):     # folded inference copy with FUSED_RESNET_CONV3X3: bias, identity and
             y = self.conv1(x) if isinstance(self.conv1, Conv3x3Fused) else F.relu(self.conv1(x))   # ReLU in the kernels
             return self.conv2(y, residual=x if self.downsample is None else self.downsample(x))
+        if isinstance(self.conv2, ConvBiasAct):      # folded inference copy: bias, identity and ReLU behind each convolution
+            return self.conv2(self.conv1(x, relu=True), residual=x if self.downsample is None else self.downsample(x), relu=True)
         y = self.conv2(_bn_relu(self.bn1, self.conv1(x)))
         return _bn_relu(self.bn2, y, x if self.downsample is None else self.downsample(x))
 
@@ -66,6 +68,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if isinstance(self.conv3, ConvBiasAct):      # folded inference copy
+            y = self.conv2(self.conv1(x, relu=True), relu=True)
+            return self.conv3(y, residual=x if self.downsample is None else self.downsample(x), relu=True)
         y = _bn_relu(self.bn1, self.conv1(x))
         y = _bn_relu(self.bn2, self.conv2(y))
         return _bn_relu(self.bn3, self.conv3(y), x if self.downsample is None else self.downsample(x))
@@ -107,7 +112,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, x):
-        x = self.maxpool(_bn_relu(self.bn1, self.conv1(x)))
+        if isinstance(self.conv1, ConvBiasAct):      # folded inference copy
+            x = self.maxpool(self.conv1(x, relu=True))
+        else:
+            x = self.maxpool(_bn_relu(self.bn1, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return torch.flatten(self.avgpool(x), 1)
 
@@ -547,10 +555,35 @@ def CIFAR_DenseNet121(pretrained=False, num_classes=10, bias=True, **kw):
 # (norm1 / bn1, the transitions', the last one) become ScaleShiftReLU (one pass instead of torch's batch-norm
 # + relu kernels).
 # ---------------------------------------------------------------------------------------------
+class ConvBiasAct(nn.Conv2d):
+    """A convolution with a folded BatchNorm in it (fold_batchnorm): conv(x) + bias [+ residual] [-> ReLU].  On the
+    MI355X with channels_last fp32 tensors (what NWNet.enable_bn_folding gives the ResNets) the bias, the block's identity
+    and the ReLU are ONE in-place pass behind a bias-free convolution (ops.bias_act_nhwc_) instead of MIOpen's bias kernel
+    + add + relu; everywhere else the torch ops of the reference backbone.  Inference only."""
+
+    def forward(self, x, residual=None, relu=False):
+        c = self.out_channels
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and c % 4 == 0 and self.bias is not None
+                and not torch.is_grad_enabled() and x.is_contiguous(memory_format=torch.channels_last)
+                and not x.is_contiguous()):
+            y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+            if y.is_contiguous(memory_format=torch.channels_last) and (
+                    residual is None or (residual.shape == y.shape and residual.dtype == torch.float32
+                                         and residual.is_contiguous(memory_format=torch.channels_last))):
+                from .. import ops
+                return ops.bias_act_nhwc_(y, self.bias, residual, relu)
+            y = y + self.bias.view(1, -1, 1, 1)
+        else:
+            y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
 def _fold_pair(conv, bn):
     scale = bn.weight.detach() * torch.rsqrt(bn.running_var.detach() + bn.eps)
-    fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
-                      conv.dilation, conv.groups, bias=True).to(conv.weight.device, conv.weight.dtype)
+    fused = ConvBiasAct(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                        conv.dilation, conv.groups, bias=True).to(conv.weight.device, conv.weight.dtype)
     fused.weight.data.copy_(conv.weight.detach() * scale.view(-1, 1, 1, 1))
     bias = conv.bias.detach() if conv.bias is not None else torch.zeros_like(scale)
     fused.bias.data.copy_(bn.bias.detach() + (bias - bn.running_mean.detach()) * scale)

@@ -428,6 +428,21 @@ def scale_shift_relu(x, scale, shift, relu=True):
     return out
 
 
+def bias_act_nhwc_(x, bias, residual=None, relu=True):
+    """IN PLACE x <- act(x + bias[c] (+ residual)) for an (n, c, h, w) fp32 activation in channels_last memory format
+    (c % 4 == 0): the folded BatchNorm bias, a ResNet block's identity and the ReLU behind a bias-free convolution in one
+    pass.  Returns x."""
+    _need_hip(x, bias, residual)
+    n, c, h, w = x.shape
+    ok = lambda t: t.dtype == torch.float32 and t.shape == x.shape and t.is_contiguous(memory_format=torch.channels_last)
+    if not ok(x) or (residual is not None and not ok(residual)) or c % 4:
+        raise ValueError("bias_act_nhwc_: fp32 channels_last (n, c, h, w) tensors with c % 4 == 0")
+    with _OnDevice(x.device):
+        _lib.check(_lib.load().nw_bias_act_nhwc_f32(_ptr(x), _ptr(_f32c(bias)), _ptr(residual), int(bool(relu)), _ptr(x),
+                                                    n * h * w, c, _stream(x)), "nw_bias_act_nhwc_f32")
+    return x
+
+
 def scale_shift_relu_avgpool2(x, scale, shift, relu=True):
     """avg_pool2d(max(x * scale[c] + shift[c], 0), 2) in one pass: (n, c, h, w) -> (n, c, h // 2, w // 2)."""
     _need_hip(x, scale, shift)

@@ -93,6 +93,11 @@ int main() {
     EXPECT(nw_bwd_uses_split(16, 256, 1024, 10, 0), 1);
     EXPECT(nw_bwd_uses_split(256, 60000, 512, 200, 0), 0);     // a row of coefficients does not fit in LDS
     EXPECT(nw_bwd_uses_split(-1, 10, 32, 10, 0), 0);
+    // NHWC bias + residual + ReLU
+    EXPECT(nw_bias_act_nhwc_f32(F, F, nullptr, 1, F, 4, 6, nullptr), NW_ERR_UNSUPPORTED);       // c % 4
+    EXPECT(nw_bias_act_nhwc_f32(nullptr, F, nullptr, 1, F, 4, 8, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bias_act_nhwc_f32(F, F, nullptr, 1, F, -1, 8, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bias_act_nhwc_f32(F, F, nullptr, 1, F, 0, 8, nullptr), NW_OK);
     // run tables of a resident bank
     EXPECT(nw_bank_tables_bytes(0), 0);
     EXPECT(nw_bank_tables_bytes(50000) >= (size_t)2 * 50000 * 4, 1);

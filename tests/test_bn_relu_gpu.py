@@ -162,3 +162,43 @@ def test_bn_relu_passthrough_accumulates_the_other_gradient(shape, extra):
     _, xp = ops.bn_relu_train(xa2, nn.BatchNorm2d(c).cuda().train(), True, None, passthrough=True)
     (xp * w2[:, :c].float().cuda()).sum().backward()
     torch.testing.assert_close(xa2.grad.cpu().double(), w2[:, :c], rtol=1e-6, atol=1e-6)
+
+
+def test_bias_act_nhwc_and_the_folded_channels_last_resnets():
+    """ops.bias_act_nhwc_ (folded BatchNorm bias + a block's identity + ReLU in one in-place pass over a channels_last
+    activation) against torch, and the folded channels_last ResNets that use it (BasicBlock and Bottleneck forms)
+    against the plain eval-mode networks."""
+    from nwhead_amd import ops
+    from nwhead_amd.model import fold_batchnorm, load_model
+    from nwhead_amd.model.backbones import ConvBiasAct
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    for n, c, h, w in ((3, 64, 7, 5), (2, 4, 1, 9), (5, 132, 6, 6)):
+        x = torch.randn(n, c, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        r = torch.randn(n, c, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(c, generator=g).to(dev)
+        for res in (None, r):
+            for relu in (False, True):
+                want = x + b.view(1, -1, 1, 1) + (0 if res is None else res)
+                want = torch.relu(want) if relu else want
+                got = ops.bias_act_nhwc_(x.clone(memory_format=torch.preserve_format), b, res, relu)
+                assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.bias_act_nhwc_(torch.randn(2, 8, 4, 4, device=dev), torch.zeros(8, device=dev))     # NCHW memory
+    for name in ("resnet18", "resnet50"):
+        torch.manual_seed(0)
+        net = load_model(name).to(dev)
+        net.train()
+        with torch.no_grad():
+            net(torch.randn(4, 3, 96, 96, device=dev))
+        net.eval()
+        folded = fold_batchnorm(net).to(memory_format=torch.channels_last)
+        assert sum(isinstance(m, ConvBiasAct) for m in folded.modules()) == (20 if name == "resnet18" else 53)
+        x = torch.randn(8, 3, 96, 96, device=dev)
+        with torch.no_grad():
+            want = net(x)
+            got = folded(x.contiguous(memory_format=torch.channels_last))
+            got_nchw = folded(x)                      # NCHW input: the torch ops
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+        np.testing.assert_allclose(got_nchw.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
