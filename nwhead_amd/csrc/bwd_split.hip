@@ -35,8 +35,8 @@ typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 constexpr int XM = 128, XN = 64, XK = 32;
 constexpr int X_BYTES = XM * 128, Y_BYTES = XK * XN * 4, XST_BYTES = X_BYTES + Y_BYTES;   // 16 KB + 8 KB
 
-// XNBUF = 3: two workgroups per CU (many short K loops, the second product), fragments single-buffered -- the other
-// workgroup's waves cover the LDS latency.  XNBUF = 6: one workgroup per CU (few long K loops, the first product),
+// XNBUF = 3 / 2: two / three workgroups per CU (many short K loops, the second product), fragments single-buffered --
+// the other workgroups' waves cover the LDS latency.  XNBUF = 6: one workgroup per CU (few long K loops, the first product),
 // fragments double-buffered in registers: the reads of stage s+1 are issued under the MFMAs of stage s.
 #ifdef XG_DIAG   // diagnostic build only (tools/bench_xgemm.hip): s_memtime stamps per workgroup
 __device__ unsigned long long nw_diag_x[8 * 4096];
@@ -47,7 +47,7 @@ __device__ unsigned long long nw_diag_x[8 * 4096];
 constexpr int XOUT_LD = 68;   // floats per row of the staged output tile (272 B: the four row groups of a store hit two bank sets)
 
 template <bool X_KM, bool FUSE, int XNBUF>
-__global__ __launch_bounds__(512, XNBUF <= 3 ? 2 : 1) void nw_xgemm_kernel(
+__global__ __launch_bounds__(512, XNBUF == 2 ? 6 : (XNBUF == 3 ? 4 : 1)) void nw_xgemm_kernel(
     const char* __restrict__ X, int64_t x_row_bytes, int x_rows, const char* __restrict__ Y, int64_t y_row_bytes,
     int y_rows, float* __restrict__ out, const float* __restrict__ fac, int fac_inverse,
     const float* __restrict__ gfac, const float* __restrict__ rowscale, const float* __restrict__ Xo, int M, int Nn,
@@ -403,19 +403,21 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
     // ring depth: deep and one workgroup per CU when there are at most ~one workgroup per CU anyway and K is long
     static const int nbuf_env = [] { const char* e = getenv("NW_XGEMM_NBUF"); return e ? atoi(e) : 0; }();
     const bool deep = nbuf_env ? nbuf_env == 6 : (gx * gy * gz <= 320 && p.k_chunk >= 6 * XK);
-    const size_t lds = (size_t)(deep ? 6 : 3) * XST_BYTES;
+    // more than two workgroups per CU's worth of tiles: two stages each, so that three are resident per CU and the whole
+    // grid runs in one round (second product at T, 632 workgroups of 8 stages: 17.7 us against 20.3 with three stages)
+    const bool thin = nbuf_env ? nbuf_env == 2 : (!deep && gx * gy * gz > 512);
+    const size_t lds = (size_t)(deep ? 6 : thin ? 2 : 3) * XST_BYTES;
     const char* Xc = reinterpret_cast<const char*>(X);
     const char* Yc = reinterpret_cast<const char*>(Y);
+#define NW_XG1(KM, FUSE, NB, OUT)                                                                                         \
+    hipLaunchKernelGGL((nw_xgemm_kernel<KM, FUSE, NB>), grid, dim3(512), lds, st, Xc, ldx * 4, (int)x_rows, Yc, ldy * 4,   \
+                       (int)y_rows, OUT, fac, fac_inverse, gfac, rowscale, Xo, (int)M, (int)Nn, (int)K, p.k_chunk,       \
+                       (int)gx, (int)gy, (int)gz, (int)rpg)
 #define NW_XG(KM, FUSE, OUT)                                                                                              \
     do {                                                                                                                  \
-        if (deep)                                                                                                         \
-            hipLaunchKernelGGL((nw_xgemm_kernel<KM, FUSE, 6>), grid, dim3(512), lds, st, Xc, ldx * 4, (int)x_rows, Yc, ldy * 4, \
-                               (int)y_rows, OUT, fac, fac_inverse, gfac, rowscale, Xo, (int)M, (int)Nn, (int)K, p.k_chunk, \
-                               (int)gx, (int)gy, (int)gz, (int)rpg);                                                      \
-        else                                                                                                              \
-            hipLaunchKernelGGL((nw_xgemm_kernel<KM, FUSE, 3>), grid, dim3(512), lds, st, Xc, ldx * 4, (int)x_rows, Yc, ldy * 4, \
-                               (int)y_rows, OUT, fac, fac_inverse, gfac, rowscale, Xo, (int)M, (int)Nn, (int)K, p.k_chunk, \
-                               (int)gx, (int)gy, (int)gz, (int)rpg);                                                      \
+        if (deep) NW_XG1(KM, FUSE, 6, OUT);                                                                               \
+        else if (thin) NW_XG1(KM, FUSE, 2, OUT);                                                                          \
+        else NW_XG1(KM, FUSE, 3, OUT);                                                                                    \
     } while (0)
     if (p.nchunks == 1) {
         if (x_km) NW_XG(true, true, out); else NW_XG(false, true, out);
@@ -426,6 +428,7 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
                            p.nchunks, fac, fac_inverse, gfac, rowscale, Xo, out, M, Nn);
     }
 #undef NW_XG
+#undef NW_XG1
     NW_CHECK_LAUNCH();
     return NW_OK;
 }
