@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void nw_sum_kernel(const float* __restrict__ x
 }
 
 struct BwdWs {
-    float *A, *Rs, *rq, *gls, *qn2, *sn2, *rs, *part;
+    float *A, *Rs, *rq, *gls, *qn2, *sn2, *rs, *part, *part2;   // part2: the second product's partial tiles (split path)
     float *s_split, *s_scale, *q_split, *ascale, *qv, *gfac;   // split path (bwd_split.hip)
     int64_t ld;    // row stride of A and Rs: N, N rounded up to 4 floats (fp32 matrix cores) or to 32 (split path)
     int64_t Bpad;  // rows of q_split: B rounded up to 32, the rest zero
@@ -528,7 +528,7 @@ size_t bwd_layout(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched, c
     w.gls = take((size_t)B);
     w.qn2 = take((size_t)B);
     w.sn2 = take(sup_batched ? (size_t)B * N : (size_t)N);
-    w.rs = w.part = nullptr;
+    w.rs = w.part = w.part2 = nullptr;
     w.s_split = w.s_scale = w.q_split = w.ascale = w.qv = w.gfac = nullptr;
     if (w.mfma) {
         w.rs = take((size_t)N);
@@ -545,7 +545,12 @@ size_t bwd_layout(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched, c
             cq = gemm_plan(B, d, N).nchunks, cs = gemm_plan(N, d, B).nchunks;
         }
         const size_t nq = cq > 1 ? (size_t)cq * B * d : 0, ns = cs > 1 ? (size_t)cs * N * d : 0;
-        w.part = take(nq > ns ? nq : ns);
+        if (w.split) {   // the first product's partial tiles are still pending while the second product runs
+            w.part = take(nq);
+            w.part2 = take(ns);
+        } else {
+            w.part = w.part2 = take(nq > ns ? nq : ns);
+        }
     }
     if (ws) *ws = w;
     return off;
@@ -658,12 +663,13 @@ extern "C" int nw_bwd_bank_f32(const float* q, const float* s, const float* s_no
             rc = launch_bwd_qsplit(q, ws.ascale, ws.qv, ws.q_split, ws.gfac, B, ws.Bpad, d, st);
             if (rc != NW_OK) return rc;
             // gq = 2^-E_b (A' s') + 2 rq q: K = N runs along the rows of A' (zero past N), the rows of s' are clamped
+            XgemmReduce gq_reduce;   // the first product's K-split reduction rides along with the second product's launch
             rc = launch_xgemm(false, ws.A, ws.ld, B, ws.s_split, d, N, ws.part, ws.ascale, 0, nullptr, ws.rq, q, gq, B, d,
-                              N, st);
+                              N, st, &gq_reduce);
             if (rc != NW_OK) return rc;
             // gs = 2^(e_j - G) (A'^T q'') + 2 rs s: K = B runs across the rows of A' (clamped), q'' is zero past B
-            rc = launch_xgemm(true, ws.A, ws.ld, B, ws.q_split, d, ws.Bpad, ws.part, ws.s_scale, 1, ws.gfac, ws.rs, s, gs,
-                              N, d, B, st);
+            rc = launch_xgemm(true, ws.A, ws.ld, B, ws.q_split, d, ws.Bpad, ws.part2, ws.s_scale, 1, ws.gfac, ws.rs, s, gs,
+                              N, d, B, st, nullptr, &gq_reduce);
             if (rc != NW_OK) return rc;
         } else {
             rc = launch_bwd_gemm<true>(ws.A, ws.ld, s, ws.part, ws.rq, q, gq, B, d, N, st);   // gq = A s + 2 rq q

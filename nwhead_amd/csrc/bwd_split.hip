@@ -51,16 +51,39 @@ __global__ __launch_bounds__(512, XNBUF == 2 ? 6 : (XNBUF == 3 ? 4 : 1)) void nw
     const char* __restrict__ X, int64_t x_row_bytes, int x_rows, const char* __restrict__ Y, int64_t y_row_bytes,
     int y_rows, float* __restrict__ out, const float* __restrict__ fac, int fac_inverse,
     const float* __restrict__ gfac, const float* __restrict__ rowscale, const float* __restrict__ Xo, int M, int Nn,
-    int K, int k_chunk, int gx, int gy, int gz, int rows_per_group) {
+    int K, int k_chunk, int gx, int gy, int gz, int rows_per_group, XgemmReduce pend) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool PIPE = XNBUF >= 6;
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The first pend.blocks workgroups finish an EARLIER product of the stream (its K-split partial tiles, summed in
+    // chunk order): the reduction rides along instead of being a launch of its own behind this one.
+    if ((int)blockIdx.x < pend.blocks) {
+        const int64_t total4 = pend.M * pend.Nn / 4;
+        const int64_t idx = (int64_t)blockIdx.x * 512 + tid;
+        if (idx < total4) {
+            const int64_t m = (idx * 4) / pend.Nn;
+            float4 a = *reinterpret_cast<const float4*>(pend.part + idx * 4);
+            for (int c = 1; c < pend.nchunks; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(pend.part + ((int64_t)c * pend.M * pend.Nn) + idx * 4);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            float f = pend.fac[m];
+            f = (pend.fac_inverse ? 1.f / f : f) * (pend.gfac ? *pend.gfac : 1.f);
+            const float rsc = 2.f * pend.rowscale[m];
+            const float4 x = *reinterpret_cast<const float4*>(pend.Xo + idx * 4);
+            a.x = __builtin_fmaf(rsc, x.x, a.x * f); a.y = __builtin_fmaf(rsc, x.y, a.y * f);
+            a.z = __builtin_fmaf(rsc, x.z, a.z * f); a.w = __builtin_fmaf(rsc, x.w, a.w * f);
+            *reinterpret_cast<float4*>(pend.out + idx * 4) = a;
+        }
+        return;
+    }
+    const int bid = blockIdx.x - pend.blocks;   // (pend.blocks % 8 == 0: the XCD of a tile does not move)
     // Workgroup -> tile, XCD-aware: consecutive workgroup ids go round the 8 XCDs (each with its own L2), so the
     // tiles that share an operand are given ids 8 apart.  A "row" r = z gy + m is one X tile (all gx n-tiles read
     // it); rows_per_group rows (all m-tiles of one K chunk when K is split: they share the Y tiles) form a group,
     // and group number 8 t + x runs on XCD x.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     const int per_group = gx * rows_per_group;
     const int gi = (slot / per_group) * 8 + xcd, t_in = slot % per_group;
     const int r = gi * rows_per_group + t_in / gx;
@@ -393,13 +416,17 @@ XgemmPlan xgemm_plan(int64_t M, int64_t Nn, int64_t K) {
 // XGEMM_TAIL_BYTES) and only feed outputs that are never stored.
 int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const float* Y, int64_t ldy, int64_t y_rows,
                  float* part, const float* fac, int fac_inverse, const float* gfac, const float* rowscale,
-                 const float* Xo, float* out, int64_t M, int64_t Nn, int64_t K, hipStream_t st) {
+                 const float* Xo, float* out, int64_t M, int64_t Nn, int64_t K, hipStream_t st, XgemmReduce* defer,
+                 const XgemmReduce* pending) {
     const XgemmPlan p = xgemm_plan(M, Nn, K);
+    XgemmReduce pend = {};
+    if (pending && pending->blocks > 0) pend = *pending;
+    if (defer) *defer = XgemmReduce{};
     const int64_t gx = (Nn + XN - 1) / XN, gy = (M + XM - 1) / XM, gz = p.nchunks;
     const int64_t rpg = gz >= 8 ? gy : 1, groups = (gy * gz + rpg - 1) / rpg;
     const int64_t nwg = (groups + 7) / 8 * 8 * gx * rpg;
-    if (nwg > 0x7fffffffLL || gy * gz > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
-    const dim3 grid((unsigned)nwg);
+    if (nwg + pend.blocks > 0x7fffffffLL || gy * gz > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    const dim3 grid((unsigned)(nwg + pend.blocks));
     // ring depth: deep and one workgroup per CU when there are at most ~one workgroup per CU anyway and K is long
     static const int nbuf_env = [] { const char* e = getenv("NW_XGEMM_NBUF"); return e ? atoi(e) : 0; }();
     const bool deep = nbuf_env ? nbuf_env == 6 : (gx * gy * gz <= 320 && p.k_chunk >= 6 * XK);
@@ -412,7 +439,7 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
 #define NW_XG1(KM, FUSE, NB, OUT)                                                                                         \
     hipLaunchKernelGGL((nw_xgemm_kernel<KM, FUSE, NB>), grid, dim3(512), lds, st, Xc, ldx * 4, (int)x_rows, Yc, ldy * 4,   \
                        (int)y_rows, OUT, fac, fac_inverse, gfac, rowscale, Xo, (int)M, (int)Nn, (int)K, p.k_chunk,       \
-                       (int)gx, (int)gy, (int)gz, (int)rpg)
+                       (int)gx, (int)gy, (int)gz, (int)rpg, pend)
 #define NW_XG(KM, FUSE, OUT)                                                                                              \
     do {                                                                                                                  \
         if (deep) NW_XG1(KM, FUSE, 6, OUT);                                                                               \
@@ -424,8 +451,15 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
     } else {
         if (x_km) NW_XG(true, false, part); else NW_XG(false, false, part);
         const int64_t total4 = M * Nn / 4;
-        hipLaunchKernelGGL(nw_xgemm_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, part,
-                           p.nchunks, fac, fac_inverse, gfac, rowscale, Xo, out, M, Nn);
+        const int64_t rblocks = ((total4 + 511) / 512 + 7) / 8 * 8;
+        if (defer && rblocks <= 4096) {   // a later launch on this stream finishes this product
+            defer->part = part; defer->fac = fac; defer->gfac = gfac; defer->rowscale = rowscale; defer->Xo = Xo;
+            defer->out = out; defer->M = M; defer->Nn = Nn; defer->nchunks = p.nchunks; defer->fac_inverse = fac_inverse;
+            defer->blocks = (int)rblocks;
+        } else {
+            hipLaunchKernelGGL(nw_xgemm_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, part,
+                               p.nchunks, fac, fac_inverse, gfac, rowscale, Xo, out, M, Nn);
+        }
     }
 #undef NW_XG
 #undef NW_XG1

@@ -43,9 +43,22 @@ struct XgemmPlan {
 };
 constexpr size_t XGEMM_TAIL_BYTES = 512;   // readable bytes every operand buffer needs past its last row
 XgemmPlan xgemm_plan(int64_t M, int64_t Nn, int64_t K);
+// A K-split product's reduction (out = f(m) sum_chunks part + 2 rowscale Xo), to be run by extra workgroups of a LATER
+// launch_xgemm on the same stream instead of a kernel of its own (blocks == 0: nothing pending).
+struct XgemmReduce {
+    const float* part;
+    const float* fac;
+    const float* gfac;
+    const float* rowscale;
+    const float* Xo;
+    float* out;
+    int64_t M, Nn;
+    int nchunks, fac_inverse, blocks;
+};
 int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const float* Y, int64_t ldy, int64_t y_rows,
                  float* part, const float* fac, int fac_inverse, const float* gfac, const float* rowscale,
-                 const float* Xo, float* out, int64_t M, int64_t Nn, int64_t K, hipStream_t st);
+                 const float* Xo, float* out, int64_t M, int64_t Nn, int64_t K, hipStream_t st,
+                 XgemmReduce* defer = nullptr, const XgemmReduce* pending = nullptr);
 int launch_bwd_qsplit(const float* q, const float* ascale, const float* qv, float* out, float* gfac, int64_t B,
                       int64_t Bpad, int64_t d, hipStream_t st);
 
