@@ -403,11 +403,10 @@ __global__ __launch_bounds__(256) void nw_bwd_reduce_kernel(const float* __restr
 
 // rs[j] = sum_b Rs[b*ld + j], deterministic: a workgroup owns 64 columns (16 float4 lanes: 256 contiguous bytes per
 // row), its 16 row groups interleave the rows and are added in order through LDS.
-__global__ __launch_bounds__(256) void nw_colsum_kernel(const float* __restrict__ Rs, int64_t ld, float* __restrict__ rs,
-                                                         int64_t B, int64_t N) {
-    __shared__ float4 red[16][16];
+__device__ __forceinline__ void colsum_block(int blk, float4 (*red)[16], const float* __restrict__ Rs, int64_t ld,
+                                             float* __restrict__ rs, int64_t B, int64_t N) {
     const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int64_t j = ((int64_t)blockIdx.x * 16 + c) * 4;   // ld % 4 == 0: whole float4s, pad columns included
+    const int64_t j = ((int64_t)blk * 16 + c) * 4;   // ld % 4 == 0: whole float4s, pad columns included
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a;
     if (j < ld) {
         int64_t b = rg;
@@ -434,6 +433,63 @@ __global__ __launch_bounds__(256) void nw_colsum_kernel(const float* __restrict_
         for (int e = 0; e < 4; ++e)
             if (j + e < N) rs[j + e] = o[e];
     }
+}
+
+// q'' = q 2^(G - E_b) as split rows, rows B .. Bpad-1 zero.  qv[b] = max_k |q[b,k]| 2^-E_b (coefficient kernel);
+// every workgroup takes the maximum of qv for G (B floats from L2), workgroup 0 publishes 2^-G.
+__device__ __forceinline__ void bwd_qsplit_block(int blk, float* red, const float* __restrict__ q,
+                                                 const float* __restrict__ ascale, const float* __restrict__ qv,
+                                                 float* __restrict__ out, float* __restrict__ gfac, int64_t B, int64_t Bpad,
+                                                 int64_t d) {
+    float vm = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 256) vm = fmaxf(vm, qv[b]);
+    vm = block_max(vm, red);
+    const int G = split_exponent(vm);
+    if (blk == 0 && threadIdx.x == 0) *gfac = __builtin_ldexpf(1.f, -G);
+    const int64_t r = (int64_t)blk * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= Bpad) return;
+    _Float16* dst = reinterpret_cast<_Float16*>(out + r * d);
+    const int64_t n4 = d / 4;
+    float up = 0.f;
+    if (r < B) {
+        // 2^(G - E_b): both factors are powers of two; the product may leave the normal range only for rows whose
+        // coefficients are 2^-100 of the batch's largest -- they contribute nothing either way
+        up = ascale[r] * __builtin_ldexpf(1.f, G);
+    }
+    const float4* src = reinterpret_cast<const float4*>(q + (r < B ? r : 0) * d);
+    for (int64_t c = lane; c < n4; c += 64) {
+        const float4 v = src[c];
+        const float sv[4] = {v.x * up, v.y * up, v.z * up, v.w * up};
+        typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+        halfx4 h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (_Float16)sv[k];
+            l[k] = (_Float16)(sv[k] - (float)h[k]);
+        }
+        const int64_t chunk = c >> 3, within = (c & 7) * 4;
+        *reinterpret_cast<halfx4*>(dst + chunk * 64 + within) = h;
+        *reinterpret_cast<halfx4*>(dst + chunk * 64 + 32 + within) = l;
+    }
+}
+
+
+// q'' and rs in ONE launch (split path): both only need the coefficient kernel's outputs, neither is long enough to be
+// worth a launch of its own.  Workgroups [0, nq): q''; the rest: column sums.
+__global__ __launch_bounds__(256) void nw_bwd_prep_kernel(int nq, const float* __restrict__ q, const float* __restrict__ ascale,
+                                                           const float* __restrict__ qv, float* __restrict__ q_split,
+                                                           float* __restrict__ gfac, int64_t B, int64_t Bpad, int64_t d,
+                                                           const float* __restrict__ Rs, int64_t ld, float* __restrict__ rs,
+                                                           int64_t N) {
+    __shared__ float4 red[16][16];
+    if ((int)blockIdx.x < nq) bwd_qsplit_block(blockIdx.x, reinterpret_cast<float*>(red), q, ascale, qv, q_split, gfac, B, Bpad, d);
+    else colsum_block(blockIdx.x - nq, red, Rs, ld, rs, B, N);
+}
+__global__ __launch_bounds__(256) void nw_colsum_kernel(const float* __restrict__ Rs, int64_t ld, float* __restrict__ rs,
+                                                         int64_t B, int64_t N) {
+    __shared__ float4 red[16][16];
+    colsum_block(blockIdx.x, red, Rs, ld, rs, B, N);
 }
 
 struct GemmPlan {
@@ -657,11 +713,16 @@ extern "C" int nw_bwd_bank_f32(const float* q, const float* s, const float* s_no
     }
 #undef NW_COEFF
     if (ws.mfma) {
-        hipLaunchKernelGGL(nw_colsum_kernel, dim3((unsigned)((ws.ld / 4 + 15) / 16)), dim3(256), 0, st, ws.Rs, ws.ld, ws.rs, B, N);
+        const unsigned ncs = (unsigned)((ws.ld / 4 + 15) / 16);
+        if (ws.split) {
+            const unsigned nq = (unsigned)((ws.Bpad + 3) / 4);
+            hipLaunchKernelGGL(nw_bwd_prep_kernel, dim3(nq + ncs), dim3(256), 0, st, (int)nq, q, ws.ascale, ws.qv, ws.q_split,
+                               ws.gfac, B, ws.Bpad, d, ws.Rs, ws.ld, ws.rs, N);
+        } else {
+            hipLaunchKernelGGL(nw_colsum_kernel, dim3(ncs), dim3(256), 0, st, ws.Rs, ws.ld, ws.rs, B, N);
+        }
         int rc;
         if (ws.split) {
-            rc = launch_bwd_qsplit(q, ws.ascale, ws.qv, ws.q_split, ws.gfac, B, ws.Bpad, d, st);
-            if (rc != NW_OK) return rc;
             // gq = 2^-E_b (A' s') + 2 rq q: K = N runs along the rows of A' (zero past N), the rows of s' are clamped
             XgemmReduce gq_reduce;   // the first product's K-split reduction rides along with the second product's launch
             rc = launch_xgemm(false, ws.A, ws.ld, B, ws.s_split, d, N, ws.part, ws.ascale, 0, nullptr, ws.rq, q, gq, B, d,

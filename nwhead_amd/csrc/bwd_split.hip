@@ -351,44 +351,6 @@ __global__ __launch_bounds__(256) void nw_xgemm_reduce_kernel(const float* __res
     *reinterpret_cast<float4*>(out + idx * 4) = a;
 }
 
-// q'' = q 2^(G - E_b) as split rows, rows B .. Bpad-1 zero.  qv[b] = max_k |q[b,k]| 2^-E_b (coefficient kernel);
-// every workgroup takes the maximum of qv for G (B floats from L2), workgroup 0 publishes 2^-G.
-__global__ __launch_bounds__(256) void nw_bwd_qsplit_kernel(const float* __restrict__ q, const float* __restrict__ ascale,
-                                                             const float* __restrict__ qv, float* __restrict__ out,
-                                                             float* __restrict__ gfac, int64_t B, int64_t Bpad, int64_t d) {
-    __shared__ float red[8];
-    float vm = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 256) vm = fmaxf(vm, qv[b]);
-    vm = block_max(vm, red);
-    const int G = split_exponent(vm);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *gfac = __builtin_ldexpf(1.f, -G);
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= Bpad) return;
-    _Float16* dst = reinterpret_cast<_Float16*>(out + r * d);
-    const int64_t n4 = d / 4;
-    float up = 0.f;
-    if (r < B) {
-        // 2^(G - E_b): both factors are powers of two; the product may leave the normal range only for rows whose
-        // coefficients are 2^-100 of the batch's largest -- they contribute nothing either way
-        up = ascale[r] * __builtin_ldexpf(1.f, G);
-    }
-    const float4* src = reinterpret_cast<const float4*>(q + (r < B ? r : 0) * d);
-    for (int64_t c = lane; c < n4; c += 64) {
-        const float4 v = src[c];
-        const float sv[4] = {v.x * up, v.y * up, v.z * up, v.w * up};
-        halfx4 h, l;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            h[k] = (_Float16)sv[k];
-            l[k] = (_Float16)(sv[k] - (float)h[k]);
-        }
-        const int64_t chunk = c >> 3, within = (c & 7) * 4;
-        *reinterpret_cast<halfx4*>(dst + chunk * 64 + within) = h;
-        *reinterpret_cast<halfx4*>(dst + chunk * 64 + 32 + within) = l;
-    }
-}
-
 int xgemm_target_wgs() {
     static const int v = [] { const char* e = getenv("NW_XGEMM_WGS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
     return v;
@@ -463,14 +425,6 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
     }
 #undef NW_XG
 #undef NW_XG1
-    NW_CHECK_LAUNCH();
-    return NW_OK;
-}
-
-int launch_bwd_qsplit(const float* q, const float* ascale, const float* qv, float* out, float* gfac, int64_t B,
-                      int64_t Bpad, int64_t d, hipStream_t st) {
-    hipLaunchKernelGGL(nw_bwd_qsplit_kernel, dim3((unsigned)((Bpad + 3) / 4)), dim3(256), 0, st, q, ascale, qv, out, gfac,
-                       B, Bpad, d);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

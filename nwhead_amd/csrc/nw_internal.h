@@ -59,8 +59,6 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
                  float* part, const float* fac, int fac_inverse, const float* gfac, const float* rowscale,
                  const float* Xo, float* out, int64_t M, int64_t Nn, int64_t K, hipStream_t st,
                  XgemmReduce* defer = nullptr, const XgemmReduce* pending = nullptr);
-int launch_bwd_qsplit(const float* q, const float* ascale, const float* qv, float* out, float* gfac, int64_t B,
-                      int64_t Bpad, int64_t d, hipStream_t st);
 
 // fused forward (fused.hip)
 void bank_tables_drop();   // forget the caller's run-table hint (nw_bank_tables_hint): every forward entry point, on return
