@@ -186,7 +186,10 @@ __global__ __launch_bounds__(1024) void nw_bwd_coeff_kernel(
     }
     if (SPLIT) {
         const int E = split_exponent(amax);
-        const float up = __builtin_ldexpf(1.f, E), down = __builtin_ldexpf(1.f, -E);
+        // A row of zeros (a query whose target class no support carries, or a saturated softmax: dS == 0 exactly) must not
+        // take part in the choice of G: with E = 0 its max|q| 2^-E would be the batch's largest by thirty binary orders and
+        // every other row of q'' would underflow.  Its scale is 0: q'' row zero, and 0 * (A' s') = 0 in the first product.
+        const float up = __builtin_ldexpf(1.f, E), down = amax > 0.f ? __builtin_ldexpf(1.f, -E) : 0.f;
         if (tid == 0) {
             ascale[b] = down;
             qv[b] = qm * down;
