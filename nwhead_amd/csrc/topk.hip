@@ -14,10 +14,8 @@
 //      threshold T and equal to it, a block scan turns the counts into output slots, so the ties that
 //      make it are the lowest-indexed ones;
 //   3. bitonic sort of the (at most 1024) survivors in LDS by (value desc, index asc).
-// Rows of up to 16384 scores are read from memory ONCE: the first pass keeps each thread's (up to 16) ordered images in
-// registers for the four histogram passes and leaves a copy in LDS for the two compaction passes, whose per-thread
-// ranges are contiguous (29 -> 12 us at N = 10000).  Longer rows are read five times (200 KB at N = 50000:
-// L2-resident after the first).
+// Rows of up to 65536 scores are read from memory ONCE and stay in registers (16 or 64 per thread); longer rows are
+// re-read in every pass (five reads).
 #include "nw_internal.h"
 
 namespace nw {
@@ -33,13 +31,17 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {  // larger float <=>
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-constexpr int TK_REGS = 16;   // CACHED: elements per thread kept in registers (N <= 16 * 1024)
-
-template <bool CACHED>
+constexpr int TK_U = 8;       // independent loads in flight per thread in the histogram passes (long rows: 254 -> ... us at N = 50000 from 4)
+// REGS > 0: the row is read from memory ONCE.  Wave w owns the contiguous segment [w seg, (w + 1) seg) of the row
+// (seg a multiple of 64, 16 seg >= N) and keeps it in registers, element e of lane l = w seg + 64 e + l (coalesced
+// loads); the histogram passes and the ordered compaction (ranks from ballots inside the wave, wave bases from one
+// LDS round) all work from those registers.  REGS = 0 (N > 65536): the row is re-read in every pass.
+template <int REGS>
 __global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __restrict__ scores,
                                                              int64_t* __restrict__ idx_out,
                                                              float* __restrict__ val_out, int N, int k) {
-    extern __shared__ __attribute__((aligned(16))) unsigned rowbuf[];   // CACHED: the row's ordered images
+    constexpr bool CACHED = REGS > 0;
+    constexpr int TK_REGS = CACHED ? REGS : TK_U;
     __shared__ unsigned hist[256];
     __shared__ unsigned sel_prefix, sel_need;  // prefix of the k-th largest so far; how many of its bin are still needed
     __shared__ unsigned scan_gt[TK_THREADS / 64], scan_eq[TK_THREADS / 64];
@@ -53,13 +55,14 @@ __global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __rest
         sel_prefix = 0;
         sel_need = (unsigned)k;
     }
-    unsigned ureg[TK_REGS];   // CACHED: element tid + 1024 e of the row
+    unsigned ureg[TK_REGS];   // CACHED: element wave * seg + 64 e + lane of the row
+    const int wv = tid >> 6;
+    const int seg = ((N + 16 * 64 - 1) / (16 * 64)) * 64;   // elements per wave
     if (CACHED) {
 #pragma unroll
         for (int e = 0; e < TK_REGS; ++e) {   // coalesced, independent loads; the only pass over memory
-            const int i = e * TK_THREADS + tid;
-            ureg[e] = i < N ? ordered_bits(row[i]) : 0u;
-            if (i < N) rowbuf[i] = ureg[e];
+            const int i = wv * seg + 64 * e + lane;
+            ureg[e] = (64 * e < seg && i < N) ? ordered_bits(row[i]) : 0u;
         }
     }
     for (int pass = 0; pass < 4; ++pass) {
@@ -67,36 +70,42 @@ __global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __rest
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const unsigned prefix = sel_prefix;
-#pragma unroll
-        for (int blk = 0; blk < (CACHED ? TK_REGS / 4 : 1); ++blk)
-        for (int i0 = CACHED ? 4 * blk * TK_THREADS : 0; i0 < (CACHED ? min(N, 4 * (blk + 1) * TK_THREADS) : N); i0 += 4 * TK_THREADS) {
-            unsigned u4[4];
-            bool ok[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {  // coalesced, independent: four loads in flight
-                const int i = i0 + e * TK_THREADS + tid;
-                ok[e] = i < N;
-                if (CACHED) u4[e] = ureg[4 * blk + e];
-                else u4[e] = ok[e] ? ordered_bits(row[i]) : 0u;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bool live = ok[e] && ((pass == 0) || ((u4[e] >> (shift + 8)) == (prefix >> (shift + 8))));
-                const unsigned bin = (u4[e] >> shift) & 255u;
-                // merge the lanes that hit the same bin (two rounds take care of a hot bin), then plain atomics; only the
-                // top byte (sign + high exponent bits) is that concentrated -- the lower digits are spread over the bins
-                // and the merge would cost more than the atomics it saves
-                for (int round = 0; round < (pass == 0 ? 2 : 0); ++round) {
-                    const unsigned long long act = __ballot(live);
-                    if (!act) break;
-                    const unsigned b0 = __builtin_amdgcn_readlane(bin, __builtin_ctzll(act));
-                    const unsigned long long same = __ballot(live && bin == b0);
-                    if (live && bin == b0) {
-                        if (lane == __builtin_ctzll(same)) atomicAdd(&hist[b0], (unsigned)__builtin_popcountll(same));
-                        live = false;
-                    }
+        // one element into the histogram: lanes that hit the same bin are merged first (two rounds take care of a hot bin),
+        // then plain atomics; only the top byte (sign + high exponent bits) is that concentrated -- the lower digits are
+        // spread over the bins and the merge would cost more than the atomics it saves
+        auto count = [&](unsigned u, bool ok) {
+            bool live = ok && ((pass == 0) || ((u >> (shift + 8)) == (prefix >> (shift + 8))));
+            const unsigned bin = (u >> shift) & 255u;
+            for (int round = 0; round < (pass == 0 ? 2 : 0); ++round) {
+                const unsigned long long act = __ballot(live);
+                if (!act) break;
+                const unsigned b0 = __builtin_amdgcn_readlane(bin, __builtin_ctzll(act));
+                const unsigned long long same = __ballot(live && bin == b0);
+                if (live && bin == b0) {
+                    if (lane == __builtin_ctzll(same)) atomicAdd(&hist[b0], (unsigned)__builtin_popcountll(same));
+                    live = false;
                 }
-                if (live) atomicAdd(&hist[bin], 1u);
+            }
+            if (live) atomicAdd(&hist[bin], 1u);
+        };
+        if (CACHED) {
+#pragma unroll
+            for (int e = 0; e < TK_REGS; ++e) {
+                count(ureg[e], ureg[e] != 0u);   // 0 is the image of no float (the smallest, -inf, is 0x007fffff): "not an element"
+                __builtin_amdgcn_sched_barrier(0);   // (one element at a time: hoisted ballots spill the scalar file)
+            }
+        } else {
+            for (int i0 = 0; i0 < N; i0 += TK_U * TK_THREADS) {
+                unsigned u4[TK_U];
+                bool ok[TK_U];
+#pragma unroll
+                for (int e = 0; e < TK_U; ++e) {  // coalesced, independent: TK_U loads in flight
+                    const int i = i0 + e * TK_THREADS + tid;
+                    ok[e] = i < N;
+                    u4[e] = ok[e] ? ordered_bits(row[i]) : 0u;
+                }
+#pragma unroll
+                for (int e = 0; e < TK_U; ++e) count(u4[e], ok[e]);
             }
         }
         __syncthreads();
@@ -130,12 +139,56 @@ __global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __rest
     const unsigned n_eq = sel_need;      // how many elements equal to T make it (the lowest-indexed ones)
     const unsigned n_gt = (unsigned)k - n_eq;
 
-    // ---- 2. ordered compaction over contiguous per-thread index ranges
+    // ---- 2. ordered compaction (ties: the lowest indices make it)
+    if (CACHED) {
+        // from the registers: every wave counts its segment, one LDS round gives the waves' bases, then the wave walks
+        // its elements in index order and ranks the survivors of each 64 with ballots
+        unsigned cg = 0, ce = 0;
+#pragma unroll
+        for (int e = 0; e < TK_REGS; ++e) {
+            // (slots past the row hold 0, below every image and so below T: they drop out by themselves)
+            cg += (unsigned)__builtin_popcountll(__ballot(ureg[e] > T));
+            ce += (unsigned)__builtin_popcountll(__ballot(ureg[e] == T));
+            __builtin_amdgcn_sched_barrier(0);   // (one ballot pair at a time: hoisted together they spill the scalar file)
+        }
+        if (lane == 0) {
+            scan_gt[wv] = cg;
+            scan_eq[wv] = ce;
+        }
+        __syncthreads();
+        unsigned og = 0, oe = 0;
+        for (int w = 0; w < wv; ++w) {
+            og += scan_gt[w];
+            oe += scan_eq[w];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int e = 0; e < TK_REGS; ++e) {
+            const int i = wv * seg + 64 * e + lane;
+            const bool isg = ureg[e] > T, ise = ureg[e] == T;
+            const unsigned long long mg = __ballot(isg), me = __ballot(ise);
+            if (isg) {
+                const unsigned slot = og + (unsigned)__builtin_popcountll(mg & below);
+                cand_u[slot] = ureg[e];
+                cand_i[slot] = i;
+            } else if (ise) {
+                const unsigned slot = oe + (unsigned)__builtin_popcountll(me & below);
+                if (slot < n_eq) {
+                    cand_u[n_gt + slot] = ureg[e];
+                    cand_i[n_gt + slot] = i;
+                }
+            }
+            og += (unsigned)__builtin_popcountll(mg);
+            oe += (unsigned)__builtin_popcountll(me);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+    // contiguous per-thread index ranges, the row read twice more
     const int per = (N + TK_THREADS - 1) / TK_THREADS;
     const int lo = min(tid * per, N), hi = min(lo + per, N);
     unsigned cg = 0, ce = 0;
     for (int i = lo; i < hi; ++i) {
-        const unsigned u = CACHED ? rowbuf[i] : ordered_bits(row[i]);
+        const unsigned u = ordered_bits(row[i]);
         cg += u > T;
         ce += u == T;
     }
@@ -150,7 +203,6 @@ __global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __rest
             ie += b;
         }
     }
-    const int wv = tid >> 6;
     if (lane == 63) {
         scan_gt[wv] = ig;
         scan_eq[wv] = ie;
@@ -162,7 +214,7 @@ __global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __rest
         oe += scan_eq[w];
     }
     for (int i = lo; i < hi; ++i) {
-        const unsigned u = CACHED ? rowbuf[i] : ordered_bits(row[i]);
+        const unsigned u = ordered_bits(row[i]);
         if (u > T) {
             cand_u[og] = u;
             cand_i[og] = i;
@@ -174,6 +226,7 @@ __global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __rest
             }
             ++oe;
         }
+    }
     }
     __syncthreads();
 
@@ -238,10 +291,14 @@ __global__ __launch_bounds__(TK_THREADS) void nw_topk_kernel(const float* __rest
 int launch_topk(const float* scores, int64_t* idx, float* vals, int64_t B, int64_t N, int64_t k, hipStream_t st) {
     if (k < 1 || k > N || k > TK_MAXK || N >= (1ll << 31) || B >= (1ll << 31)) return NW_ERR_UNSUPPORTED;
     if (B == 0) return NW_OK;
-    if (N <= TK_REGS * TK_THREADS)
-        hipLaunchKernelGGL(nw_topk_kernel<true>, dim3((unsigned)B), dim3(TK_THREADS), (size_t)N * 4, st, scores, idx, vals, (int)N, (int)k);
+    if (N <= 16 * TK_THREADS)
+        hipLaunchKernelGGL((nw_topk_kernel<16>), dim3((unsigned)B), dim3(TK_THREADS), 0, st, scores, idx, vals, (int)N, (int)k);
+    else if (N <= 32 * TK_THREADS)
+        hipLaunchKernelGGL((nw_topk_kernel<32>), dim3((unsigned)B), dim3(TK_THREADS), 0, st, scores, idx, vals, (int)N, (int)k);
+    else if (N <= 64 * TK_THREADS)
+        hipLaunchKernelGGL((nw_topk_kernel<64>), dim3((unsigned)B), dim3(TK_THREADS), 0, st, scores, idx, vals, (int)N, (int)k);
     else
-        hipLaunchKernelGGL(nw_topk_kernel<false>, dim3((unsigned)B), dim3(TK_THREADS), 0, st, scores, idx, vals, (int)N, (int)k);
+        hipLaunchKernelGGL((nw_topk_kernel<0>), dim3((unsigned)B), dim3(TK_THREADS), 0, st, scores, idx, vals, (int)N, (int)k);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }
