@@ -150,6 +150,7 @@ class NWNet(nn.Module):
         self.full_cache = ops.SplitBank(self.full_feat, labels=self.full_y)   # norms + split-fp16 rows for predict('full')
         self.full_norm2 = self.full_cache.norm2
         self.support_eval.build_infer_iters(*info)
+        self.support_eval.knn.bank = self.support_eval.hnsw.bank = self.full_cache   # neighbour search over the same bank
 
     @torch.no_grad()
     def precompute_sharded(self, group=None, partial_fn=None, merge_fn=None):

@@ -112,8 +112,11 @@ class KNN:
     def __init__(self, data, labels, n_neighbors=20):
         self.data, self.labels, self.n_neighbors = data, labels, n_neighbors
 
+    bank = None   # the data's ops.SplitBank when there is one (NWNet.precompute): scores from the split-fp16 tile kernel
+
     def indices(self, x):
-        scores = ops.nw_scores(x, self.data.to(x.device), "euclidean")
+        data = self.data.to(x.device)
+        scores = ops.nw_scores(x, data, "euclidean", support_cache=self.bank if data.is_cuda else None)
         k = min(self.n_neighbors, scores.shape[1])
         # descending score == ascending distance; ties resolve like a stable argsort would
         if k <= 1024:

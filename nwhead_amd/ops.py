@@ -96,8 +96,10 @@ def _workspace(nbytes, device, stream=None):
     return ws
 
 
-def nw_scores(q, s, kind="euclidean", logit_scale=None):
-    """q:(B,d), s:(N,d)|(B,N,d) -> (B,N) fp32 scores.  Replaces nwhead/kernel.py:13-44."""
+def nw_scores(q, s, kind="euclidean", logit_scale=None, support_cache=None):
+    """q:(B,d), s:(N,d)|(B,N,d) -> (B,N) fp32 scores.  Replaces nwhead/kernel.py:13-44.
+    support_cache: the SplitBank of `s` (a resident bank, e.g. the neighbour search over precompute()'s features): the
+    scores then come from the split-fp16 tile kernel (the forward with its score output; 2-3x the fp32 scores kernel)."""
     _need_hip(q, s, logit_scale)
     lib = _lib.load()
     q, s = _f32c(q), _f32c(s)
@@ -106,6 +108,20 @@ def nw_scores(q, s, kind="euclidean", logit_scale=None):
     N = s.shape[-2]
     out = torch.empty(B, N, dtype=torch.float32, device=q.device)
     ls = None if logit_scale is None else _f32c(logit_scale)
+    if (support_cache is not None and not batched and support_cache.split is not None and support_cache.sorted_rows is None
+            and support_cache.matches(s) and B > 0 and N > 0 and N % 4 == 0):
+        # one class, all labels 0: the aggregation is a formality, the (B, N) score matrix is what is wanted
+        zeros = getattr(support_cache, "_zero_labels", None)
+        if zeros is None or zeros.numel() != N:
+            zeros = support_cache._zero_labels = torch.zeros(N, dtype=torch.int64, device=q.device)
+        out1 = torch.empty(B, 1, dtype=torch.float32, device=q.device)
+        ws_bytes = _fwd_ws_bytes(lib, B, N, d, 1)
+        ws = _workspace(ws_bytes, q.device) if ws_bytes else None
+        with _OnDevice(q.device):
+            _lib.check(lib.nw_fwd_f32(_ptr(q), _ptr(s), _ptr(zeros), _ptr(support_cache.norm2), _ptr(support_cache.split),
+                                      _ptr(support_cache.scale), _ptr(out1), _ptr(out), None, None, _ptr(ws), ws_bytes,
+                                      B, N, d, 1, _kind_id(kind), _ptr(ls), 0, 0, _stream(q)), "nw_fwd_f32")
+        return out
     with torch.cuda.device(q.device):
         _lib.check(lib.nw_scores_f32(_ptr(q), _ptr(s), _ptr(out), B, N, d, _kind_id(kind), _ptr(ls),
                                      int(batched), _stream(q)), "nw_scores_f32")

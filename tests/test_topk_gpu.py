@@ -79,3 +79,25 @@ def test_knn_support_uses_topk(dev, ops):
     assert torch.equal(idx.cpu(), _ref(scores, 20))
     sx, sy = knn(q)
     assert sx.shape == (6 * 20, 64) and torch.equal(sy.cpu(), labels.cpu()[idx.cpu().reshape(-1)])
+
+
+def test_scores_through_the_bank_and_few_class_merge():
+    """ops.nw_scores(..., support_cache=bank): the neighbour search's (B, N) score matrix from the split-fp16 tile kernel
+    (the forward with its score output and one class) against the fp32 scores kernel and fp64; the merge behind it sums
+    ONE class over every tile (the lanes of a group share the tiles), so C = 1 and C = 2 outputs are checked too."""
+    from nwhead_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    for B, N, d in ((256, 10000, 512), (37, 4100, 96)):
+        q, s = torch.randn(B, d, generator=g).to(dev), torch.randn(N, d, generator=g).to(dev)
+        bank = ops.SplitBank(s)
+        a = ops.nw_scores(q, s)
+        b = ops.nw_scores(q, s, support_cache=bank)
+        ref = -torch.cdist(q.double(), s.double())
+        assert (a.double() - ref).abs().max().item() < 3e-5 and (b.double() - ref).abs().max().item() < 3e-5
+        for C in (1, 2):
+            sy = (torch.arange(N, device=dev) * C // N)
+            out = ops.nw_head(q, s, sy, C, support_cache=bank)
+            w = torch.softmax(ref, -1)
+            want = torch.log(torch.stack([w[:, sy == c].sum(1) for c in range(C)], 1) + 1e-12)
+            assert (out.double() - want).abs().max().item() < 3e-5
