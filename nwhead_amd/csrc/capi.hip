@@ -58,7 +58,7 @@ extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_
     (void)d; (void)C;
     if (B <= 0 || N <= 0) return 0;
     const size_t plain = align256((size_t)B * (size_t)N * sizeof(float));
-    const size_t fused = align256(nw::fused_workspace_bytes(B, N, d));
+    const size_t fused = align256(nw::fused_workspace_bytes(B, N, d, C));
     // + room for the split-fp16 form of the queries (rows, scales, norms) behind the fused area
     const size_t qsplit = align256((size_t)B * (size_t)d * sizeof(float)) + 2 * align256((size_t)B * sizeof(float));
     // + B floats for the log-sum-exp when weights / influences are derived from the fused kernel's scores

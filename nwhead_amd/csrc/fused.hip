@@ -116,7 +116,7 @@ bool env_flag(const char* name) {
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws) {
+size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws, int64_t C) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char* p = base ? base + off : nullptr;
@@ -131,6 +131,7 @@ size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws
     w.num = reinterpret_cast<float*>(take((size_t)n_stiles * BS * B * 4));
     w.runid = reinterpret_cast<int*>(take(((size_t)n_stiles * BS + 64) * 4));
     w.bnd = reinterpret_cast<int*>(take((size_t)n_stiles * 2 * 4));
+    w.ctab = reinterpret_cast<int*>(take((size_t)C * (3 + 4) * 4));   // class tables of the run merge when they do not fit in LDS
     if (ws) *ws = w;
     return off;
 }
@@ -154,12 +155,18 @@ namespace {
 //  dependent-latency loads take 25 us, and agent-scope release/acquire fences cost ~40 us per launch on
 //  the 8-XCD part.  A query-blocked workspace with packed run rows was measured too: no change.)
 constexpr int MTHREADS = 512, MENT = 4, MTPT = 16;
-template <bool PARTIAL, int MQ, bool TABLES>
+// TMODE: where the per-class tables (count, first / last tile, up to MENT entries) live: 1 = LDS, built by every
+// workgroup (they fit up to a few thousand classes); 2 = global memory, built once per launch by
+// nw_class_tables_kernel (more classes than LDS holds: MQ = 1, results written directly); 0 = none (every class scans
+// every tile: only when there is no workspace for mode 2).
+template <bool PARTIAL, int MQ, int TMODE>
 __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
     const float* __restrict__ ws_m, const float* __restrict__ ws_den, const int* __restrict__ ws_nrun,
     const int* __restrict__ ws_lab, const float* __restrict__ ws_num, float* __restrict__ out,
     float* __restrict__ lse, float* __restrict__ m_out, float* __restrict__ den_out,
-    float* __restrict__ num_out, int B, int C, int n_stiles, int BS) {
+    float* __restrict__ num_out, int B, int C, int n_stiles, int BS, const int* __restrict__ ctab) {
+    constexpr bool TABLES = TMODE != 0;
+    constexpr bool LTAB = TMODE == 1;   // tables built here, in LDS
     constexpr int ML = MTHREADS / MQ;  // tile lanes per query
     constexpr int MNS = MQ + 1;        // row stride of res[class][query] in LDS: odd, the output phase reads columns
     constexpr int NW = MTHREADS / 64;  // waves
@@ -169,11 +176,12 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
     float* red = reinterpret_cast<float*>(smem);  // [NW][MQ] x 2
     float* Ms = red + 2 * NW * MQ;                // [MQ]
     float* inv_s = Ms + MQ;                       // [MQ]
-    int* cnt = reinterpret_cast<int*>(inv_s + MQ);  // [C]   entries of class c        (TABLES only, like the next four)
+    int* lds_tab = reinterpret_cast<int*>(inv_s + MQ);
+    int* cnt = TMODE == 2 ? const_cast<int*>(ctab) : lds_tab;  // [C]   entries of class c   (TABLES only, like the next four)
     int* tlo = cnt + C;                             // [C]   first tile carrying c
     int* thi = tlo + C;                             // [C]   last tile carrying c
     int* ent = thi + C;                             // [C][MENT]  tile * BS + run, ascending
-    float* res = reinterpret_cast<float*>(ent + (size_t)C * MENT);  // [C][MNS]
+    float* res = reinterpret_cast<float*>(lds_tab + (size_t)C * (3 + MENT));  // [C][MNS]   (LDS tables, MQ > 1)
     const int tid = threadIdx.x, bq = tid & (MQ - 1), sl = tid / MQ, wave = tid >> 6;
     const int b0 = blockIdx.x * MQ;
     const int b = min(b0 + bq, B - 1);  // rows past the batch repeat the last query and are never written
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
         }
     }
     int tnr = 0, tl3[3] = {-1, -1, -1};
-    const bool one_pass_tables = TABLES && n_stiles <= MTHREADS;
+    const bool one_pass_tables = LTAB && n_stiles <= MTHREADS;
     if (one_pass_tables && tid < n_stiles) {
         tnr = ws_nrun[tid];
         const int* lt = ws_lab + (size_t)tid * BS;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
         tl3[1] = lt[1];
         tl3[2] = lt[2];
     }
-    if (TABLES) {
+    if (LTAB) {
         for (int c = tid; c < C; c += MTHREADS) {
             cnt[c] = 0;
             tlo[c] = 0x7fffffff;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
     if ((tid & 63) < MQ) red[wave * MQ + bq] = M;
     __syncthreads();  // also publishes the reset tables
     // ---- phase 0: class tables
-    if (TABLES) {
+    if (LTAB) {
         auto add_tile = [&](int t, int nr, const int (&l3)[3]) {
             const int* lt = ws_lab + (size_t)t * BS;
             for (int r = 0; r < nr; ++r) {
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
     if ((tid & 63) < MQ) red[NW * MQ + wave * MQ + bq] = den;
     if (sl == 0) Ms[bq] = M;
     __syncthreads();  // partial dens and the class tables are complete
-    if (TABLES) {  // slots were handed out in arrival order: put each class's entries in bank order
+    if (LTAB) {  // slots were handed out in arrival order: put each class's entries in bank order
         for (int c = tid; c < C; c += MTHREADS) {
             const int n = cnt[c];
             if (n > 1 && n <= MENT) {
@@ -334,19 +342,69 @@ __global__ __launch_bounds__(MTHREADS) void nw_merge_runs_kernel(
             for (int o = P >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
             if (sub != 0) continue;
         }
-        if (TABLES && MQ > 1) {
+        if (LTAB && MQ > 1) {
             res[c * MNS + q] = acc;
         } else if (q < nq) {  // one query per workgroup (consecutive classes: coalesced), or no room for the staging table
             if (PARTIAL) num_out[(size_t)bb * C + c] = acc;
             else out[(size_t)bb * C + c] = logf(acc * inv_s[q] + NW_LOG_EPS);
         }
     }
-    if (!TABLES || MQ == 1) return;
+    if (!LTAB || MQ == 1) return;
     __syncthreads();
     for (int x = tid; x < nq * C; x += MTHREADS) {
         const int qq = x / C, c = x - qq * C;
         if (PARTIAL) num_out[(size_t)(b0 + qq) * C + c] = res[c * MNS + qq];
         else out[(size_t)(b0 + qq) * C + c] = logf(res[c * MNS + qq] * inv_s[qq] + NW_LOG_EPS);
+    }
+}
+
+// The run merge's per-class tables in GLOBAL memory (ctab = cnt[C] | tlo[C] | thi[C] | ent[C][MENT]), for class counts
+// whose tables do not fit in LDS: built once per launch by ONE workgroup (the tables depend on the labels and the
+// tiling only, not on the queries), integer atomics hand out the slots, then every class's entries are put in bank
+// order -- the same construction nw_merge_runs_kernel does per workgroup in LDS.
+__global__ __launch_bounds__(1024) void nw_class_tables_kernel(const int* __restrict__ ws_nrun, const int* __restrict__ ws_lab,
+                                                                int n_stiles, int BS, int C, int* __restrict__ ctab) {
+    int* cnt = ctab;
+    int* tlo = cnt + C;
+    int* thi = tlo + C;
+    int* ent = thi + C;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < C; c += 1024) {
+        cnt[c] = 0;
+        tlo[c] = 0x7fffffff;
+        thi[c] = -1;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int t = tid; t < n_stiles; t += 1024) {
+        const int nr = ws_nrun[t];
+        const int* lt = ws_lab + (size_t)t * BS;
+        for (int r = 0; r < nr; ++r) {
+            const int y = lt[r];
+            if (y < 0) continue;
+            atomicMin(&tlo[y], t);
+            atomicMax(&thi[y], t);
+            const int slot = atomicAdd(&cnt[y], 1);
+            if (slot < MENT) ent[y * MENT + slot] = t * BS + r;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int c = tid; c < C; c += 1024) {
+        const int n = cnt[c];
+        if (n > 1 && n <= MENT) {
+            int e[MENT];
+#pragma unroll
+            for (int k = 0; k < MENT; ++k) e[k] = k < n ? ent[c * MENT + k] : 0x7fffffff;
+#pragma unroll
+            for (int i = 1; i < MENT; ++i)
+#pragma unroll
+                for (int j = MENT - 1; j >= i; --j)
+                    if (e[j] < e[j - 1]) { const int x = e[j]; e[j] = e[j - 1]; e[j - 1] = x; }
+#pragma unroll
+            for (int k = 0; k < MENT; ++k)
+                if (k < n) ent[c * MENT + k] = e[k];
+        }
     }
 }
 
@@ -488,15 +546,22 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
     const int grid = (B + mq - 1) / mq;
 #define NW_MERGE(P_, Q_, T_)                                                                                       \
     hipLaunchKernelGGL((nw_merge_runs_kernel<P_, Q_, T_>), dim3(grid), dim3(MTHREADS), lds, st, ws.m, ws.den, ws.nrun, \
-                       ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS)
+                       ws.lab, ws.num, out, lse, m, den, num, B, C, n_stiles, BS, ws.ctab)
     if (!tables) {
-        if (out) NW_MERGE(false, 1, false); else NW_MERGE(true, 1, false);
+        // more classes than LDS holds tables for (C > ~4200): the tables go to the workspace, built once per launch
+        // (measured at C = 5000: 4.9 ms per call at T when every class scanned every tile, 35 ms at B = 4096, N = 50000)
+        if (ws.ctab && !env_flag("NW_MERGE_NO_GLOBAL_TABLES")) {
+            hipLaunchKernelGGL(nw_class_tables_kernel, dim3(1), dim3(1024), 0, st, ws.nrun, ws.lab, n_stiles, BS, C, ws.ctab);
+            if (out) NW_MERGE(false, 1, 2); else NW_MERGE(true, 1, 2);
+        } else {
+            if (out) NW_MERGE(false, 1, 0); else NW_MERGE(true, 1, 0);
+        }
     } else if (mq == 1) {
-        if (out) NW_MERGE(false, 1, true); else NW_MERGE(true, 1, true);
+        if (out) NW_MERGE(false, 1, 1); else NW_MERGE(true, 1, 1);
     } else if (mq == 16) {
-        if (out) NW_MERGE(false, 16, true); else NW_MERGE(true, 16, true);
+        if (out) NW_MERGE(false, 16, 1); else NW_MERGE(true, 16, 1);
     } else {
-        if (out) NW_MERGE(false, 32, true); else NW_MERGE(true, 32, true);
+        if (out) NW_MERGE(false, 32, 1); else NW_MERGE(true, 32, 1);
     }
 #undef NW_MERGE
     NW_CHECK_LAUNCH();
@@ -538,12 +603,12 @@ int pick_rs(int64_t B, int64_t N, int64_t d, bool f16) {
     return best_rs;
 }
 
-size_t fused_workspace_bytes(int64_t B, int64_t N, int64_t d) {
+size_t fused_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C) {
     size_t need = 0;
     for (int f16 = 0; f16 < 2; ++f16) {  // either operand form may be chosen at launch
         const int rs = pick_rs(B, N, d, f16 != 0);
         const int64_t n_stiles = (N + 16 * rs - 1) / (16 * rs);
-        const size_t n = fused_layout(B, n_stiles, 16 * rs, nullptr, nullptr);
+        const size_t n = fused_layout(B, n_stiles, 16 * rs, nullptr, nullptr, C);
         need = n > need ? n : need;
     }
     return need;

@@ -18,8 +18,9 @@ struct FusedWs {  // views into the caller's workspace
     float* num;   // [n_stiles][BS][B]   run sums, rows >= nrun[st] never touched
     int* runid;   // [n_stiles][BS] (+64)  run of every support row inside its tile (persistent kernel only)
     int* bnd;     // [n_stiles][2]  first tile rows of runs 1 and 2 (BS when there is no such run)
+    int* ctab;    // [C][3 + MENT]  the run merge's class tables when they do not fit in LDS (nw_class_tables_kernel)
 };
-size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws);
+size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws, int64_t C = 0);
 int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st);
 bool bank_tables_take(const int64_t* sy, int N, int C, int n_stiles, int BS, FusedWs* ws);   // the caller's cached tables, if named for this call
 void bank_tables_drop();
@@ -381,7 +382,7 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
     const int n_stiles = (N + BS - 1) / BS;
     const int n_qtiles = (B + BQ - 1) / BQ;
     FusedWs ws;
-    const size_t need = fused_layout(B, n_stiles, BS, static_cast<char*>(workspace), &ws);
+    const size_t need = fused_layout(B, n_stiles, BS, static_cast<char*>(workspace), &ws, C);
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
     const int grid = padded_grid(n_stiles, n_qtiles);
     // RS = 5 exists for the LDS-DMA modes only (two workgroups per CU); the register-staged loaders

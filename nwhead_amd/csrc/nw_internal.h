@@ -67,7 +67,7 @@ int tile_timer_enable(bool on);
 int tile_timer_read(double* total_us, int64_t* launches);
 int pick_rs(int64_t B, int64_t N, int64_t d, bool f16 = false);
 bool fused_eligible(const float* q, const float* s, int64_t B, int64_t N, int64_t d, int64_t C);
-size_t fused_workspace_bytes(int64_t B, int64_t N, int64_t d);
+size_t fused_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C = 0);
 int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d,
                       hipStream_t st);
 int launch_fused(const float* q, const float* s, const int64_t* sy, const float* s_norm2,

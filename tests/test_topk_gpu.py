@@ -101,3 +101,20 @@ def test_scores_through_the_bank_and_few_class_merge():
             w = torch.softmax(ref, -1)
             want = torch.log(torch.stack([w[:, sy == c].sum(1) for c in range(C)], 1) + 1e-12)
             assert (out.double() - want).abs().max().item() < 3e-5
+
+
+def test_many_classes_merge_tables_in_global_memory():
+    """More classes than the run merge holds tables for in LDS (C > ~4200): the tables are built once per launch in the
+    workspace (nw_class_tables_kernel).  Outputs against fp64, sorted and shuffled labels, with and without a bank."""
+    from nwhead_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    B, N, d, C = 192, 12000, 64, 6000
+    q, s = torch.randn(B, d, generator=g).to(dev), torch.randn(N, d, generator=g).to(dev)
+    w = torch.softmax(-torch.cdist(q.double(), s.double()), -1)
+    for sy in ((torch.arange(N) * C // N), torch.randint(0, C, (N,), generator=g)):
+        syd = sy.to(dev)
+        want = torch.log(w @ torch.nn.functional.one_hot(syd, C).double() + 1e-12)
+        for cache in (None, ops.SplitBank(s, labels=syd)):
+            out = ops.nw_head(q, s, syd, C, support_cache=cache)
+            assert (out.double() - want).abs().max().item() < 3e-5
