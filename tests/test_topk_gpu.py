@@ -118,3 +118,35 @@ def test_many_classes_merge_tables_in_global_memory():
         for cache in (None, ops.SplitBank(s, labels=syd)):
             out = ops.nw_head(q, s, syd, C, support_cache=cache)
             assert (out.double() - want).abs().max().item() < 3e-5
+
+
+def test_embedding_sizes_that_are_not_multiples_of_four():
+    """d % 4 != 0: nw_head pads the operands with zero columns (same scores, same norms) so that the tile kernels serve
+    them; outputs and gradients against fp64, with and without a bank's cached norms."""
+    import torch.nn.functional as F
+    from nwhead_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(13)
+    for kind in ("euclidean", "cosine"):
+        for B, N, d, C in ((33, 700, 130, 10), (64, 3000, 67, 50)):
+            q0, s0 = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+            sy = torch.randint(0, C, (N,), generator=g)
+            t = torch.randint(0, C, (B,), generator=g)
+            q64, s64 = q0.double().requires_grad_(True), s0.double().requires_grad_(True)
+            if kind == "euclidean":
+                sc = -torch.cdist(q64, s64)
+            else:
+                sc = F.normalize(q64, dim=-1) @ F.normalize(s64, dim=-1).t()
+            ref = torch.log(torch.softmax(sc, -1) @ F.one_hot(sy, C).double() + 1e-12)
+            F.nll_loss(ref, t).backward()
+            q, s = q0.to(dev).requires_grad_(True), s0.to(dev).requires_grad_(True)
+            out = ops.nw_head(q, s, sy.to(dev), C, kind)
+            F.nll_loss(out, t.to(dev)).backward()
+            assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 3e-5
+            for got, want in ((q.grad, q64.grad), (s.grad, s64.grad)):
+                assert got.shape == want.shape
+                assert ((got.cpu().double() - want).abs().max() / want.abs().max()).item() < 1e-4
+            sd = s0.to(dev)
+            bank = ops.SplitBank(sd)
+            out2 = ops.nw_head(q0.to(dev), sd, sy.to(dev), C, kind, support_cache=bank)
+            assert (out2.cpu().double() - ref.detach()).abs().max().item() < 3e-5
