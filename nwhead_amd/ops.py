@@ -110,6 +110,8 @@ def nw_scores(q, s, kind="euclidean", logit_scale=None, support_cache=None):
     ls = None if logit_scale is None else _f32c(logit_scale)
     if (support_cache is not None and not batched and support_cache.split is not None and support_cache.sorted_rows is None
             and support_cache.matches(s) and B > 0 and N > 0 and N % 4 == 0):
+        q, s = _apply_bank_padding(q, s, support_cache)
+        d = q.shape[1]
         # one class, all labels 0: the aggregation is a formality, the (B, N) score matrix is what is wanted
         zeros = getattr(support_cache, "_zero_labels", None)
         if zeros is None or zeros.numel() != N:
@@ -159,7 +161,9 @@ def row_norm2(x):
 class SplitBank:
     """A support matrix prepared once for repeated 'full' inference: split-fp16 rows, row scales and
     squared norms (nw_split_rows_f16x2).  Pass it as ``support_cache`` to nw_head / nw_partials.
-    Falls back to norms only (fp32 matrix cores) when d % 32 != 0.
+    The split format needs d % 32 == 0: a bank of another width (d >= 64) keeps a copy padded with zero columns
+    (``rows``, ``pad``; no dot product or norm changes) and the callers pad the queries to match; narrower ones fall back
+    to norms only (fp32 matrix cores).
 
     ``labels``: the (N,) labels that will be used with this bank.  The tile kernels sum softmax weights
     per RUN of equal consecutive labels, so a class-sorted bank (what precompute() builds) costs 1-2 sums
@@ -179,6 +183,10 @@ class SplitBank:
             if lo < 0:
                 raise ValueError("support labels must be non-negative class indices (F.one_hot, nw.py:276, raises too)")
             self.label_max = hi                # nw_head refuses n_classes <= label_max, like F.one_hot
+        self.pad, self.rows = 0, None
+        if sc.dim() == 2 and sc.shape[1] % 32 and sc.shape[1] >= 64 and sc.shape[0] > 0:
+            self.pad = (-sc.shape[1]) % 32
+            sc = self.rows = torch.nn.functional.pad(sc, (0, self.pad))     # what the kernels read instead of `s`
         self.sorted_rows = self.sorted_labels = None
         if labels is not None and sc.dim() == 2 and labels.dim() == 1 and labels.numel() > 1:
             lab = labels.detach().to(torch.int64)
@@ -242,6 +250,17 @@ def _resolve_sorted_bank(s, sy, cache, per_position_outputs=False):
     if per_position_outputs or not same:
         return s, sy, None
     return cache.sorted_rows, cache.sorted_labels, cache
+
+
+def _apply_bank_padding(q, s, cache):
+    """A bank of a width that is not a multiple of 32 holds zero-padded rows (SplitBank.rows / .sorted_rows): pad the
+    queries alike and read the bank's rows instead of the caller's tensor."""
+    if cache is None or not cache.pad:
+        return q, s
+    q = torch.nn.functional.pad(q, (0, cache.pad))
+    if s.shape[-1] != cache.shape[1]:
+        s = cache.rows
+    return q, s
 
 
 class _NoCtx:
@@ -352,6 +371,11 @@ def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weig
                          "(the reference's F.one_hot, nw.py:276, raises)")
     s, sy, support_cache = _resolve_sorted_bank(s, sy, support_cache,
                                                 return_weights or (torch.is_grad_enabled() and s.requires_grad))
+    if support_cache is not None and support_cache.pad:
+        if torch.is_grad_enabled() and s.requires_grad:    # the padded copy is not part of the caller's graph
+            support_norm2, support_cache = support_cache.norm2, None
+        else:
+            q, s = _apply_bank_padding(q, s, support_cache)
     if q.shape[-1] % 4 and s.dim() == 2 and s.shape[0] > 25:
         # an embedding size that is not a multiple of 4 would miss every tile kernel (they move 16-byte pieces) and land
         # on the generic two-kernel path (measured at d = 130: 925 us against 19 at d = 128; 52 ms with 20000 classes):
@@ -392,13 +416,14 @@ def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_sca
     """Write partials into ``packed`` laid out as [m (B) | den (B) | num (B*C)] (flat, contiguous):
     one buffer = one collective.  Inputs must already be fp32/int64 contiguous HIP tensors."""
     lib = _lib.load()
+    qc, sc = _apply_bank_padding(qc, sc, cache)
     B, d = qc.shape
     N = sc.shape[0]
     C = int(n_classes)
     flat = packed.view(-1)
     m, den, num = flat[:B], flat[B:2 * B], flat[2 * B:2 * B + B * C]
     ws_bytes = lib.nw_fwd_workspace_bytes(B, N, d, C)
-    if ws is None:
+    if ws is None or ws.numel() < ws_bytes:
         ws = _workspace(ws_bytes, qc.device)
     ls = None if logit_scale is None else _f32c(logit_scale)
     ssplit = sscale = None
@@ -692,6 +717,7 @@ def nw_head_influence(q, s, sy, n_classes, qy, kind="euclidean", logit_scale=Non
         raise ValueError("support_cache was prepared from another support tensor")
     # influences are indexed by support position: an unsorted bank's class-sorted copy cannot serve them
     s, sy, support_cache = _resolve_sorted_bank(s, sy, support_cache, per_position_outputs=True)
+    q, s = _apply_bank_padding(q, s, support_cache)
     lib = _lib.load()
     qc, sc = _f32c(q), _f32c(s)
     syc = sy.detach().to(torch.int64).contiguous()

@@ -73,6 +73,8 @@ class ShardedBank:
     # ---- HIP compute hooks (the product path)
     def _hip_partial(self, packed_row, q):
         N, d = self.feat.shape
+        if self.cache is not None and self.cache.pad:
+            d = self.cache.shape[1]              # a shard of a width that is not a multiple of 32: the bank's padded rows
         B = q.shape[0]
         need = ops._lib.load().nw_fwd_workspace_bytes(B, N, d, self.CL)
         if self._ws is None or self._ws.numel() < need:

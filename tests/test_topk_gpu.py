@@ -150,3 +150,46 @@ def test_embedding_sizes_that_are_not_multiples_of_four():
             bank = ops.SplitBank(sd)
             out2 = ops.nw_head(q0.to(dev), sd, sy.to(dev), C, kind, support_cache=bank)
             assert (out2.cpu().double() - ref.detach()).abs().max().item() < 3e-5
+
+
+def test_banks_whose_width_is_not_a_multiple_of_32():
+    """SplitBank of a (N, d) bank with d % 32 != 0, d >= 64: the bank keeps rows padded with zero columns (split format),
+    callers pad the queries: nw_head (sorted and shuffled labels, with weights, with a gradient for the queries),
+    nw_scores, nw_head_influence and the sharded partial path against fp64."""
+    import torch.nn.functional as F
+    from nwhead_amd import ops
+    from nwhead_amd.sharded import ShardedBank
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(14)
+    for B, N, d, C in ((96, 6000, 100, 20), (300, 20000, 130, 7)):
+        q0, s0 = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+        q, s = q0.to(dev), s0.to(dev)
+        sc64 = -torch.cdist(q0.double(), s0.double())
+        w64 = torch.softmax(sc64, -1)
+        for sy in ((torch.arange(N) * C // N), torch.randint(0, C, (N,), generator=g)):
+            syd = sy.to(dev)
+            want = torch.log(w64 @ F.one_hot(sy, C).double() + 1e-12)
+            bank = ops.SplitBank(s, labels=syd)
+            assert bank.pad == (-d) % 32 and bank.split is not None
+            out = ops.nw_head(q, s, syd, C, support_cache=bank)
+            assert out.shape == (B, C) and (out.cpu().double() - want).abs().max().item() < 3e-5
+            out_w, wts = ops.nw_head(q, s, syd, C, return_weights=True, support_cache=bank)
+            assert (wts.cpu().double() - w64).abs().max().item() < 3e-6 and (out_w.cpu().double() - want).abs().max().item() < 3e-5
+            qg = q.clone().requires_grad_(True)
+            t = torch.randint(0, C, (B,), generator=g)
+            F.nll_loss(ops.nw_head(qg, s, syd, C, support_cache=bank), t.to(dev)).backward()
+            q64 = q0.double().requires_grad_(True)
+            F.nll_loss(torch.log(torch.softmax(-torch.cdist(q64, s0.double()), -1) @ F.one_hot(sy, C).double() + 1e-12), t).backward()
+            assert qg.grad.shape == (B, d)
+            assert ((qg.grad.cpu().double() - q64.grad).abs().max() / q64.grad.abs().max()).item() < 1e-4
+        plain = ops.SplitBank(s)
+        assert (ops.nw_scores(q, s, support_cache=plain).cpu().double() - sc64).abs().max().item() < 3e-5
+        sy = (torch.arange(N) * C // N); syd = sy.to(dev)
+        qy = torch.randint(0, C, (B,), generator=g).to(dev)
+        out_i, infl = ops.nw_head_influence(q, s, syd, C, qy, support_cache=plain)
+        want = torch.log(w64 @ F.one_hot(sy, C).double() + 1e-12)
+        assert (out_i.cpu().double() - want).abs().max().item() < 3e-5 and infl.shape == (B, N)
+        sb = ShardedBank(s, syd, C)
+        assert sb.cache.pad == (-d) % 32
+        got = sb.predict_stream([q[:50], q[50:]], bucket=2)
+        assert (torch.cat(got).cpu().double() - want).abs().max().item() < 3e-5
