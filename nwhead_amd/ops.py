@@ -387,6 +387,14 @@ def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weig
         q, s = torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(s, (0, pad))
     needs_grad = torch.is_grad_enabled() and (q.requires_grad or s.requires_grad or
                                               (logit_scale is not None and logit_scale.requires_grad))
+    d_now = q.shape[-1]
+    if (needs_grad and support_cache is None and s.dim() == 2 and d_now % 32 and d_now >= 256
+            and _lib.load().nw_bwd_uses_split(q.shape[0], s.shape[0], d_now + (-d_now) % 32, int(n_classes), 0)):
+        # a training step at a width that is not a multiple of 32: zero columns take it to the split-row kernels of the
+        # forward and the backward (d = 1000 at T: 326 -> 237 us per eager forward + backward; narrow widths lose more to the
+        # two extra torch ops than the kernels gain: d = 100, 168 -> 232 us); autograd slices the gradients back
+        pad = (-d_now) % 32
+        q, s = torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(s, (0, pad))
     if not needs_grad:   # inference: skip the autograd node (its bookkeeping costs more than the kernels at small sizes)
         return _NWHeadFn.forward(_NoCtx, q, s, sy, logit_scale, int(n_classes), kid, bool(return_weights),
                                  support_norm2, support_cache)
