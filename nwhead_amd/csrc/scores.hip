@@ -72,15 +72,9 @@ __global__ __launch_bounds__(TILE_THREADS) void nw_scores_mfma_kernel(
 // One wave per (query b, support j): direct-difference form for the distance kernels (torch's
 // cdist regime for N <= 25: exact 0 for identical rows), plain dot/norms for the others.
 template <int KIND>
-__global__ __launch_bounds__(256) void nw_scores_direct_kernel(
-    const float* __restrict__ q, const float* __restrict__ s, float* __restrict__ scores,
-    const float* __restrict__ logit_scale, int64_t B, int64_t N, int64_t d, int sup_batched) {
-    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (pair >= B * N) return;
-    const int64_t b = pair / N, j = pair % N;
-    const float* x = q + b * d;
-    const float* y = s + (sup_batched ? (b * N + j) * d : j * d);
+__device__ __forceinline__ void direct_pair(const float* __restrict__ x, const float* __restrict__ y,
+                                            float* __restrict__ scores, const float* __restrict__ logit_scale,
+                                            int64_t pair, int64_t d, int lane) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     if (KIND == NW_SCORE_EUCLIDEAN) {
         for (int64_t k = lane; k < d; k += 64) {
@@ -117,6 +111,31 @@ __global__ __launch_bounds__(256) void nw_scores_direct_kernel(
     if (lane == 0) scores[pair] = out;
 }
 
+// one wave per (query, support) pair: the training episodes' shapes (a few dozen queries, a few dozen supports)
+template <int KIND>
+__global__ __launch_bounds__(256) void nw_scores_direct_kernel(
+    const float* __restrict__ q, const float* __restrict__ s, float* __restrict__ scores,
+    const float* __restrict__ logit_scale, int64_t B, int64_t N, int64_t d, int sup_batched) {
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pair >= B * N) return;
+    const int64_t b = pair / N, j = pair % N;
+    direct_pair<KIND>(q + b * d, s + (sup_batched ? (b * N + j) * d : j * d), scores, logit_scale, pair, d, lane);
+}
+
+// one wave per QUERY, its supports in turn (same arithmetic per pair): with thousands of queries a wave per pair re-reads
+// every query row N times through L2 (65536 x 20 x 512: 0.64 ms); here the row stays in the wave's L1
+template <int KIND>
+__global__ __launch_bounds__(256) void nw_scores_direct_rows_kernel(
+    const float* __restrict__ q, const float* __restrict__ s, float* __restrict__ scores,
+    const float* __restrict__ logit_scale, int64_t B, int64_t N, int64_t d, int sup_batched) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    for (int64_t j = 0; j < N; ++j)
+        direct_pair<KIND>(q + b * d, s + (sup_batched ? (b * N + j) * d : j * d), scores, logit_scale, b * N + j, d, lane);
+}
+
 template <int RS, int KIND>
 int launch_mfma_rs(const float* q, const float* s, float* scores, const float* ls, int B, int N,
                    int d, hipStream_t st) {
@@ -148,6 +167,14 @@ int launch_kind(const float* q, const float* s, float* scores, int64_t B, int64_
         }
     }
     const int64_t pairs = B * N;
+    if (B >= 4096 && N > 1) {   // enough queries to fill the chip with a wave each
+        const int64_t grid = (B + 3) / 4;
+        if (grid > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+        hipLaunchKernelGGL((nw_scores_direct_rows_kernel<KIND>), dim3((unsigned)grid), dim3(256), 0, st, q,
+                           s, scores, ls, B, N, d, sup_batched);
+        NW_CHECK_LAUNCH();
+        return NW_OK;
+    }
     const int64_t grid = (pairs + 3) / 4;
     if (grid > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
     hipLaunchKernelGGL((nw_scores_direct_kernel<KIND>), dim3((unsigned)grid), dim3(256), 0, st, q,
