@@ -479,7 +479,11 @@ int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* 
                 int d, int C, int n_stiles, int n_qtiles, hipStream_t st) {
     if constexpr (RS > 5) {
         (void)sy; (void)C;  // the run tables (launch_run_tables) are the caller's job
-        const int cus = device_cu_count() & ~7;  // the same number of workgroups on every XCD
+        int cus = device_cu_count() & ~7;  // the same number of workgroups on every XCD
+        // NW_PERSISTENT_WGS: fewer workgroups than CUs (a multiple of 8), e.g. to leave CUs to a concurrent RCCL kernel
+        // of the sharded path -- an experiment for a multi-GPU box, never measured here (one GPU)
+        static const int wg_cap = [] { const char* e = getenv("NW_PERSISTENT_WGS"); return e ? atoi(e) & ~7 : 0; }();
+        if (wg_cap >= 8 && wg_cap < cus) cus = wg_cap;
         // 0: 64-query tiles, one workgroup per CU; 1: two per CU; 2: 128-query tiles.  Measured at B = 2048,
         // N = 50000, d = 512 (tools/bench_fused.hip, same device): 387 / 353 / 337 us.  128-query tiles
         // unless their padding costs more than 15 % of the rows (then two 64-query workgroups per CU).
