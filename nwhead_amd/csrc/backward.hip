@@ -676,7 +676,8 @@ extern "C" int nw_bwd_bank_f32(const float* q, const float* s, const float* s_no
     const size_t need = bwd_layout(B, N, d, C, sup_batched, static_cast<char*>(workspace), &ws);
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
     const size_t lds = (80 + (size_t)C + (ws.split ? (size_t)ws.ld : 0)) * sizeof(float);
-    const unsigned coeff_threads = N >= 2048 ? 1024 : 256;
+    static const int coeff_env = [] { const char* e = getenv("NW_COEFF_THREADS"); return e ? atoi(e) : 0; }();   // timing experiments
+    const unsigned coeff_threads = (coeff_env == 256 || coeff_env == 512 || coeff_env == 1024) ? (unsigned)coeff_env : (N >= 2048 ? 1024 : 256);
     if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
     const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(s) |
                            reinterpret_cast<uintptr_t>(gq) | reinterpret_cast<uintptr_t>(gs)) & 15) == 0;
