@@ -302,6 +302,30 @@ int nw_conv1x1_f32(const float *x, int64_t x_batch_stride, const float *pre_scal
                    int64_t n, int64_t cin, int64_t cout, int64_t hw, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Convolution of the backbones on the fp16 matrix cores at fp32-grade accuracy (csrc/conv_nhwc.hip): an implicit
+ * GEMM over fp32 NHWC (torch channels_last) activations.  Replaces F.conv2d at model/resnet.py:31-66 (BasicBlock's
+ * 3x3), :147-156 / :178-190 (strided 3x3 and the 1x1 projection of a stage's first block), model/densenet.py:33-60
+ * (conv1 1x1, conv2 3x3), :82-91 (transition 1x1); a stride-1 convolution's data gradient (train.py:414) is the same
+ * call on the flipped, transposed weight.
+ *     y[n, yo, xo, co] = post( bias[co] + sum_{ky,kx,ci} W[co,ky,kx,ci] x[n, s yo + ky - pad, s xo + kx - pad, ci] [+ residual] )
+ *   x         (n, H, W, Cin) fp32, Cin % 32 == 0
+ *   amax_in   device scalar: an upper bound on max|x| (nw_absmax_f32, or the amax_out of the call that wrote x): the
+ *             activations are split into fp16 pairs on the way into LDS with ONE power of two per tensor
+ *   w_split, w_scale   the weight as (Cout, KH*KW*Cin) rows -- the bytes of a channels_last (Cout, Cin, KH, KW) tensor --
+ *             through nw_split_rows_f16x2 (its third output, the row norms, is not used); Cout % 32 == 0
+ *   bias      optional (Cout,);  residual optional (n, Ho, Wo, Cout);  relu != 0: max(., 0) (NaN kept)
+ *   y         (n, Ho, Wo, Cout) fp32;  amax_out optional device scalar <- max|y| (cleared by the call)
+ * nw_conv2d_nhwc_supported: 1 when the shape is served (else nw_conv2d_nhwc_f16x2 returns NW_ERR_UNSUPPORTED).
+ * ------------------------------------------------------------------------------------------- */
+int nw_absmax_f32(const float *x, int64_t count, float *amax_out, void *stream);
+int nw_conv2d_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                             int64_t stride, int64_t pad);
+int nw_conv2d_nhwc_f16x2(const float *x, const float *amax_in, const float *w_split, const float *w_scale,
+                         const float *bias, const float *residual, int relu, float *y, float *amax_out,
+                         int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                         int64_t stride, int64_t pad, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ ReLU) in front of / behind the backbones' convolutions, forward and
  * backward, one kernel each (torch: batch-norm kernels + a relu kernel each way).  Same call sites as
  * nw_scale_shift_relu_f32 plus the conv -> bn -> relu pairs of model/resnet.py:31-66; the backward is what

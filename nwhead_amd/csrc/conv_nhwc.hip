@@ -1,0 +1,524 @@
+// conv_nhwc.hip -- 2-D convolution of the backbones as an implicit GEMM on the fp16 matrix cores at fp32-grade
+// accuracy (gfx950 / MI355X only).  Replaces F.conv2d at the call sites of model/resnet.py:31-66, :147-156, :178-190
+// and model/densenet.py:33-60, :82-91 (forward; the data gradient of a stride-1 convolution is the same kernel on the
+// flipped, transposed weight).
+//
+//     y[n, yo, xo, co] = post( bias[co] + sum_{ky,kx,ci} W[co, ky, kx, ci] x[n, s yo + ky - p, s xo + kx - p, ci] [+ res] )
+//
+// Layout: activations fp32 NHWC (torch channels_last), Cin % 32 == 0, Cout % 32 == 0.  Arithmetic: the head's
+// (tile_f16.h): every fp32 operand is a pair of fp16 numbers x = h + l, a product of two operands is three
+// v_mfma_f32_16x16x32_f16 (hl, lh, hh), accumulated in fp32.
+//   * weights: split ONCE per weight update (nw_split_rows_f16x2 over the (Cout, KH KW Cin) matrix a channels_last
+//     weight is: one power of two per output channel -- an OUTPUT index, undone in the store);
+//   * activations: split IN FLIGHT by the loader waves (global_load_dwordx4 -> 2^e x -> h, l -> ds_write_b128) with ONE
+//     power of two per tensor, from a bound on max|x| the producer of x left in `amax_in` (any upper bound is legal;
+//     the convolution's own store does an atomicMax into `amax_out`, so a chain of convolutions never reads a tensor
+//     twice).  Per-pixel scales would not do: the taps of one output read pixels with different scales.
+//
+// One persistent 512-thread workgroup per CU: waves 0-3 multiply (tile = 128 or 256 output pixels x 32 / 64 / 128
+// output channels; the output channels are the A operand so that a lane ends up with four consecutive channels of one
+// pixel: 16-byte stores), waves 4-7 move data and run ahead across tile boundaries.
+//   PATCH mode (3x3, stride 1, padding 1): per 32 input channels the pixels around the tile go to LDS ONCE -- a range
+//     of a virtual padded raster (rows W + 1 apart, one zero row between images: the zeros are written by the loader,
+//     the nine taps are nine constant row shifts and no border test exists in the loop) -- and serve nine stages; the
+//     weights of each (channel chunk, tap) stage come by LDS-DMA.
+//   GATHER mode (everything else: 1x1, strided, other kernel sizes): every stage gathers the pixels of its tap.
+#include "nw_internal.h"
+#include "tile_dma.h"
+#include <cstdlib>
+
+namespace nw {
+namespace {
+
+struct ConvP {
+    const float* x;
+    const float* amax_in;
+    const char* ws;          // split weight rows, (Cout, T * Cin) floats-worth of bytes
+    const float* wscale;     // (Cout,) 2^-e of the weight rows
+    const float* bias;       // nullable
+    const float* res;        // nullable (M, Cout)
+    float* y;
+    unsigned* amax_out;      // nullable
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
+    int IP, IMG;             // virtual raster of PATCH mode: row stride W + pad, image stride (H + pad) IP
+    int M, mtiles, ntiles;
+};
+
+template <int NA, int NB, int WM, bool PATCH>
+struct ConvCfg {
+    static constexpr int WN = 4 / WM;
+    static constexpr int BN = 16 * NA * WM, BM = 16 * NB * WN;
+    static constexpr int NIW = BN / 32;                           // weight DMAs per loader wave per stage
+    static constexpr int EMAX = PATCH ? BM + 192 : BM;            // activation entries (pixels) per buffer
+    static constexpr int NPASS = EMAX / 64;
+    static constexpr int NACT = 2 * NPASS;                        // global loads per lane per chunk
+    static constexpr int TI = PATCH ? 9 : 1;                      // stages per activation chunk
+    static constexpr int NSET = PATCH ? 1 : 2;                    // register sets of activation loads in flight
+    static constexpr int NWR = BN == 128 ? (PATCH ? 4 : 6) : 8;   // weight ring depth
+    static constexpr int AH = NWR - 1;                            // weight stages issued ahead
+    static constexpr int WST = BN * 128, PB = EMAX * 128;
+    // activation buffers: a chunk is written two stages before its first stage; the first stage of a TILE is read at
+    // its own start (no fragment prefetch across tiles), so with one-stage chunks the buffer two chunks back may still
+    // be in use: three buffers in GATHER mode
+    static constexpr int NPB = PATCH ? 2 : 3;
+    static constexpr size_t LDS = (size_t)NWR * WST + NPB * (size_t)PB;
+    static_assert(EMAX % 64 == 0 && LDS <= 160 * 1024, "tile shape");
+    static_assert(PATCH ? (9 * NIW < 64 && (AH - 2) * NIW + NACT < 64) : ((AH - 2) * (NACT + NIW) < 64), "vmcnt is a 6-bit field");
+};
+
+template <int NA, int NB, int WM, bool PATCH>
+__global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
+    using C = ConvCfg<NA, NB, WM, PATCH>;
+    constexpr int BN = C::BN, BM = C::BM, NIW = C::NIW, NPASS = C::NPASS, NACT = C::NACT, TI = C::TI, NSET = C::NSET;
+    constexpr int NWR = C::NWR, AH = C::AH, WST = C::WST, PB = C::PB, NPB = C::NPB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wring = smem;
+    char* const pbuf = smem + NWR * WST;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.KH * p.KW, nc = p.Cin >> 5;
+    const int ST = nc * T;                                         // stages per tile
+    const int CH = ST / TI;                                        // activation chunks per tile
+    // tiles of this workgroup: every XCD (workgroups with equal id mod 8) walks a contiguous range, its workgroups
+    // take consecutive tiles (neighbouring tiles share halo pixels and weights in the XCD's L2)
+    const int total = p.mtiles * p.ntiles;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int tpx = (total + 7) >> 3;
+    const int tbeg = xcd * tpx + slot, tend = min(total, (xcd + 1) * tpx);
+    const int ntile = tbeg < tend ? (tend - tbeg + nslot - 1) / nslot : 0;
+    if (ntile == 0) return;
+    const int S = ntile * ST;                                      // stages of this workgroup
+    const int QT = ntile * CH;                                     // activation chunks of this workgroup
+    const int HW = p.Ho * p.Wo;
+    const size_t wrow = (size_t)T * p.Cin * 4;                     // bytes per weight row
+
+    if (wave >= 4) {
+        // ============================================================== loaders
+        const int lw = wave - 4, lt = tid - 256, lj = lt & 3, le = lt >> 2;
+        const float up = __builtin_ldexpf(1.f, split_exponent(*p.amax_in));
+        // ---- weight DMA: stage cursor
+        unsigned woff[NIW];
+#pragma unroll
+        for (int m = 0; m < NIW; ++m) {
+            const int R = 8 * (lw + 4 * m) + (lane >> 3);
+            woff[m] = (unsigned)((size_t)R * wrow) + (unsigned)(((lane & 7) ^ ((R >> 1) & 7)) << 4);
+        }
+        int d_tile = 0, d_k = 0, d_s = 0;                          // next stage to issue: tile index, stage in tile, global
+        auto issue_w = [&]() {
+            const int t_id = tbeg + d_tile * nslot;
+            const int nt = t_id % p.ntiles;
+            int c, t;
+            if (PATCH) { c = d_k / 9; t = d_k - 9 * c; } else { t = d_k / nc; c = d_k - t * nc; }
+            const char* base = p.ws + (size_t)(nt * BN) * wrow + ((size_t)t * p.Cin + 32 * c) * 4;
+            char* dst = wring + (d_s % NWR) * WST;
+#pragma unroll
+            for (int m = 0; m < NIW; ++m)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[m]),
+                                                 (__attribute__((address_space(3))) void*)(dst + 1024 * (lw + 4 * m)), 16, 0, 0);
+            ++d_s;
+            if (++d_k == ST) { d_k = 0; ++d_tile; }
+        };
+        // ---- activations: chunk cursor
+        int a_tile = 0, a_q = 0, a_g = 0;                          // next chunk to LOAD: tile index, chunk in tile, global
+        unsigned aoff[NPASS];                                      // PATCH: source offset (floats) of the entry at chunk 0
+        unsigned avalid = 0;                                       // bit q: the entry of pass q is a real pixel
+        int gy[NPASS], gx[NPASS], gn[NPASS];                       // GATHER: s yo - pad, s xo - pad, n H  (gn < 0: no pixel)
+        auto setup_tile = [&]() {
+            const int t_id = tbeg + a_tile * nslot;
+            const int m0 = (t_id / p.ntiles) * BM;
+            if (PATCH) {
+                const int n0 = m0 / HW, r0 = m0 - n0 * HW, y0 = r0 / p.Wo, x0 = r0 - y0 * p.Wo;
+                const int lo = n0 * p.IMG + y0 * p.IP + x0;
+                avalid = 0;
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const int idx = lo + le + 64 * q;
+                    const int n = idx / p.IMG, r = idx - n * p.IMG, row = r / p.IP, col = r - row * p.IP;
+                    const int yi = row - p.pad, xi = col - p.pad;
+                    const bool ok = n < p.N && yi >= 0 && xi >= 0 && xi < p.W;
+                    aoff[q] = ok ? (unsigned)(((n * p.H + yi) * p.W + xi) * p.Cin + 8 * lj) : 0u;
+                    avalid |= ok ? (1u << q) : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const int m = m0 + le + 64 * q;
+                    const int n = m / HW, r = m - n * HW, yo = r / p.Wo, xo = r - yo * p.Wo;
+                    gy[q] = p.stride * yo - p.pad;
+                    gx[q] = p.stride * xo - p.pad;
+                    gn[q] = m < p.M ? n * p.H : -1;
+                }
+            }
+        };
+        float4 ld[NSET][NPASS][2];
+        unsigned ldvalid[NSET];
+        auto issue_a = [&](float4 (&L)[NPASS][2], unsigned& valid) {   // loads of the cursor's chunk
+            if (a_q == 0) setup_tile();
+            if (PATCH) {
+                const float* base = p.x + 32 * a_q;
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const float4* src = reinterpret_cast<const float4*>(base + aoff[q]);
+                    L[q][0] = src[0];
+                    L[q][1] = src[1];
+                }
+                valid = avalid;
+            } else {
+                const int t = a_q / nc, c = a_q - t * nc, dy = t / p.KW, dx = t - dy * p.KW;
+                valid = 0;
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const int yi = gy[q] + dy, xi = gx[q] + dx;
+                    const bool ok = gn[q] >= 0 && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+                    const unsigned off = ok ? (unsigned)(((gn[q] + yi) * p.W + xi) * p.Cin + 32 * c + 8 * lj) : 0u;
+                    const float4* src = reinterpret_cast<const float4*>(p.x + off);
+                    L[q][0] = src[0];
+                    L[q][1] = src[1];
+                    valid |= ok ? (1u << q) : 0u;
+                }
+            }
+            ++a_g;
+            if (++a_q == CH) { a_q = 0; ++a_tile; }
+        };
+        auto write_a = [&](const float4 (&L)[NPASS][2], unsigned valid, int g) {   // a loaded chunk -> split -> buffer g % NPB
+            char* pb = pbuf + (g % NPB) * PB;
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) {
+                const bool ok = (valid >> q) & 1;
+                const float xs[8] = {L[q][0].x, L[q][0].y, L[q][0].z, L[q][0].w, L[q][1].x, L[q][1].y, L[q][1].z, L[q][1].w};
+                half8 h, l;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float v = ok ? xs[k] * up : 0.f;
+                    h[k] = (_Float16)v;
+                    l[k] = (_Float16)(v - (float)h[k]);
+                }
+                const int e = le + 64 * q, sw = (e >> 1) & 7;
+                *reinterpret_cast<half8*>(pb + e * 128 + ((lj ^ sw) << 4)) = h;
+                *reinterpret_cast<half8*>(pb + e * 128 + (((4 + lj) ^ sw) << 4)) = l;
+            }
+        };
+        // Chunk g is WRITTEN in iteration TI g - 2 (its buffer was last read for stage TI (g - 1) - 1, whose reads
+        // are complete at barrier TI (g - 1) - 2) and its loads are ISSUED NSET chunks earlier, right after the write
+        // that frees their registers.  Weights of stage s + AH are issued in iteration s; stage s + 2 (activations and
+        // weights) is complete at barrier s.  In the steady state the order of issue is periodic, so the counted waits
+        // are constants; at the two ends of the run (first iterations, and once one of the cursors has run out)
+        // everything is waited for.
+        // ---- prologue: chunks written before the first barrier (stages 0 and 1), loads of the following NSET chunks
+        //      and the weights of stages 0 .. AH - 1 in flight
+        issue_a(ld[0], ldvalid[0]);
+        wait_vmcnt<0>();
+        write_a(ld[0], ldvalid[0], 0);
+        int w_g = 1;                                               // next chunk to write
+        if (TI == 1 && QT > 1) {
+            issue_a(ld[0], ldvalid[0]);
+            wait_vmcnt<0>();
+            write_a(ld[0], ldvalid[0], 1);
+            w_g = 2;
+        }
+#pragma unroll
+        for (int u = 0; u < NSET; ++u)
+            if (a_g < QT) issue_a(ld[u], ldvalid[u]);   // (chunk w_g + u goes to set (w_g + u) % NSET = u: w_g % NSET == 0)
+#pragma unroll
+        for (int s = 0; s < AH; ++s)
+            if (d_s < S) issue_w();
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // (the activation loads issued above were waited for: the first write of the loop finds them landed)
+        int since_a = 1 << 20;                                     // iterations since activation loads were last issued
+        int steady = 0;                                            // iterations run in the periodic order
+        for (int s = 0; s < S; ++s) {
+            const bool regular = steady >= (PATCH ? 9 + AH : AH + NSET + 1) && d_s < S && (PATCH || a_g < QT);
+            bool issued = false;
+            // A: the chunk whose first stage is s + 2
+            if (s + 2 < S && (s + 2) % TI == 0) {
+                const int g = w_g;                                 // == (s + 2) / TI
+                if (!regular) wait_vmcnt<0>();
+                else if constexpr (PATCH) wait_vmcnt<9 * NIW>();   // its loads are older than nine stages of weights
+                else wait_vmcnt<NSET * NIW + (NSET - 1) * NACT>(); // ... than NSET stages of weights, NSET - 1 chunks
+                if (NSET == 1 || (g % NSET) == 0) {
+                    write_a(ld[0], ldvalid[0], g);
+                    if (a_g < QT) { issue_a(ld[0], ldvalid[0]); issued = true; }
+                } else {
+                    write_a(ld[NSET - 1], ldvalid[NSET - 1], g);
+                    if (a_g < QT) { issue_a(ld[NSET - 1], ldvalid[NSET - 1]); issued = true; }
+                }
+                ++w_g;
+            }
+            // B: weights AH stages ahead
+            if (d_s < S) issue_w();
+            // C: stage s + 2 has landed: all but the weight stages (and activation chunks) issued after it
+            since_a = issued ? 0 : since_a + 1;
+            if (!regular) wait_vmcnt<0>();
+            else if constexpr (!PATCH) wait_vmcnt<(AH - 2) * (NACT + NIW)>();
+            else {
+                if (since_a < AH - 2) wait_vmcnt<(AH - 2) * NIW + NACT>();
+                else wait_vmcnt<(AH - 2) * NIW>();
+            }
+            ++steady;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ================================================================== consumers
+    const int i = lane & 15, g = lane >> 4;
+    const int wco = (wave % WM) * (16 * NA), wpx = (wave / WM) * (16 * NB);
+    const int asw = (i >> 1) & 7;
+    const int aoff_h = (wco + i) * 128 + ((g ^ asw) << 4), aoff_l = (wco + i) * 128 + (((4 + g) ^ asw) << 4);
+    const float inv_up = __builtin_ldexpf(1.f, -split_exponent(*p.amax_in));
+    struct Frag {
+        float4 ah[NA], al[NA], bh[NB], bl[NB];
+    };
+    auto mm = [](const float4& a, const float4& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    };
+    float amax = 0.f;
+    int sg = 0, qg = 0;                                            // global stage / chunk counters
+    __builtin_amdgcn_s_barrier();                                  // the prologue's stages have landed
+    for (int tl = 0; tl < ntile; ++tl) {
+        const int t_id = tbeg + tl * nslot;
+        const int mt = t_id / p.ntiles, nt = t_id - mt * p.ntiles;
+        const int m0 = mt * BM, co0 = nt * BN;
+        int eb[NB];
+        if (PATCH) {
+            const int n0 = m0 / HW, r0 = m0 - n0 * HW, y0 = r0 / p.Wo, x0 = r0 - y0 * p.Wo;
+            const int lo = n0 * p.IMG + y0 * p.IP + x0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int m = min(m0 + wpx + 16 * b + i, p.M - 1);
+                const int n = m / HW, r = m - n * HW, yo = r / p.Wo, xo = r - yo * p.Wo;
+                eb[b] = n * p.IMG + yo * p.IP + xo - lo;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) eb[b] = wpx + 16 * b + i;
+        }
+        f32x4 acc[NA][NB];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        auto load_frags = [&](Frag& f, int k) {                    // stage k of this tile
+            const char* wb = wring + ((sg + k) % NWR) * WST;
+            int shift = 0, q = k;
+            if (PATCH) {
+                q = k / 9;
+                const int t = k - 9 * q, dy = t / 3, dx = t - 3 * dy;
+                shift = dy * p.IP + dx;
+            }
+            const char* pb = pbuf + ((qg + q) % NPB) * PB;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                f.ah[a] = *reinterpret_cast<const float4*>(wb + aoff_h + a * 2048);
+                f.al[a] = *reinterpret_cast<const float4*>(wb + aoff_l + a * 2048);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int e = eb[b] + shift, sw = (e >> 1) & 7;
+                f.bh[b] = *reinterpret_cast<const float4*>(pb + e * 128 + ((g ^ sw) << 4));
+                f.bl[b] = *reinterpret_cast<const float4*>(pb + e * 128 + (((4 + g) ^ sw) << 4));
+            }
+        };
+        auto mfma_stage = [&](const Frag& f) {                     // small terms first, the dominant h*h product last
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = mm(f.al[a], f.bh[b], acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = mm(f.ah[a], f.bl[b], acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = mm(f.ah[a], f.bh[b], acc[a][b]);
+        };
+        auto interleave = [&]() {
+            constexpr int RD = 2 * (NA + NB), MF = 3 * NA * NB;
+            constexpr int PAIR = RD < MF ? RD : MF;
+#pragma unroll
+            for (int x = 0; x < PAIR; ++x) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (MF > PAIR) __builtin_amdgcn_sched_group_barrier(0x008, MF - PAIR, 0);
+        };
+        Frag f0, f1;
+        load_frags(f0, 0);
+        int k = 0;
+        for (; k + 2 < ST; k += 2) {
+            load_frags(f1, k + 1);
+            mfma_stage(f0);
+            interleave();
+            tile_barrier();
+            load_frags(f0, k + 2);
+            mfma_stage(f1);
+            interleave();
+            tile_barrier();
+        }
+        for (; k < ST; ++k) {
+            if (k + 1 < ST) load_frags(f1, k + 1);
+            mfma_stage(f0);
+            tile_barrier();
+            f0 = f1;
+        }
+        sg += ST;
+        qg += CH;
+        // ---- store: acc[a][b][e] of lane (i, g) = y[pixel m0 + wpx + 16 b + i][channel co0 + wco + 16 a + 4 g + e]
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int co = co0 + wco + 16 * a + 4 * g;
+            const float4 ws4 = *reinterpret_cast<const float4*>(p.wscale + co);
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int m = m0 + wpx + 16 * b + i;
+                if (m < p.M) {
+                    float4 v;
+                    v.x = __builtin_fmaf(acc[a][b][0], ws4.x * inv_up, b4.x);
+                    v.y = __builtin_fmaf(acc[a][b][1], ws4.y * inv_up, b4.y);
+                    v.z = __builtin_fmaf(acc[a][b][2], ws4.z * inv_up, b4.z);
+                    v.w = __builtin_fmaf(acc[a][b][3], ws4.w * inv_up, b4.w);
+                    const size_t o = (size_t)m * p.Cout + co;
+                    if (p.res) {
+                        const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    }
+                    if (p.relu) {   // (x < 0 ? 0 : x keeps a NaN, like torch's relu)
+                        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+                        v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                    }
+                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                    *reinterpret_cast<float4*>(p.y + o) = v;
+                }
+            }
+        }
+    }
+    if (p.amax_out) {
+        amax = wave_max(amax);
+        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(amax));
+    }
+}
+
+// max |x| over a dense fp32 array, atomically maxed into *out (as the bit pattern of a non-negative float)
+__global__ __launch_bounds__(256) void nw_absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (int64_t)gridDim.x * 256) {
+        const float4 v = x4[k];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int64_t k = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        m = fmaxf(m, fabsf(x[k]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+int num_cus() {
+    static const int v = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    return v;
+}
+
+template <int NA, int NB, int WM, bool PATCH>
+int launch_conv_cfg(ConvP p, hipStream_t st) {
+    using C = ConvCfg<NA, NB, WM, PATCH>;
+    p.mtiles = (p.M + C::BM - 1) / C::BM;
+    p.ntiles = p.Cout / C::BN;
+    const int64_t total = (int64_t)p.mtiles * p.ntiles;
+    int64_t grid = num_cus();
+    if (grid > total) grid = total;
+    grid = (grid + 7) / 8 * 8;
+    auto kern = nw_conv_nhwc_kernel<NA, NB, WM, PATCH>;
+    static const bool attr = [&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess;
+    }();
+    if (!attr) return NW_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS, st, p);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+}  // namespace
+}  // namespace nw
+
+extern "C" int nw_absmax_f32(const float* x, int64_t count, float* amax_out, void* stream) {
+    if (count < 0 || !amax_out || (count > 0 && !x)) return NW_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(x) & 15) return NW_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(amax_out, 0, sizeof(float), st) != hipSuccess) return NW_ERR_LAUNCH;
+    if (count == 0) return NW_OK;
+    int64_t blocks = (count / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nw::nw_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, count, reinterpret_cast<unsigned*>(amax_out));
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_conv2d_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                                        int64_t stride, int64_t pad) {
+    if (n <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+    if (Cin % 32 || Cout % 32 || KH > 15 || KW > 15) return 0;
+    const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    // 32-bit element offsets inside the kernels
+    if (n * H * W * Cin >= (1LL << 31) || n * Ho * Wo * Cout >= (1LL << 31) || Cout * KH * KW * Cin >= (1LL << 29)) return 0;
+    if (n * (H + pad) * (W + pad) >= (1LL << 30)) return 0;
+    return 1;
+}
+
+extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const float* w_split, const float* w_scale,
+                                    const float* bias, const float* residual, int relu, float* y, float* amax_out,
+                                    int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                                    int64_t stride, int64_t pad, void* stream) {
+    if (n < 0 || H < 0 || W < 0) return NW_ERR_INVALID_ARG;
+    if (n == 0) return NW_OK;
+    if (!nw_conv2d_nhwc_supported(n, H, W, Cin, Cout, KH, KW, stride, pad)) return NW_ERR_UNSUPPORTED;
+    if (!x || !amax_in || !w_split || !w_scale || !y) return NW_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y) |
+         reinterpret_cast<uintptr_t>(w_scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 15)
+        return NW_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    nw::ConvP p;
+    p.x = x; p.amax_in = amax_in; p.ws = reinterpret_cast<const char*>(w_split); p.wscale = w_scale; p.bias = bias;
+    p.res = residual; p.y = y; p.amax_out = reinterpret_cast<unsigned*>(amax_out);
+    p.N = (int)n; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout; p.KH = (int)KH; p.KW = (int)KW;
+    p.stride = (int)stride; p.pad = (int)pad; p.relu = relu;
+    p.Ho = (int)((H + 2 * pad - KH) / stride + 1);
+    p.Wo = (int)((W + 2 * pad - KW) / stride + 1);
+    p.IP = (int)(W + pad);
+    p.IMG = (int)((H + pad) * (W + pad));
+    p.M = (int)(n * p.Ho * p.Wo);
+    p.mtiles = p.ntiles = 0;
+    if (amax_out && hipMemsetAsync(amax_out, 0, sizeof(float), st) != hipSuccess) return NW_ERR_LAUNCH;
+    // PATCH mode: 3x3 / stride 1 / padding 1 whose patch (the tile's pixels, one raster row and one pixel on either side,
+    // the gaps of the row and image boundaries the tile crosses) fits the LDS buffer
+    const bool k33 = KH == 3 && KW == 3 && stride == 1 && pad == 1;
+    auto patch_fits = [&](int BM) {
+        const int64_t rc = (BM - 1 + W - 1) / W, ic = (BM - 1 + H * W - 1) / (H * W);
+        return BM + rc * (p.IP - W) + ic * pad * p.IP + 2 * p.IP + 2 <= BM + 192;
+    };
+    static const int force_gather = [] { const char* e = getenv("NW_CONV_GATHER"); return e && e[0] == '1'; }();
+    if (Cout % 128 == 0) {
+        if (k33 && patch_fits(128) && !force_gather) return nw::launch_conv_cfg<4, 4, 2, true>(p, st);
+        return nw::launch_conv_cfg<4, 4, 2, false>(p, st);
+    }
+    if (Cout % 64 == 0) {
+        if (k33 && patch_fits(128) && !force_gather) return nw::launch_conv_cfg<4, 2, 1, true>(p, st);
+        return nw::launch_conv_cfg<4, 2, 1, false>(p, st);
+    }
+    if (k33 && patch_fits(256) && !force_gather) return nw::launch_conv_cfg<2, 4, 1, true>(p, st);
+    return nw::launch_conv_cfg<2, 4, 1, false>(p, st);
+}

@@ -764,3 +764,77 @@ def support_influence_idx(probs, qy, w, sy):
         _lib.check(lib.nw_support_influence_f32(_ptr(probs), _ptr(qy), _ptr(w), _ptr(sy), _ptr(out), B, N, Cc,
                                                 _stream(probs)), "nw_support_influence_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Convolutions on the fp16 matrix cores at fp32-grade accuracy (csrc/conv_nhwc.hip): fp32 channels_last activations,
+# weights split once per update, activations split in flight with one power of two per tensor.
+def absmax(x):
+    """max |x| of a dense fp32 HIP tensor as a 0-d device tensor (nw_absmax_f32): the `amax` a tensor needs before it
+    can feed conv2d_nhwc when its producer did not leave one."""
+    _need_hip(x)
+    xc = x if (x.dtype == torch.float32 and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))) \
+        else x.float().contiguous()
+    out = torch.empty((), dtype=torch.float32, device=xc.device)
+    with _OnDevice(xc.device):
+        _lib.check(_lib.load().nw_absmax_f32(_ptr(xc), xc.numel(), _ptr(out), _stream(xc)), "nw_absmax_f32")
+    return out
+
+
+class SplitConvWeight:
+    """A (Cout, Cin, KH, KW) convolution weight prepared for conv2d_nhwc: its channels_last bytes are a (Cout,
+    KH*KW*Cin) matrix whose rows go through nw_split_rows_f16x2 (one power of two per output channel).  Rebuild after
+    every weight update."""
+
+    def __init__(self, w):
+        _need_hip(w)
+        cout, cin, kh, kw = w.shape
+        rows = w.detach().float().permute(0, 2, 3, 1).contiguous().view(cout, kh * kw * cin)
+        if rows.shape[1] % 32:
+            raise ValueError("conv2d_nhwc needs Cin % 32 == 0")
+        self.shape = (cout, cin, kh, kw)
+        self.split = torch.empty_like(rows)
+        self.scale = torch.empty(cout, dtype=torch.float32, device=rows.device)
+        norm2 = torch.empty(cout, dtype=torch.float32, device=rows.device)
+        with _OnDevice(rows.device):
+            _lib.check(_lib.load().nw_split_rows_f16x2(_ptr(rows), _ptr(self.split), _ptr(self.scale), _ptr(norm2),
+                                                       cout, rows.shape[1], _stream(rows)), "nw_split_rows_f16x2")
+
+
+def conv2d_nhwc_supported(x_shape, w_shape, stride, pad):
+    n, cin, h, w = x_shape
+    cout, cin2, kh, kw = w_shape
+    return cin == cin2 and bool(_lib.load().nw_conv2d_nhwc_supported(n, h, w, cin, cout, kh, kw, stride, pad))
+
+
+def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0, amax=None, want_amax=True):
+    """y = post(conv2d(x, W, stride, pad) + bias [+ residual]) for a channels_last fp32 (n, Cin, H, W) HIP tensor and a
+    SplitConvWeight; returns a channels_last (n, Cout, Ho, Wo) tensor.  `amax`: 0-d device tensor with a bound on
+    max|x| (default: x.nw_amax when x came out of this function, else one absmax pass); the result carries its own
+    in `.nw_amax` when want_amax."""
+    _need_hip(x, bias, residual)
+    lib = _lib.load()
+    n, cin, h, w = x.shape
+    cout, cin2, kh, kw = weight.shape
+    if cin != cin2:
+        raise ValueError(f"conv2d_nhwc: input has {cin} channels, the weight {cin2}")
+    if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.float().contiguous(memory_format=torch.channels_last)
+    if amax is None:
+        amax = getattr(x, "nw_amax", None)
+        if amax is None:
+            amax = absmax(x)
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and (residual.shape != y.shape or residual.dtype != torch.float32
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        residual = residual.float().expand_as(y).contiguous(memory_format=torch.channels_last)
+    am_out = torch.empty((), dtype=torch.float32, device=x.device) if want_amax else None
+    with _OnDevice(x.device):
+        _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(x), _ptr(amax), _ptr(weight.split), _ptr(weight.scale),
+                                            None if bias is None else _ptr(_f32c(bias)), _ptr(residual), int(bool(relu)),
+                                            _ptr(y), _ptr(am_out), n, h, w, cin, cout, kh, kw, int(stride), int(pad),
+                                            _stream(x)), "nw_conv2d_nhwc_f16x2")
+    if want_amax:
+        y.nw_amax = am_out
+    return y
