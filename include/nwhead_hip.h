@@ -308,16 +308,25 @@ int nw_conv1x1_f32(const float *x, int64_t x_batch_stride, const float *pre_scal
  * (conv1 1x1, conv2 3x3), :82-91 (transition 1x1); a stride-1 convolution's data gradient (train.py:414) is the same
  * call on the flipped, transposed weight.
  *     y[n, yo, xo, co] = post( bias[co] + sum_{ky,kx,ci} W[co,ky,kx,ci] x[n, s yo + ky - pad, s xo + kx - pad, ci] [+ residual] )
- *   x         (n, H, W, Cin) fp32, Cin % 32 == 0
- *   amax_in   device scalar: an upper bound on max|x| (nw_absmax_f32, or the amax_out of the call that wrote x): the
- *             activations are split into fp16 pairs on the way into LDS with ONE power of two per tensor
+ *   x         (n, H, W, Cin) fp32, Cin % 32 == 0 -- or few channels with KW * Cin <= 32 (the stems: Cin = 4 after
+ *             nw_to_nhwc_pad_f32 is the fast form); the weight is then the (Cout, KH, 32) matrix [co][ky][kx * Cin + ci],
+ *             zero-padded, through the same split
+ *   amax_in   the amax record of x: NW_AMAX_SLOTS floats whose maximum is an upper bound on max|x| (nw_absmax_f32, or the
+ *             amax_out of the call that wrote x; partial maxima per producing workgroup: no atomics, nothing to clear):
+ *             the activations are split into fp16 pairs on the way into LDS with ONE power of two per tensor
  *   w_split, w_scale   the weight as (Cout, KH*KW*Cin) rows -- the bytes of a channels_last (Cout, Cin, KH, KW) tensor --
  *             through nw_split_rows_f16x2 (its third output, the row norms, is not used); Cout % 32 == 0
  *   bias      optional (Cout,);  residual optional (n, Ho, Wo, Cout);  relu != 0: max(., 0) (NaN kept)
- *   y         (n, Ho, Wo, Cout) fp32;  amax_out optional device scalar <- max|y| (cleared by the call)
+ *   y         (n, Ho, Wo, Cout) fp32;  amax_out optional: the amax record of y (NW_AMAX_SLOTS floats, all written)
  * nw_conv2d_nhwc_supported: 1 when the shape is served (else nw_conv2d_nhwc_f16x2 returns NW_ERR_UNSUPPORTED).
  * ------------------------------------------------------------------------------------------- */
+#define NW_AMAX_SLOTS 256
 int nw_absmax_f32(const float *x, int64_t count, float *amax_out, void *stream);
+/* x (n, c, hw) fp32 with element strides (stride_n, stride_c, stride_p) -- NCHW or channels_last -- to y (n, hw, cp)
+ * channels-last with the channels c .. cp-1 zero (cp % 4 == 0), and amax_out <- max|x|: the network input as the
+ * 4-channel NHWC tensor the 7x7 stems (model/resnet.py:147, model/densenet.py:118) read pixel by aligned pixel. */
+int nw_to_nhwc_pad_f32(const float *x, float *y, float *amax_out, int64_t n, int64_t c, int64_t hw, int64_t cp,
+                       int64_t stride_n, int64_t stride_c, int64_t stride_p, void *stream);
 int nw_conv2d_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                              int64_t stride, int64_t pad);
 int nw_conv2d_nhwc_f16x2(const float *x, const float *amax_in, const float *w_split, const float *w_scale,

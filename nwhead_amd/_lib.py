@@ -55,6 +55,7 @@ SIGNATURES = {
     "nw_bn_relu_train_fwd_f32": (_int, [_p] * 10 + [_i64, _i64, _i64, _i64, C.c_float, C.c_float, _int, _p]),
     "nw_bn_relu_train_bwd_f32": (_int, [_p] * 12 + [_i64, _i64, _i64, _i64, _i64, _int, _p]),
     "nw_absmax_f32": (_int, [_p, _i64, _p, _p]),
+    "nw_to_nhwc_pad_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "nw_conv2d_nhwc_supported": (_int, [_i64] * 9),
     "nw_conv2d_nhwc_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _int, _p, _p] + [_i64] * 9 + [_p]),
     "nw_debug_tile_timing": (_int, [_int]),

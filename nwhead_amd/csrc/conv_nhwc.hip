@@ -30,31 +30,42 @@
 namespace nw {
 namespace {
 
+// what the loaders read in place of a pixel that does not exist (padding, tile tail): selecting the ADDRESS costs two
+// v_cndmask per load, selecting the data one per element
+__device__ float4 nw_conv_zeros[2];
+
 struct ConvP {
     const float* x;
-    const float* amax_in;
+    const float* amax_in;    // CV_AMAX_SLOTS floats, their maximum bounds max|x|
     const char* ws;          // split weight rows, (Cout, T * Cin) floats-worth of bytes
     const float* wscale;     // (Cout,) 2^-e of the weight rows
     const float* bias;       // nullable
     const float* res;        // nullable (M, Cout)
     float* y;
-    unsigned* amax_out;      // nullable
+    float* amax_out;         // nullable: CV_AMAX_SLOTS floats
+    const float4* zeros;     // 32 bytes of zeros (what a loader reads for a pixel that does not exist)
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
     int IP, IMG;             // virtual raster of PATCH mode: row stride W + pad, image stride (H + pad) IP
     int M, mtiles, ntiles;
 };
 
-template <int NA, int NB, int WM, bool PATCH>
+constexpr int CV_GATHER = 0, CV_PATCH = 1, CV_ROWRUN = 2, CV_ROWRUN4 = 3;
+constexpr int CV_AMAX_SLOTS = 256;   // floats of an `amax` record: one partial maximum per workgroup of its producer
+
+template <int NA, int NB, int WM, int MODE>
 struct ConvCfg {
+    static constexpr bool PATCH = MODE == CV_PATCH, ROWRUN = MODE == CV_ROWRUN || MODE == CV_ROWRUN4;
     static constexpr int WN = 4 / WM;
     static constexpr int BN = 16 * NA * WM, BM = 16 * NB * WN;
     static constexpr int NIW = BN / 32;                           // weight DMAs per loader wave per stage
     static constexpr int EMAX = PATCH ? BM + 192 : BM;            // activation entries (pixels) per buffer
     static constexpr int NPASS = EMAX / 64;
-    static constexpr int NACT = 2 * NPASS;                        // global loads per lane per chunk
+    static constexpr int NACT = (MODE == CV_ROWRUN ? 8 : 2) * NPASS;   // global loads per lane per chunk
     static constexpr int TI = PATCH ? 9 : 1;                      // stages per activation chunk
-    static constexpr int NSET = PATCH ? 1 : 2;                    // register sets of activation loads in flight
-    static constexpr int NWR = BN == 128 ? (PATCH ? 4 : 6) : 8;   // weight ring depth
+    // register sets of activation loads in flight: a one-stage chunk (GATHER) needs several to cover the memory latency
+    static constexpr int NSET = PATCH ? 1 : (MODE == CV_ROWRUN ? 2 : 4);
+    static constexpr int UNR = PATCH ? 9 : NSET;                  // the loaders' loop is unrolled over one period of their issue order
+    static constexpr int NWR = MODE == CV_ROWRUN ? 4 : (BN == 128 ? (PATCH ? 4 : 6) : 8);   // weight ring depth
     static constexpr int AH = NWR - 1;                            // weight stages issued ahead
     static constexpr int WST = BN * 128, PB = EMAX * 128;
     // activation buffers: a chunk is written two stages before its first stage; the first stage of a TILE is read at
@@ -63,21 +74,35 @@ struct ConvCfg {
     static constexpr int NPB = PATCH ? 2 : 3;
     static constexpr size_t LDS = (size_t)NWR * WST + NPB * (size_t)PB;
     static_assert(EMAX % 64 == 0 && LDS <= 160 * 1024, "tile shape");
-    static_assert(PATCH ? (9 * NIW < 64 && (AH - 2) * NIW + NACT < 64) : ((AH - 2) * (NACT + NIW) < 64), "vmcnt is a 6-bit field");
+    static_assert((AH - 2) * ((PATCH ? 0 : NACT) + NIW) + (PATCH ? NACT : 0) < 64 && 9 * NIW < 64 &&
+                  NSET * NIW + (NSET - 1) * NACT < 64, "vmcnt is a 6-bit field");
 };
 
-template <int NA, int NB, int WM, bool PATCH>
+// max of an amax record (CV_AMAX_SLOTS floats), by one wave
+__device__ __forceinline__ float amax_read(const float* rec, int lane) {
+    const float4 v = reinterpret_cast<const float4*>(rec)[lane];
+    return wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+}
+// workgroup b of g writes its maximum to slot b and zeros to the slots b + g, b + 2 g, ... it stands in for
+__device__ __forceinline__ void amax_write(float* rec, float m, int b, int g) {
+    for (int k = b; k < CV_AMAX_SLOTS; k += g) rec[k] = k == b ? m : 0.f;
+}
+
+template <int NA, int NB, int WM, int MODE>
 __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
-    using C = ConvCfg<NA, NB, WM, PATCH>;
+    using C = ConvCfg<NA, NB, WM, MODE>;
+    constexpr bool PATCH = C::PATCH, ROWRUN = C::ROWRUN;
     constexpr int BN = C::BN, BM = C::BM, NIW = C::NIW, NPASS = C::NPASS, NACT = C::NACT, TI = C::TI, NSET = C::NSET;
-    constexpr int NWR = C::NWR, AH = C::AH, WST = C::WST, PB = C::PB, NPB = C::NPB;
+    constexpr int NWR = C::NWR, AH = C::AH, WST = C::WST, PB = C::PB, NPB = C::NPB, UNR = C::UNR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wring = smem;
     char* const pbuf = smem + NWR * WST;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = p.KH * p.KW, nc = p.Cin >> 5;
+    // ROWRUN (few input channels, e.g. the 7x7 / 2 stem over RGB): the KW * Cin <= 32 values one kernel ROW reads are
+    // contiguous in NHWC memory; they are one 32-wide k chunk (zero-padded, in the weight too) and a stage is a kernel row
+    const int T = ROWRUN ? p.KH : p.KH * p.KW, nc = ROWRUN ? 1 : p.Cin >> 5;
     const int ST = nc * T;                                         // stages per tile
     const int CH = ST / TI;                                        // activation chunks per tile
     // tiles of this workgroup: every XCD (workgroups with equal id mod 8) walks a contiguous range, its workgroups
@@ -87,16 +112,18 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     const int tpx = (total + 7) >> 3;
     const int tbeg = xcd * tpx + slot, tend = min(total, (xcd + 1) * tpx);
     const int ntile = tbeg < tend ? (tend - tbeg + nslot - 1) / nslot : 0;
-    if (ntile == 0) return;
+    if (ntile == 0) {
+        if (p.amax_out && tid == 0) amax_write(p.amax_out, 0.f, blockIdx.x, gridDim.x);
+        return;
+    }
     const int S = ntile * ST;                                      // stages of this workgroup
     const int QT = ntile * CH;                                     // activation chunks of this workgroup
     const int HW = p.Ho * p.Wo;
-    const size_t wrow = (size_t)T * p.Cin * 4;                     // bytes per weight row
+    const size_t wrow = ROWRUN ? (size_t)T * 128 : (size_t)T * p.Cin * 4;   // bytes per weight row
 
     if (wave >= 4) {
         // ============================================================== loaders
         const int lw = wave - 4, lt = tid - 256, lj = lt & 3, le = lt >> 2;
-        const float up = __builtin_ldexpf(1.f, split_exponent(*p.amax_in));
         // ---- weight DMA: stage cursor
         unsigned woff[NIW];
 #pragma unroll
@@ -105,12 +132,18 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             woff[m] = (unsigned)((size_t)R * wrow) + (unsigned)(((lane & 7) ^ ((R >> 1) & 7)) << 4);
         }
         int d_tile = 0, d_k = 0, d_s = 0;                          // next stage to issue: tile index, stage in tile, global
+        // Every iteration issues the same instructions (past the end of the run: the weights' first rows into a ring
+        // slot nobody reads any more, the page of zeros for the activations), so that the order of issue is periodic
+        // and both hipcc's own waits for the register loads and the counted waits below are exact.
         auto issue_w = [&]() {
-            const int t_id = tbeg + d_tile * nslot;
-            const int nt = t_id % p.ntiles;
-            int c, t;
-            if (PATCH) { c = d_k / 9; t = d_k - 9 * c; } else { t = d_k / nc; c = d_k - t * nc; }
-            const char* base = p.ws + (size_t)(nt * BN) * wrow + ((size_t)t * p.Cin + 32 * c) * 4;
+            const char* base = p.ws;
+            if (d_s < S) {
+                const int t_id = tbeg + d_tile * nslot;
+                const int nt = t_id % p.ntiles;
+                int c, t;
+                if (PATCH) { c = d_k / 9; t = d_k - 9 * c; } else { t = d_k / nc; c = d_k - t * nc; }
+                base = p.ws + (size_t)(nt * BN) * wrow + (ROWRUN ? (size_t)t * 128 : ((size_t)t * p.Cin + 32 * c) * 4);
+            }
             char* dst = wring + (d_s % NWR) * WST;
 #pragma unroll
             for (int m = 0; m < NIW; ++m)
@@ -151,116 +184,162 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 }
             }
         };
+        int rdx[8];                                                // ROWRUN: k -> pixel of the run (k / Cin), far negative past the run
+        if (MODE == CV_ROWRUN) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * lj + j;
+                rdx[j] = k < p.KW * p.Cin ? k / p.Cin : -(1 << 20);
+            }
+        }
+        // a pixel's address, or the page of zeros: selected as INTEGERS (two v_cndmask; given the pointers, hipcc turns the
+        // select into a branch around two loads and then waits for everything in flight at the join)
+        const uintptr_t zpage = reinterpret_cast<uintptr_t>(p.zeros);
+        auto pick = [&](bool ok, const void* ptr) {
+            return reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(ptr) : zpage);
+        };
+        // (the activation loads are plain loads: hipcc's own waits order them against the conversions that read their
+        //  registers; with the LDS stores of write_a out of its sight those waits come out counted, not vmcnt(0))
+        auto ldg2 = [](float4& a, float4& b, const float4* src) { a = src[0]; b = src[1]; };
+        auto ldg1 = [](float4& a, const float4* src) { a = src[0]; };
         float4 ld[NSET][NPASS][2];
         unsigned ldvalid[NSET];
         auto issue_a = [&](float4 (&L)[NPASS][2], unsigned& valid) {   // loads of the cursor's chunk
-            if (a_q == 0) setup_tile();
+            const bool live = a_g < QT;
+            if (live && a_q == 0) setup_tile();
+            valid = 0xffffffffu;
             if (PATCH) {
                 const float* base = p.x + 32 * a_q;
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q) {
-                    const float4* src = reinterpret_cast<const float4*>(base + aoff[q]);
-                    L[q][0] = src[0];
-                    L[q][1] = src[1];
+                    ldg2(L[q][0], L[q][1], pick(live && ((avalid >> q) & 1), base + aoff[q]));
                 }
-                valid = avalid;
+            } else if (MODE == CV_ROWRUN4) {                       // Cin == 4: a pixel is one aligned float4, two pixels per lane
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const int yi = gy[q] + a_q;
+                    const bool rowok = live && gn[q] >= 0 && yi >= 0 && yi < p.H;
+                    const int x0 = gx[q] + 2 * lj, x1 = x0 + 1;
+                    const bool ok0 = rowok && 2 * lj < p.KW && (unsigned)x0 < (unsigned)p.W;
+                    const bool ok1 = rowok && 2 * lj + 1 < p.KW && (unsigned)x1 < (unsigned)p.W;
+                    const float4* row = reinterpret_cast<const float4*>(p.x) + (gn[q] + yi) * p.W;
+                    ldg1(L[q][0], pick(ok0, row + x0));
+                    ldg1(L[q][1], pick(ok1, row + x1));
+                }
+            } else if (MODE == CV_ROWRUN) {
+                valid = 0;                                         // bit 8 q + j: element j of pass q is a real value
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const int yi = gy[q] + a_q;
+                    const bool rowok = live && gn[q] >= 0 && yi >= 0 && yi < p.H;
+                    const int base = ((gn[q] + yi) * p.W + gx[q]) * p.Cin + 8 * lj;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool ok = rowok && (unsigned)(gx[q] + rdx[j]) < (unsigned)p.W;
+                        v[j] = p.x[ok ? base + j : 0];
+                        valid |= ok ? (1u << (8 * q + j)) : 0u;
+                    }
+                    L[q][0] = make_float4(v[0], v[1], v[2], v[3]);
+                    L[q][1] = make_float4(v[4], v[5], v[6], v[7]);
+                }
             } else {
                 const int t = a_q / nc, c = a_q - t * nc, dy = t / p.KW, dx = t - dy * p.KW;
-                valid = 0;
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q) {
                     const int yi = gy[q] + dy, xi = gx[q] + dx;
-                    const bool ok = gn[q] >= 0 && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
-                    const unsigned off = ok ? (unsigned)(((gn[q] + yi) * p.W + xi) * p.Cin + 32 * c + 8 * lj) : 0u;
-                    const float4* src = reinterpret_cast<const float4*>(p.x + off);
-                    L[q][0] = src[0];
-                    L[q][1] = src[1];
-                    valid |= ok ? (1u << q) : 0u;
+                    const bool ok = live && gn[q] >= 0 && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+                    const unsigned off = (unsigned)(((gn[q] + yi) * p.W + xi) * p.Cin + 32 * c + 8 * lj);
+                    ldg2(L[q][0], L[q][1], pick(ok, p.x + off));
                 }
             }
-            ++a_g;
-            if (++a_q == CH) { a_q = 0; ++a_tile; }
+            if (live) {
+                ++a_g;
+                if (++a_q == CH) { a_q = 0; ++a_tile; }
+            }
         };
+        // the tensor's scale: one power of two from the bound its producer left (read behind the first loads)
+        float up = 1.f;
         auto write_a = [&](const float4 (&L)[NPASS][2], unsigned valid, int g) {   // a loaded chunk -> split -> buffer g % NPB
             char* pb = pbuf + (g % NPB) * PB;
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) {
-                const bool ok = (valid >> q) & 1;
                 const float xs[8] = {L[q][0].x, L[q][0].y, L[q][0].z, L[q][0].w, L[q][1].x, L[q][1].y, L[q][1].z, L[q][1].w};
-                half8 h, l;
+                float xv[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float v = ok ? xs[k] * up : 0.f;
-                    h[k] = (_Float16)v;
-                    l[k] = (_Float16)(v - (float)h[k]);
-                }
+                for (int k = 0; k < 8; ++k) xv[k] = (MODE == CV_ROWRUN && !((valid >> (8 * q + k)) & 1)) ? 0.f : xs[k];
+                // h = fp16(2^e x), l = fp16(2^e x - h): two mixed-precision FMAs per element, written by hand (hipcc
+                // builds three quarters of them from packed fp32 FMAs and conversions: 22 instructions for these 16).
+                // A half-register write is followed by a read of that register no sooner than two instructions later
+                // (gfx950's destination-select forwarding hazard; hipcc pads nothing inside an asm statement).
+                unsigned hh[4], ll[4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    asm volatile(
+                        "v_fma_mixlo_f16 %0, %4, %8, 0\n"
+                        "v_fma_mixlo_f16 %1, %6, %8, 0\n"
+                        "v_fma_mixhi_f16 %0, %5, %8, 0\n"
+                        "v_fma_mixhi_f16 %1, %7, %8, 0\n"
+                        "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n"
+                        "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n"
+                        "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+                        "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+                        "s_nop 0"
+                        : "=&v"(hh[2 * u]), "=&v"(hh[2 * u + 1]), "=&v"(ll[2 * u]), "=&v"(ll[2 * u + 1])
+                        : "v"(xv[4 * u]), "v"(xv[4 * u + 1]), "v"(xv[4 * u + 2]), "v"(xv[4 * u + 3]), "v"(up));
                 const int e = le + 64 * q, sw = (e >> 1) & 7;
-                *reinterpret_cast<half8*>(pb + e * 128 + ((lj ^ sw) << 4)) = h;
-                *reinterpret_cast<half8*>(pb + e * 128 + (((4 + lj) ^ sw) << 4)) = l;
+                // the LDS stores by hand too: a wave with LDS-DMAs in flight gets an s_waitcnt vmcnt(0) from hipcc in front
+                // of every LDS access it can see (it cannot tell the DMA's target from this buffer)
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 hv = {hh[0], hh[1], hh[2], hh[3]}, lv = {ll[0], ll[1], ll[2], ll[3]};
+                typedef __attribute__((address_space(3))) char lds_char;
+                const unsigned ah_ = (unsigned)(uintptr_t)(lds_char*)(pb + e * 128 + ((lj ^ sw) << 4));
+                const unsigned al_ = (unsigned)(uintptr_t)(lds_char*)(pb + e * 128 + (((4 + lj) ^ sw) << 4));
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %2, %3" ::"v"(ah_), "v"(hv), "v"(al_), "v"(lv) : "memory");
             }
         };
-        // Chunk g is WRITTEN in iteration TI g - 2 (its buffer was last read for stage TI (g - 1) - 1, whose reads
-        // are complete at barrier TI (g - 1) - 2) and its loads are ISSUED NSET chunks earlier, right after the write
-        // that frees their registers.  Weights of stage s + AH are issued in iteration s; stage s + 2 (activations and
-        // weights) is complete at barrier s.  In the steady state the order of issue is periodic, so the counted waits
-        // are constants; at the two ends of the run (first iterations, and once one of the cursors has run out)
-        // everything is waited for.
-        // ---- prologue: chunks written before the first barrier (stages 0 and 1), loads of the following NSET chunks
-        //      and the weights of stages 0 .. AH - 1 in flight
-        issue_a(ld[0], ldvalid[0]);
-        wait_vmcnt<0>();
-        write_a(ld[0], ldvalid[0], 0);
-        int w_g = 1;                                               // next chunk to write
-        if (TI == 1 && QT > 1) {
-            issue_a(ld[0], ldvalid[0]);
-            wait_vmcnt<0>();
-            write_a(ld[0], ldvalid[0], 1);
-            w_g = 2;
-        }
+        // Iteration s (from -2; a barrier closes it from -1 on, the first one releases the consumers):
+        //   A  the chunk whose first stage is s + 2 goes to LDS (its buffer was last read for a stage whose reads are
+        //      complete at barrier s - 1) and the loads of the chunk NSET further on are issued into the registers it
+        //      leaves;  B  the weights of stage s + AH are issued;  C  stage s + 2's weights have landed: all but the
+        //      DMAs (and loads) issued after them, a constant in the periodic order.
 #pragma unroll
-        for (int u = 0; u < NSET; ++u)
-            if (a_g < QT) issue_a(ld[u], ldvalid[u]);   // (chunk w_g + u goes to set (w_g + u) % NSET = u: w_g % NSET == 0)
+        for (int u = 0; u < NSET; ++u) issue_a(ld[u], ldvalid[u]);     // chunks 0 .. NSET - 1
 #pragma unroll
-        for (int s = 0; s < AH; ++s)
-            if (d_s < S) issue_w();
-        wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // (the activation loads issued above were waited for: the first write of the loop finds them landed)
-        int since_a = 1 << 20;                                     // iterations since activation loads were last issued
-        int steady = 0;                                            // iterations run in the periodic order
-        for (int s = 0; s < S; ++s) {
-            const bool regular = steady >= (PATCH ? 9 + AH : AH + NSET + 1) && d_s < S && (PATCH || a_g < QT);
-            bool issued = false;
-            // A: the chunk whose first stage is s + 2
-            if (s + 2 < S && (s + 2) % TI == 0) {
-                const int g = w_g;                                 // == (s + 2) / TI
-                if (!regular) wait_vmcnt<0>();
-                else if constexpr (PATCH) wait_vmcnt<9 * NIW>();   // its loads are older than nine stages of weights
-                else wait_vmcnt<NSET * NIW + (NSET - 1) * NACT>(); // ... than NSET stages of weights, NSET - 1 chunks
-                if (NSET == 1 || (g % NSET) == 0) {
-                    write_a(ld[0], ldvalid[0], g);
-                    if (a_g < QT) { issue_a(ld[0], ldvalid[0]); issued = true; }
-                } else {
-                    write_a(ld[NSET - 1], ldvalid[NSET - 1], g);
-                    if (a_g < QT) { issue_a(ld[NSET - 1], ldvalid[NSET - 1]); issued = true; }
+        for (int k = 0; k < AH - 2; ++k) issue_w();                    // stages 0 .. AH - 3
+        up = __builtin_ldexpf(1.f, split_exponent(amax_read(p.amax_in, lane)));
+        int w_g = 0;                                                   // next chunk to write
+        for (int s = -2; s < S; s += UNR) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int si = s + u;
+                if (si >= S) break;
+                if (!PATCH || u == 0) {
+                    constexpr int SET_MASK = NSET - 1;
+                    float4 (&L)[NPASS][2] = ld[PATCH ? 0 : (u & SET_MASK)];
+                    unsigned& V = ldvalid[PATCH ? 0 : (u & SET_MASK)];
+                    // the chunk's loads have landed: all but what was issued after them
+                    if (si < (PATCH ? 9 : NSET) + AH) wait_vmcnt<0>();
+                    else if constexpr (PATCH) wait_vmcnt<9 * NIW>();
+                    else wait_vmcnt<NSET * NIW + (NSET - 1) * NACT>();
+                    if (w_g < QT) write_a(L, V, w_g);
+                    ++w_g;
+                    issue_a(L, V);
                 }
-                ++w_g;
+                issue_w();
+                if (si < AH) wait_vmcnt<0>();
+                else if constexpr (PATCH) {
+                    if (u <= AH - 3) wait_vmcnt<(AH - 2) * NIW + NACT>();   // this period's chunk loads are younger too
+                    else wait_vmcnt<(AH - 2) * NIW>();
+                } else {
+                    wait_vmcnt<(AH - 2) * (NACT + NIW)>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (si >= -1) __builtin_amdgcn_s_barrier();
             }
-            // B: weights AH stages ahead
-            if (d_s < S) issue_w();
-            // C: stage s + 2 has landed: all but the weight stages (and activation chunks) issued after it
-            since_a = issued ? 0 : since_a + 1;
-            if (!regular) wait_vmcnt<0>();
-            else if constexpr (!PATCH) wait_vmcnt<(AH - 2) * (NACT + NIW)>();
-            else {
-                if (since_a < AH - 2) wait_vmcnt<(AH - 2) * NIW + NACT>();
-                else wait_vmcnt<(AH - 2) * NIW>();
-            }
-            ++steady;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
         }
+        wait_vmcnt<0>();                                               // (the dummy tail of the issue order)
+        __builtin_amdgcn_s_barrier();                                  // the consumers have parked their maxima
         return;
     }
 
@@ -269,7 +348,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     const int wco = (wave % WM) * (16 * NA), wpx = (wave / WM) * (16 * NB);
     const int asw = (i >> 1) & 7;
     const int aoff_h = (wco + i) * 128 + ((g ^ asw) << 4), aoff_l = (wco + i) * 128 + (((4 + g) ^ asw) << 4);
-    const float inv_up = __builtin_ldexpf(1.f, -split_exponent(*p.amax_in));
+    const float inv_up = __builtin_ldexpf(1.f, -split_exponent(amax_read(p.amax_in, lane)));
     struct Frag {
         float4 ah[NA], al[NA], bh[NB], bl[NB];
     };
@@ -400,14 +479,19 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             }
         }
     }
-    if (p.amax_out) {
-        amax = wave_max(amax);
-        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(amax));
-    }
+    // this workgroup's maximum -> its slot of the output's amax record (no atomics, nothing to clear beforehand)
+    amax = wave_max(amax);
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) red[wave] = amax;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (p.amax_out && tid == 0)
+        amax_write(p.amax_out, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), blockIdx.x, gridDim.x);
 }
 
-// max |x| over a dense fp32 array, atomically maxed into *out (as the bit pattern of a non-negative float)
-__global__ __launch_bounds__(256) void nw_absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+// max |x| over a dense fp32 array as an amax record: block b's maximum in slot b
+__global__ __launch_bounds__(256) void nw_absmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float red[8];
     float m = 0.f;
     const int64_t n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -417,8 +501,45 @@ __global__ __launch_bounds__(256) void nw_absmax_kernel(const float* __restrict_
     }
     for (int64_t k = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
         m = fmaxf(m, fabsf(x[k]));
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    m = block_max(m, red);
+    if (threadIdx.x == 0) amax_write(out, m, blockIdx.x, gridDim.x);
+}
+
+// (n, c, hw) fp32 with strides (sn, sc, sp) -> (n, hw, cp) channels-last with channels c .. cp-1 zero, and max |x|:
+// the network input (NCHW from the loader, or channels_last) becomes the 4-channel NHWC tensor the stem reads
+__global__ __launch_bounds__(256) void nw_to_nhwc_pad_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              float* __restrict__ amax, int64_t npix, int c, int hw,
+                                                              int cp, int64_t sn, int64_t sc, int64_t sp) {
+    __shared__ float red[8];
+    float m = 0.f;
+    for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * 256) {
+        const int64_t n = pix / hw, p = pix - n * hw;
+        const float* src = x + n * sn + p * sp;
+        float* dst = y + pix * cp;
+        for (int c0 = 0; c0 < cp; c0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = c0 + j < c ? src[(c0 + j) * sc] : 0.f;
+                m = fmaxf(m, fabsf(v[j]));
+            }
+            *reinterpret_cast<float4*>(dst + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) amax_write(amax, m, blockIdx.x, gridDim.x);
+}
+
+const float4* zero_page() {   // device address of nw_conv_zeros on the current device
+    static const float4* cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!cache[dev]) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(nw_conv_zeros)) != hipSuccess) return nullptr;
+        cache[dev] = static_cast<const float4*>(ptr);
+    }
+    return cache[dev];
 }
 
 int num_cus() {
@@ -431,16 +552,18 @@ int num_cus() {
     return v;
 }
 
-template <int NA, int NB, int WM, bool PATCH>
+template <int NA, int NB, int WM, int MODE>
 int launch_conv_cfg(ConvP p, hipStream_t st) {
-    using C = ConvCfg<NA, NB, WM, PATCH>;
+    using C = ConvCfg<NA, NB, WM, MODE>;
     p.mtiles = (p.M + C::BM - 1) / C::BM;
     p.ntiles = p.Cout / C::BN;
     const int64_t total = (int64_t)p.mtiles * p.ntiles;
-    int64_t grid = num_cus();
+    int64_t grid = num_cus() < CV_AMAX_SLOTS ? num_cus() : CV_AMAX_SLOTS;
+    static const int cap = [] { const char* e = getenv("NW_CONV_MAX_WGS"); return e ? atoi(e) : 0; }();   // tests: many tiles per workgroup
+    if (cap > 0 && grid > cap) grid = cap;
     if (grid > total) grid = total;
     grid = (grid + 7) / 8 * 8;
-    auto kern = nw_conv_nhwc_kernel<NA, NB, WM, PATCH>;
+    auto kern = nw_conv_nhwc_kernel<NA, NB, WM, MODE>;
     static const bool attr = [&] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess;
     }();
@@ -455,14 +578,26 @@ int launch_conv_cfg(ConvP p, hipStream_t st) {
 
 extern "C" int nw_absmax_f32(const float* x, int64_t count, float* amax_out, void* stream) {
     if (count < 0 || !amax_out || (count > 0 && !x)) return NW_ERR_INVALID_ARG;
-    if (reinterpret_cast<uintptr_t>(x) & 15) return NW_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(amax_out)) & 15) return NW_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(amax_out, 0, sizeof(float), st) != hipSuccess) return NW_ERR_LAUNCH;
-    if (count == 0) return NW_OK;
     int64_t blocks = (count / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > nw::CV_AMAX_SLOTS) blocks = nw::CV_AMAX_SLOTS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(nw::nw_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, count, reinterpret_cast<unsigned*>(amax_out));
+    hipLaunchKernelGGL(nw::nw_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, count, amax_out);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_to_nhwc_pad_f32(const float* x, float* y, float* amax_out, int64_t n, int64_t c, int64_t hw, int64_t cp,
+                                  int64_t stride_n, int64_t stride_c, int64_t stride_p, void* stream) {
+    if (n < 0 || c <= 0 || hw < 0 || cp < c || cp % 4 || !amax_out) return NW_ERR_INVALID_ARG;
+    if ((n * hw > 0 && (!x || !y)) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(amax_out)) & 15)) return NW_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int64_t blocks = (n * hw + 255) / 256;
+    if (blocks > nw::CV_AMAX_SLOTS) blocks = nw::CV_AMAX_SLOTS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nw::nw_to_nhwc_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, amax_out, n * hw, (int)c,
+                       (int)hw, (int)cp, stride_n, stride_c, stride_p);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }
@@ -470,7 +605,8 @@ extern "C" int nw_absmax_f32(const float* x, int64_t count, float* amax_out, voi
 extern "C" int nw_conv2d_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                                         int64_t stride, int64_t pad) {
     if (n <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
-    if (Cin % 32 || Cout % 32 || KH > 15 || KW > 15) return 0;
+    if (Cout % 32 || KH > 15 || KW > 15) return 0;
+    if (Cin % 32 && Cin * KW > 32) return 0;   // (few input channels: one kernel row = one 32-wide k chunk)
     const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return 0;
     // 32-bit element offsets inside the kernels
@@ -488,12 +624,15 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
     if (!nw_conv2d_nhwc_supported(n, H, W, Cin, Cout, KH, KW, stride, pad)) return NW_ERR_UNSUPPORTED;
     if (!x || !amax_in || !w_split || !w_scale || !y) return NW_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y) |
-         reinterpret_cast<uintptr_t>(w_scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 15)
+         reinterpret_cast<uintptr_t>(w_scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) |
+         reinterpret_cast<uintptr_t>(amax_in) | reinterpret_cast<uintptr_t>(amax_out)) & 15)
         return NW_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     nw::ConvP p;
     p.x = x; p.amax_in = amax_in; p.ws = reinterpret_cast<const char*>(w_split); p.wscale = w_scale; p.bias = bias;
-    p.res = residual; p.y = y; p.amax_out = reinterpret_cast<unsigned*>(amax_out);
+    p.res = residual; p.y = y; p.amax_out = amax_out;
+    p.zeros = nw::zero_page();
+    if (!p.zeros) return NW_ERR_LAUNCH;
     p.N = (int)n; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout; p.KH = (int)KH; p.KW = (int)KW;
     p.stride = (int)stride; p.pad = (int)pad; p.relu = relu;
     p.Ho = (int)((H + 2 * pad - KH) / stride + 1);
@@ -502,7 +641,6 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
     p.IMG = (int)((H + pad) * (W + pad));
     p.M = (int)(n * p.Ho * p.Wo);
     p.mtiles = p.ntiles = 0;
-    if (amax_out && hipMemsetAsync(amax_out, 0, sizeof(float), st) != hipSuccess) return NW_ERR_LAUNCH;
     // PATCH mode: 3x3 / stride 1 / padding 1 whose patch (the tile's pixels, one raster row and one pixel on either side,
     // the gaps of the row and image boundaries the tile crosses) fits the LDS buffer
     const bool k33 = KH == 3 && KW == 3 && stride == 1 && pad == 1;
@@ -511,14 +649,24 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
         return BM + rc * (p.IP - W) + ic * pad * p.IP + 2 * p.IP + 2 <= BM + 192;
     };
     static const int force_gather = [] { const char* e = getenv("NW_CONV_GATHER"); return e && e[0] == '1'; }();
-    if (Cout % 128 == 0) {
-        if (k33 && patch_fits(128) && !force_gather) return nw::launch_conv_cfg<4, 4, 2, true>(p, st);
-        return nw::launch_conv_cfg<4, 4, 2, false>(p, st);
+    if (Cin % 32) {   // ROWRUN: w_split is the split form of the (Cout, KH, 32) matrix [co][ky][kx * Cin + ci], zero-padded
+        if (Cin == 4 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+            if (Cout % 64 == 0) return nw::launch_conv_cfg<4, 2, 1, nw::CV_ROWRUN4>(p, st);
+            return nw::launch_conv_cfg<2, 4, 1, nw::CV_ROWRUN4>(p, st);
+        }
+        if (Cout % 64 == 0) return nw::launch_conv_cfg<4, 2, 1, nw::CV_ROWRUN>(p, st);
+        return nw::launch_conv_cfg<2, 4, 1, nw::CV_ROWRUN>(p, st);
+    }
+    // 128-channel tiles unless they would leave a quarter of the chip idle (7x7 planes: 25 pixel tiles)
+    const int64_t tiles128 = ((int64_t)p.M + 127) / 128 * (Cout / 128);
+    if (Cout % 128 == 0 && tiles128 * 4 >= (int64_t)nw::num_cus() * 3) {
+        if (k33 && patch_fits(128) && !force_gather) return nw::launch_conv_cfg<4, 4, 2, nw::CV_PATCH>(p, st);
+        return nw::launch_conv_cfg<4, 4, 2, nw::CV_GATHER>(p, st);
     }
     if (Cout % 64 == 0) {
-        if (k33 && patch_fits(128) && !force_gather) return nw::launch_conv_cfg<4, 2, 1, true>(p, st);
-        return nw::launch_conv_cfg<4, 2, 1, false>(p, st);
+        if (k33 && patch_fits(128) && !force_gather) return nw::launch_conv_cfg<4, 2, 1, nw::CV_PATCH>(p, st);
+        return nw::launch_conv_cfg<4, 2, 1, nw::CV_GATHER>(p, st);
     }
-    if (k33 && patch_fits(256) && !force_gather) return nw::launch_conv_cfg<2, 4, 1, true>(p, st);
-    return nw::launch_conv_cfg<2, 4, 1, false>(p, st);
+    if (k33 && patch_fits(256) && !force_gather) return nw::launch_conv_cfg<2, 4, 1, nw::CV_PATCH>(p, st);
+    return nw::launch_conv_cfg<2, 4, 1, nw::CV_GATHER>(p, st);
 }

@@ -113,7 +113,10 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         if isinstance(self.conv1, ConvBiasAct):      # folded inference copy
-            x = self.maxpool(self.conv1(x, relu=True))
+            y = self.conv1(x, relu=True)
+            x = self.maxpool(y)
+            if hasattr(y, "nw_amax"):               # a bound on max|.| survives the pooling: the next convolution needs it
+                x.nw_amax = y.nw_amax
         else:
             x = self.maxpool(_bn_relu(self.bn1, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
@@ -134,6 +137,9 @@ FUSED_CONV3X3 = _os.environ.get("NW_OWN_CONV3X3", "1") != "0"
 # bias, the identity and the ReLU in its store (NCHW; the stem, the strided convolutions and the 1x1 projections stay on
 # MIOpen).  Measured against the channels_last MIOpen path (tools/fold_time.py): see DESIGN.md 4.7e; NW_RESNET_OWN_CONV3X3.
 FUSED_RESNET_CONV3X3 = _os.environ.get("NW_RESNET_OWN_CONV3X3", "0") == "1"
+# Folded channels_last copies (the ResNets): every convolution through ops.conv2d_nhwc (csrc/conv_nhwc.hip: implicit GEMM on
+# the fp16 matrix cores with split-fp16 operands, bias / identity / ReLU in its store).  NW_CONV_NHWC=0: MIOpen + the bias pass.
+FUSED_CONV_NHWC = _os.environ.get("NW_CONV_NHWC", "1") != "0"
 FUSED_CONV1X1 = True            # folded inference copies: 1x1 convolutions with their BatchNorm / ReLU neighbours as one kernel (Conv1x1Fused)
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
 
@@ -561,8 +567,24 @@ class ConvBiasAct(nn.Conv2d):
     and the ReLU are ONE in-place pass behind a bias-free convolution (ops.bias_act_nhwc_) instead of MIOpen's bias kernel
     + add + relu; everywhere else the torch ops of the reference backbone.  Inference only."""
 
+    def _split_weight(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if getattr(self, "_nw_split_key", None) != key:
+            from .. import ops
+            self._nw_split, self._nw_split_key = ops.SplitConvWeight(w), key
+        return self._nw_split
+
     def forward(self, x, residual=None, relu=False):
         c = self.out_channels
+        if (FUSED_CONV_NHWC and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_grad_enabled()
+                and self.groups == 1 and self.dilation == (1, 1) and self.padding[0] == self.padding[1]
+                and self.stride[0] == self.stride[1] and isinstance(self.padding[0], int)
+                and (x.is_contiguous(memory_format=torch.channels_last) or x.shape[1] == 3)):
+            from .. import ops
+            if ops.conv2d_nhwc_supported(x.shape, self.weight.shape, self.stride[0], self.padding[0]):
+                # the whole conv -> bias -> (+ identity) -> ReLU on the fp16 matrix cores at fp32-grade accuracy
+                return ops.conv2d_nhwc(x, self._split_weight(), self.bias, residual, relu, self.stride[0], self.padding[0])
         if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and c % 4 == 0 and self.bias is not None
                 and not torch.is_grad_enabled() and x.is_contiguous(memory_format=torch.channels_last)
                 and not x.is_contiguous()):

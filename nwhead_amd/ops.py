@@ -769,16 +769,35 @@ def support_influence_idx(probs, qy, w, sy):
 # ------------------------------------------------------------------------------------------------------------------
 # Convolutions on the fp16 matrix cores at fp32-grade accuracy (csrc/conv_nhwc.hip): fp32 channels_last activations,
 # weights split once per update, activations split in flight with one power of two per tensor.
+AMAX_SLOTS = 256    # floats of an `amax` record: per-workgroup partial maxima of its producer (their max bounds max|x|)
+
+
 def absmax(x):
-    """max |x| of a dense fp32 HIP tensor as a 0-d device tensor (nw_absmax_f32): the `amax` a tensor needs before it
-    can feed conv2d_nhwc when its producer did not leave one."""
+    """A bound on max |x| of a dense fp32 HIP tensor as an amax record -- AMAX_SLOTS partial maxima, no atomics, nothing to
+    clear -- (nw_absmax_f32): what a tensor needs before it can feed conv2d_nhwc when its producer did not leave one."""
     _need_hip(x)
     xc = x if (x.dtype == torch.float32 and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))) \
         else x.float().contiguous()
-    out = torch.empty((), dtype=torch.float32, device=xc.device)
+    out = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=xc.device)
     with _OnDevice(xc.device):
         _lib.check(_lib.load().nw_absmax_f32(_ptr(xc), xc.numel(), _ptr(out), _stream(xc)), "nw_absmax_f32")
     return out
+
+
+def to_nhwc_pad(x, cpad=4):
+    """(n, c, h, w) fp32 HIP tensor, NCHW-contiguous or channels_last -> (n, cpad, h, w) channels_last with zero channels
+    behind the c real ones, carrying `.nw_amax` (one pass: nw_to_nhwc_pad_f32).  What the stem convolution reads."""
+    _need_hip(x)
+    n, c, h, w = x.shape
+    if x.dtype != torch.float32 or not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+        x = x.float().contiguous()
+    y = torch.empty((n, cpad, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    am = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=x.device)
+    with _OnDevice(x.device):
+        _lib.check(_lib.load().nw_to_nhwc_pad_f32(_ptr(x), _ptr(y), _ptr(am), n, c, h * w, cpad, c * h * w, x.stride(1),
+                                                  x.stride(3), _stream(x)), "nw_to_nhwc_pad_f32")
+    y.nw_amax = am
+    return y
 
 
 class SplitConvWeight:
@@ -789,9 +808,17 @@ class SplitConvWeight:
     def __init__(self, w):
         _need_hip(w)
         cout, cin, kh, kw = w.shape
-        rows = w.detach().float().permute(0, 2, 3, 1).contiguous().view(cout, kh * kw * cin)
-        if rows.shape[1] % 32:
-            raise ValueError("conv2d_nhwc needs Cin % 32 == 0")
+        if cin == 3 and kw <= 8:        # RGB stems run on a 4-channel input (to_nhwc_pad): a pixel is one aligned float4
+            w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 1))
+            cin = 4
+        rows = w.detach().float().permute(0, 2, 3, 1).contiguous()          # (cout, kh, kw, cin)
+        if cin % 32 == 0:
+            rows = rows.view(cout, kh * kw * cin)
+        elif kw * cin <= 32:
+            # few input channels (the 7x7 stem over RGB): one kernel ROW is one 32-wide k chunk, zero-padded
+            rows = torch.nn.functional.pad(rows.view(cout, kh, kw * cin), (0, 32 - kw * cin)).reshape(cout, kh * 32)
+        else:
+            raise ValueError("conv2d_nhwc needs Cin % 32 == 0 (or KW * Cin <= 32)")
         self.shape = (cout, cin, kh, kw)
         self.split = torch.empty_like(rows)
         self.scale = torch.empty(cout, dtype=torch.float32, device=rows.device)
@@ -809,13 +836,16 @@ def conv2d_nhwc_supported(x_shape, w_shape, stride, pad):
 
 def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0, amax=None, want_amax=True):
     """y = post(conv2d(x, W, stride, pad) + bias [+ residual]) for a channels_last fp32 (n, Cin, H, W) HIP tensor and a
-    SplitConvWeight; returns a channels_last (n, Cout, Ho, Wo) tensor.  `amax`: 0-d device tensor with a bound on
-    max|x| (default: x.nw_amax when x came out of this function, else one absmax pass); the result carries its own
-    in `.nw_amax` when want_amax."""
+    SplitConvWeight; returns a channels_last (n, Cout, Ho, Wo) tensor.  `amax`: the amax record of x (AMAX_SLOTS floats
+    whose maximum bounds max|x|; default: x.nw_amax when x came out of this function, else one absmax pass); the result
+    carries its own in `.nw_amax` when want_amax."""
     _need_hip(x, bias, residual)
     lib = _lib.load()
     n, cin, h, w = x.shape
     cout, cin2, kh, kw = weight.shape
+    if cin == 3 and cin2 == 4:          # an RGB stem: SplitConvWeight padded its weight, the input follows (one pass, with amax)
+        x = to_nhwc_pad(x, 4)
+        cin = 4
     if cin != cin2:
         raise ValueError(f"conv2d_nhwc: input has {cin} channels, the weight {cin2}")
     if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
@@ -829,7 +859,7 @@ def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0
     if residual is not None and (residual.shape != y.shape or residual.dtype != torch.float32
                                  or not residual.is_contiguous(memory_format=torch.channels_last)):
         residual = residual.float().expand_as(y).contiguous(memory_format=torch.channels_last)
-    am_out = torch.empty((), dtype=torch.float32, device=x.device) if want_amax else None
+    am_out = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=x.device) if want_amax else None
     with _OnDevice(x.device):
         _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(x), _ptr(amax), _ptr(weight.split), _ptr(weight.scale),
                                             None if bias is None else _ptr(_f32c(bias)), _ptr(residual), int(bool(relu)),
