@@ -173,7 +173,9 @@ int nw_bwd_f32(const float *q, const float *s, const int64_t *sy,
  * shared supports, d % 32 == 0, a row of N coefficients fits in LDS -- the two products of the backward
  * (gq = A s + 2 rq q, gs = A^T q + 2 rs s) run on the fp16 matrix cores with split-row operands like the forward
  * (three fp16 MFMAs per fp32 multiply-add, fp32 accumulation); without a bank the rows are split inside the call.
- * A training step builds the bank once, hands it to nw_fwd_f32 (scores saved for the backward) and to this call. */
+ * A training step builds the bank once, hands it to nw_fwd_f32 (scores saved for the backward) and to this call.
+ * The caller's s_split (exactly N * d floats, no tail required) is used when d % 64 == 0; for d % 64 == 32 the rows
+ * are split again into the workspace, whose copy carries the tail the product kernel's last column tile reads. */
 int nw_bwd_uses_split(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched);
 int nw_bwd_bank_f32(const float *q, const float *s, const float *s_norm2, const float *s_split,
                     const float *s_scale, const int64_t *sy,

@@ -685,7 +685,9 @@ extern "C" int nw_bwd_bank_f32(const float* q, const float* s, const float* s_no
 
     const bool norms = (kind == NW_SCORE_HYPERSPHERE || kind == NW_SCORE_COSINE || kind == NW_SCORE_CLIP);
     if (norms) hipLaunchKernelGGL(nw_rownorm_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, q, ws.qn2, B, d);
-    if (ws.split && s_split) {   // the forward's bank: split rows, scales and norms of these very supports
+    // The caller's bank is the Y operand of a 64-column tile kernel that reads a clamped last row to the end of its
+    // tile: only a row length that is a multiple of 64 keeps it inside N * d floats (the workspace copy has a tail)
+    if (ws.split && s_split && d % 64 == 0) {   // the forward's bank: split rows, scales and norms of these very supports
         ws.s_split = const_cast<float*>(s_split);
         ws.s_scale = const_cast<float*>(s_scale);
         ws.sn2 = const_cast<float*>(s_norm2);

@@ -7,6 +7,8 @@
 // relu), each a full read + write of the activation.  The input may be the first c channels of a wider
 // slab (the concat-free dense block): rows (n, c) are hw contiguous floats, batch stride given.
 #include "nw_internal.h"
+// max(v, 0) that keeps a NaN, like torch's relu (fmaxf(NaN, 0) is 0)
+#define NW_RELU(v) ((v) < 0.f ? 0.f : (v))
 
 namespace nw {
 namespace {
@@ -27,11 +29,11 @@ __global__ __launch_bounds__(256) void nw_scale_shift_kernel(const float* __rest
             float4 v = *reinterpret_cast<const float4*>(x + n * x_batch_stride + c * hw + 4 * within);
             v.x = __builtin_fmaf(v.x, a, b); v.y = __builtin_fmaf(v.y, a, b);
             v.z = __builtin_fmaf(v.z, a, b); v.w = __builtin_fmaf(v.w, a, b);
-            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (RELU) { v.x = NW_RELU(v.x); v.y = NW_RELU(v.y); v.z = NW_RELU(v.z); v.w = NW_RELU(v.w); }
             *reinterpret_cast<float4*>(out + plane * hw + 4 * within) = v;
         } else {
             float v = __builtin_fmaf(x[n * x_batch_stride + c * hw + within], a, b);
-            if (RELU) v = fmaxf(v, 0.f);
+            if (RELU) v = NW_RELU(v);
             out[plane * hw + within] = v;
         }
     }
@@ -57,8 +59,9 @@ __global__ __launch_bounds__(256) void nw_scale_shift_relu_pool2_kernel(const fl
         const int c = (int)(plane - n * C);
         const float a = scale[c], b = shift[c];
         const float* p = x + n * x_batch_stride + ((int64_t)c * h + 2 * yo) * w + 2 * xo;
-        const float v0 = fmaxf(__builtin_fmaf(p[0], a, b), lo), v1 = fmaxf(__builtin_fmaf(p[1], a, b), lo);
-        const float v2 = fmaxf(__builtin_fmaf(p[w], a, b), lo), v3 = fmaxf(__builtin_fmaf(p[w + 1], a, b), lo);
+        auto clamp = [lo](float v) { return v < lo ? lo : v; };   // keeps a NaN (fmaxf would drop it)
+        const float v0 = clamp(__builtin_fmaf(p[0], a, b)), v1 = clamp(__builtin_fmaf(p[1], a, b));
+        const float v2 = clamp(__builtin_fmaf(p[w], a, b)), v3 = clamp(__builtin_fmaf(p[w + 1], a, b));
         out[i] = ((v0 + v1) + (v2 + v3)) * 0.25f;
     }
 }
@@ -153,11 +156,11 @@ __global__ __launch_bounds__(1024) void nw_bn_train_fwd_kernel(
                 const float4 r = *reinterpret_cast<const float4*>(rc + i * C * hw + j);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
-            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (RELU) { v.x = NW_RELU(v.x); v.y = NW_RELU(v.y); v.z = NW_RELU(v.z); v.w = NW_RELU(v.w); }
             *reinterpret_cast<float4*>(yc + i * C * hw + j) = v;
         } else {
             if (RES) v.x += rc[i * C * hw + j];
-            if (RELU) v.x = fmaxf(v.x, 0.f);
+            if (RELU) v.x = NW_RELU(v.x);
             yc[i * C * hw + j] = v.x;
         }
     });
@@ -243,8 +246,8 @@ inline unsigned channel_threads(int64_t per_channel) { return per_channel >= 163
 // a bias-free convolution in the folded channels_last ResNets (bias add, identity add and ReLU in ONE pass instead of
 // three element-wise launches).  float4 along C (C % 4 == 0); in place allowed.
 template <bool RELU, bool RES>
-__global__ __launch_bounds__(256) void nw_bias_act_rows_kernel(const float* __restrict__ x, const float* __restrict__ bias,
-                                                               const float* __restrict__ res, float* __restrict__ out,
+__global__ __launch_bounds__(256) void nw_bias_act_rows_kernel(const float* x, const float* __restrict__ bias,
+                                                               const float* __restrict__ res, float* out,   // out may be x (in place)
                                                                int64_t total4, int c4) {
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
         const int c = (int)(idx % c4);
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void nw_bias_act_rows_kernel(const float* __re
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         if (RELU) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            v.x = NW_RELU(v.x); v.y = NW_RELU(v.y); v.z = NW_RELU(v.z); v.w = NW_RELU(v.w);
         }
         reinterpret_cast<float4*>(out)[idx] = v;
     }

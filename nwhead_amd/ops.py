@@ -40,6 +40,12 @@ class _OnDevice:
             self.ctx.__exit__(*a)
 
 
+def _sig(t):
+    """(storage address, shape, in-place version) of a tensor: what 'the very tensor, unmodified' means for the cached
+    banks and run tables.  Inference tensors (torch.inference_mode) carry no version counter: None stands in."""
+    return (t.data_ptr(), tuple(t.shape), None if t.is_inference() else t._version)
+
+
 _WS_BYTES = {}
 
 
@@ -176,7 +182,7 @@ class SplitBank:
         lib = _lib.load()
         sc = _f32c(s)
         # the tensor this bank was prepared from: identity, shape and in-place version (see matches())
-        self._src = (s.data_ptr(), tuple(s.shape), s._version)
+        self._src = _sig(s)
         self.label_max = None
         if labels is not None and labels.numel():
             lo, hi = (int(v) for v in torch.aminmax(labels.detach()))
@@ -208,6 +214,7 @@ class SplitBank:
         else:
             self.norm2 = row_norm2(sc)
         self.tables = self._tables_src = None
+        self.tables_label_max = -1
         if labels is not None and labels.dim() == 1 and self.split is not None:
             self.build_tables(self.sorted_labels if self.sorted_labels is not None else labels)
 
@@ -220,23 +227,30 @@ class SplitBank:
         N = self.shape[0]
         if lab64.dim() != 1 or lab64.numel() != N or N == 0 or not lab64.is_cuda:
             return
+        lo, hi = (int(v) for v in torch.aminmax(lab64))
+        if lo < 0:
+            raise ValueError("support labels must be non-negative class indices (F.one_hot, nw.py:276, raises too)")
+        self.tables_label_max = hi      # the tables hold every label as a real class: n_classes must exceed it (hint_tables)
         nbytes = lib.nw_bank_tables_bytes(N)
         tables = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=lab64.device)
         with torch.cuda.device(lab64.device):
             # C: any bound above the labels gives the same tables (nw_head refuses labels >= n_classes)
             _lib.check(lib.nw_bank_tables_build(_ptr(lab64), N, 0x7fffffff, _ptr(tables), nbytes, _stream(lab64)),
                        "nw_bank_tables_build")
-        self.tables, self._tables_src = tables, (labels.data_ptr(), tuple(labels.shape), labels._version)
+        self.tables, self._tables_src = tables, _sig(labels)
 
     def hint_tables(self, lib, sy, syc, n_classes):
         """Name the cached run tables for the forward call that follows, if ``sy`` is the label tensor they were built
         from (``syc``: the int64 contiguous form handed to the library)."""
-        if self.tables is not None and (sy.data_ptr(), tuple(sy.shape), sy._version) == self._tables_src:
+        if self.tables is not None and _sig(sy) == self._tables_src:
+            if self.tables_label_max >= int(n_classes):
+                raise ValueError(f"support label {self.tables_label_max} is outside [0, n_classes={int(n_classes)}) "
+                                 "(the reference's F.one_hot, nw.py:276, raises)")
             lib.nw_bank_tables_hint(_ptr(self.tables), self.tables.numel(), _ptr(syc), self.shape[0], int(n_classes))
 
     def matches(self, s):
         """True when `s` is the very tensor (storage, shape, no in-place update since) this bank was prepared from."""
-        return (s.data_ptr(), tuple(s.shape), s._version) == self._src
+        return _sig(s) == self._src
 
 
 def _resolve_sorted_bank(s, sy, cache, per_position_outputs=False):

@@ -16,6 +16,9 @@ hipError_t_ hipGetDeviceCount(int* n) { if (n) *n = 0; return 100; }   /* hipErr
 hipError_t_ hipGetDevice(int* d) { if (d) *d = 0; return 100; }
 hipError_t_ hipGetDevicePropertiesR0600(...) { return 100; }
 hipError_t_ hipDeviceGetAttribute(int* v, ...) { if (v) *v = 0; return 100; }
+hipError_t_ hipGetSymbolAddress(void** p, const void*) { if (p) *p = nullptr; return 100; }
+hipError_t_ hipFuncSetAttribute(...) { return 100; }
+void __hipRegisterVar(void**, void*, char*, const char*, int, unsigned long, int, int) {}
 hipError_t_ hipEventCreate(...) { return 100; }
 hipError_t_ hipEventRecord(...) { return 100; }
 hipError_t_ hipEventSynchronize(...) { return 100; }

@@ -202,3 +202,64 @@ def test_cached_run_tables_give_the_same_output_and_follow_the_labels(dev):
     a2 = ops.nw_head(q, s, sy, C, support_cache=plain)
     b2 = ops.nw_head(q, s, sy, C, support_cache=withtab)
     assert torch.equal(a2, b2) and not torch.equal(a, a2)
+
+
+def test_run_tables_refuse_labels_outside_the_class_range(dev):
+    """A bank built WITHOUT labels whose tables are built afterwards (what ShardedBank does) still refuses a call whose
+    n_classes does not cover the labels in those tables (they are indexed by class in the merge)."""
+    from nwhead_amd import ops
+    from nwhead_amd.sharded import ShardedBank
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(1024, 64, generator=g).to(dev)
+    sy = (torch.arange(1024) % 9).sort().values.to(dev)
+    q = torch.randn(16, 64, generator=g).to(dev)
+    bank = ops.SplitBank(s)
+    bank.build_tables(sy)
+    assert bank.tables_label_max == 8
+    ops.nw_partials(q, s, sy, 9, support_cache=bank)
+    with pytest.raises(ValueError, match="outside"):
+        ops.nw_partials(q, s, sy, 5, support_cache=bank)
+    with pytest.raises(ValueError, match="non-negative"):
+        ops.SplitBank(s).build_tables(sy - 1)
+    with pytest.raises(ValueError, match="outside"):
+        ShardedBank(s, sy, 5).predict(q)
+
+
+def test_banks_work_under_inference_mode(dev):
+    """torch.inference_mode tensors carry no version counter: the identity signature copes."""
+    from nwhead_amd import ops
+    from oracle import nw_oracle as O
+    g = torch.Generator().manual_seed(4)
+    sc, qc = torch.randn(700, 64, generator=g), torch.randn(12, 64, generator=g)
+    syc = (torch.arange(700) % 11).sort().values
+    with torch.inference_mode():
+        s, q, sy = sc.to(dev), qc.to(dev), syc.to(dev)
+        bank = ops.SplitBank(s, sy)
+        out = ops.nw_head(q, s, sy, 11, support_cache=bank)
+        assert bank.matches(s)
+    ref = O.nw_head_f64(qc, sc, syc, 11)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("d", [96, 160])
+def test_bank_backward_at_widths_that_are_not_multiples_of_64(dev, d):
+    """nw_bwd_bank_f32 with a bank whose split buffer is exactly N * d floats (no tail): the product kernel's last
+    64-column tile must not read past it -- the rows are re-split into the workspace at such widths."""
+    from nwhead_amd import ops, _lib
+    from oracle import nw_oracle as O
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    B, N, C = 64, 1536, 12
+    if not _lib.load().nw_bwd_uses_split(B, N, d, C, 0):
+        pytest.skip("the split backward does not apply at this shape")
+    qc, sc = torch.randn(B, d, generator=g), torch.randn(N, d, generator=g)
+    syc, t = (torch.arange(N) % C), torch.randint(0, C, (B,), generator=g)
+    q, s = qc.to(dev).requires_grad_(True), sc.to(dev).requires_grad_(True)
+    out = ops.nw_head(q, s, syc.to(dev), C)
+    F.nll_loss(out, t.to(dev)).backward()
+    torch.cuda.synchronize()
+    gout = torch.zeros(B, C, dtype=torch.float64)
+    gout[torch.arange(B), t] = -1.0 / B
+    gq, gs = O.nw_head_bwd_f64(qc, sc, syc, C, gout)
+    assert (q.grad.cpu().double() - gq).abs().max().item() < 2e-5 * gq.abs().max().item() + 1e-9
+    assert (s.grad.cpu().double() - gs).abs().max().item() < 2e-5 * gs.abs().max().item() + 1e-9
