@@ -364,6 +364,42 @@ int nw_bn_relu_train_bwd_f32(const float *x, const float *residual, const float 
                              int64_t acc_batch_stride, int64_t n, int64_t c, int64_t hw,
                              int64_t x_batch_stride, int relu, void *stream);
 
+/* Weight gradient of a stride-1 'same' convolution (1x1, or 3x3 with padding 1) over channels-last activations on the fp16
+ * matrix cores (csrc/conv_wgrad.hip): what autograd derives for the weight of F.conv2d at model/densenet.py:33-60, :82-91
+ * and model/resnet.py:31-66 in loss.backward() (train.py:414).
+ *     dw[co, ky, kx, ci] = sum_{n,y,x} gy[n, y, x, co] * x[n, y + ky - pad, x + kx - pad, ci]
+ *   x (n, H, W, Cin), gy (n, H, W, Cout) fp32 with their amax records; Cin % 8 == 0, Cout % 8 == 0
+ *   dw (Cout, KH, KW, Cin) fp32: the bytes of a channels_last (Cout, Cin, KH, KW) tensor
+ *   workspace: nw_conv2d_nhwc_wgrad_workspace_bytes(...) (partial tiles of the position chunks, added in order)
+ * nw_conv2d_nhwc_wgrad_supported: 1 when the shape is served, else the call returns NW_ERR_UNSUPPORTED. */
+int nw_conv2d_nhwc_wgrad_supported(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                                   int64_t stride, int64_t pad);
+size_t nw_conv2d_nhwc_wgrad_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH,
+                                            int64_t KW, int64_t stride, int64_t pad);
+int nw_conv2d_nhwc_wgrad_f16x2(const float *x, const float *amax_x, const float *gy, const float *amax_g, float *dw,
+                               void *workspace, size_t workspace_bytes, int64_t n, int64_t H, int64_t W, int64_t Cin,
+                               int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, void *stream);
+/* device address of 32 bytes of zeros the convolution kernels read in place of pixels that do not exist (internal) */
+const void *nw_conv_zero_page(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * The same pair over channels-last activations (csrc/bn_nhwc.hip), for the training path whose convolutions run in
+ * nw_conv2d_nhwc_f16x2: x is (rows = n h w, c) with row stride ldx >= c floats (a channel prefix of a wider NHWC
+ * tensor qualifies), c % 4 == 0, y / dy / dx dense (rows, c).  Moments per row chunk merged in a fixed order (Chan),
+ * deterministic; amax_out (nullable): the amax record (NW_AMAX_SLOTS floats) of y / dx for the convolution that reads
+ * it next.  acc (nullable, backward): a second gradient of x with row stride ldacc, added into dx.
+ * workspace: nw_bn_nhwc_workspace_bytes(rows, c).
+ * ------------------------------------------------------------------------------------------- */
+size_t nw_bn_nhwc_workspace_bytes(int64_t rows, int64_t c);
+int nw_bn_relu_nhwc_train_fwd_f32(const float *x, int64_t ldx, const float *gamma, const float *beta, float *running_mean,
+                                  float *running_var, float *y, float *save_mean, float *save_invstd,
+                                  int64_t *num_batches_tracked, float *amax_out, void *workspace, size_t workspace_bytes,
+                                  int64_t rows, int64_t c, float momentum, float eps, int relu, void *stream);
+int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, const float *gamma, const float *beta,
+                                  const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
+                                  float *dbeta, const float *acc, int64_t ldacc, float *amax_out, void *workspace,
+                                  size_t workspace_bytes, int64_t rows, int64_t c, int relu, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): device time of the TILE kernel alone -- the kernel the
  * roofline is quoted on (nw_fused_kernel / nw_fused_f16p_kernel), without the small kernels around

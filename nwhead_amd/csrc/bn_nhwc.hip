@@ -1,0 +1,335 @@
+// bn_nhwc.hip -- training-mode BatchNorm2d (+ ReLU) over channels-last activations, forward and backward (gfx950 /
+// MI355X only).  The NHWC counterpart of bnrelu.hip's one-workgroup-per-channel kernels, for the training path whose
+// convolutions run in csrc/conv_nhwc.hip: same call sites (model/densenet.py:33-60 norm1 / norm2, :82-91, :139;
+// model/resnet.py:31-66), same arithmetic (shifted / merged moments, centred normalisation, the ReLU mask recomputed
+// from x in the backward), and every pass that writes an activation also leaves its amax record (per-workgroup maxima,
+// include/nwhead_hip.h) for the convolution that reads it next.
+//
+// A tensor is (rows = n h w, C) with a row stride ldx >= C (a channel prefix of a wider NHWC tensor qualifies),
+// C % 4 == 0.  Three launches each way:
+//   forward : stats (per row chunk and channel: count, mean, M2 -- Welford moments of the chunk, merged pairwise in a
+//             fixed order with Chan's formula: no E[x^2] - E[x]^2 cancellation, deterministic)
+//             -> finalize (merge the chunks; mean, 1/sqrt(var + eps), running statistics, step counter)
+//             -> apply (y = max((x - mean) a + beta, 0), a = gamma invstd; amax record of y)
+//   backward: stats (per chunk and channel: sum g, sum g xhat, g = dy [y > 0]) -> finalize (dgamma, dbeta, the two
+//             means) -> apply (dx = a (g - mean(g) - xhat mean(g xhat)) [+ acc]; amax record of dx)
+#include "nw_internal.h"
+#include <cstdlib>
+
+namespace nw {
+namespace {
+
+constexpr int BN_SLOTS = 256;        // = NW_AMAX_SLOTS
+constexpr int BN_TC = 64;            // channels per stats workgroup (16 float4 lanes) x 16 row lanes
+
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float n2, float mean2, float m22) {
+    const float nt = n + n2;
+    if (n2 > 0.f) {
+        const float d = mean2 - mean, f = n2 / nt;
+        mean = __builtin_fmaf(d, f, mean);
+        m2 = m2 + m22 + d * d * n * f;
+    }
+    n = nt;
+}
+
+// partial moments of rows [r0, r1) for the 64 channels of tile blockIdx.y: part[(k * G + g) * C + c], k = 0 count, 1 mean, 2 M2
+__global__ __launch_bounds__(256) void nw_bn_nhwc_stats_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ part,
+                                                                int64_t R, int C, int G, int64_t rows_per_chunk) {
+    __shared__ float sh[3][16][BN_TC + 1];
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int c0 = blockIdx.y * BN_TC + 4 * cq;
+    const int g = blockIdx.x;
+    const int64_t r0 = (int64_t)g * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float n = 0.f, K[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+        int64_t r = r0 + rl;
+        if (r < r1) {   // the shift: this thread's first value per channel
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+            K[0] = v.x; K[1] = v.y; K[2] = v.z; K[3] = v.w;
+        }
+        for (; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+            const float d[4] = {v.x - K[0], v.y - K[1], v.z - K[2], v.w - K[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s1[j] += d[j];
+                s2[j] = __builtin_fmaf(d[j], d[j], s2[j]);
+            }
+            n += 1.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float md = n > 0.f ? s1[j] / n : 0.f;
+        sh[0][rl][4 * cq + j] = n;
+        sh[1][rl][4 * cq + j] = K[j] + md;
+        sh[2][rl][4 * cq + j] = n > 0.f ? fmaxf(s2[j] - md * s1[j], 0.f) : 0.f;
+    }
+    __syncthreads();
+    if (tid < BN_TC && blockIdx.y * BN_TC + tid < C) {
+        float nn = sh[0][0][tid], mean = sh[1][0][tid], m2 = sh[2][0][tid];
+        for (int l = 1; l < 16; ++l) chan_merge(nn, mean, m2, sh[0][l][tid], sh[1][l][tid], sh[2][l][tid]);
+        const int c = blockIdx.y * BN_TC + tid;
+        part[((int64_t)0 * G + g) * C + c] = nn;
+        part[((int64_t)1 * G + g) * C + c] = mean;
+        part[((int64_t)2 * G + g) * C + c] = m2;
+    }
+}
+
+__global__ __launch_bounds__(256) void nw_bn_nhwc_finalize_kernel(const float* __restrict__ part, int G, int C,
+                                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                   int64_t* __restrict__ num_batches_tracked, float momentum, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+    if (c >= C) return;
+    float n = part[c], mean = part[(int64_t)G * C + c], m2 = part[(int64_t)2 * G * C + c];
+    for (int g = 1; g < G; ++g)
+        chan_merge(n, mean, m2, part[(int64_t)g * C + c], part[((int64_t)G + g) * C + c], part[((int64_t)2 * G + g) * C + c]);
+    const float var = n > 0.f ? fmaxf(m2 / n, 0.f) : 0.f;
+    save_mean[c] = mean;
+    save_invstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
+}
+
+// y[r][c] = act((x[r][c] - mean[c]) a[c] + beta[c]), a = gamma invstd; amax record of y
+template <bool RELU>
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                                 const float* __restrict__ save_invstd, float* __restrict__ y,
+                                                                 float* __restrict__ amax, int64_t R, int C) {
+    extern __shared__ float prm[];   // [3][C]: mean, a, beta
+    __shared__ float red[16];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        prm[c] = save_mean[c];
+        prm[C + c] = gamma[c] * save_invstd[c];
+        prm[2 * C + c] = beta[c];
+    }
+    __syncthreads();
+    const int q4 = C >> 2;
+    const int64_t total = R * q4;
+    float mx = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / q4;
+        const int c = (int)(idx - r * q4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 m = *reinterpret_cast<const float4*>(prm + c), a = *reinterpret_cast<const float4*>(prm + C + c),
+                     b = *reinterpret_cast<const float4*>(prm + 2 * C + c);
+        v.x = __builtin_fmaf(v.x - m.x, a.x, b.x); v.y = __builtin_fmaf(v.y - m.y, a.y, b.y);
+        v.z = __builtin_fmaf(v.z - m.z, a.z, b.z); v.w = __builtin_fmaf(v.w - m.w, a.w, b.w);
+        if (RELU) {   // (keeps a NaN, like torch's relu)
+            v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+        }
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        *reinterpret_cast<float4*>(y + r * C + c) = v;
+    }
+    mx = block_max(mx, red);
+    if (amax && threadIdx.x == 0)
+        for (int k = blockIdx.x; k < BN_SLOTS; k += gridDim.x) amax[k] = k == (int)blockIdx.x ? mx : 0.f;
+}
+
+// backward partial sums of rows [r0, r1): part[(k * G + g) * C + c], k = 0 sum g, 1 sum g xhat
+template <bool RELU>
+__global__ __launch_bounds__(256) void nw_bn_nhwc_bwd_stats_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                                    float* __restrict__ part, int64_t R, int C, int G,
+                                                                    int64_t rows_per_chunk) {
+    __shared__ float sh[2][16][BN_TC + 1];
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int c0 = blockIdx.y * BN_TC + 4 * cq;
+    const int g = blockIdx.x;
+    const int64_t r0 = (int64_t)g * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+        const float4 m4 = *reinterpret_cast<const float4*>(save_mean + c0), i4 = *reinterpret_cast<const float4*>(save_invstd + c0),
+                     g4 = *reinterpret_cast<const float4*>(gamma + c0), b4 = *reinterpret_cast<const float4*>(beta + c0);
+        const float mean[4] = {m4.x, m4.y, m4.z, m4.w}, inv[4] = {i4.x, i4.y, i4.z, i4.w};
+        const float a[4] = {g4.x * i4.x, g4.y * i4.y, g4.z * i4.z, g4.w * i4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+        for (int64_t r = r0 + rl; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+            const float4 d = *reinterpret_cast<const float4*>(dy + r * C + c0);
+            const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pre = __builtin_fmaf(xv[j] - mean[j], a[j], b[j]);   // the forward's own y: same ReLU mask
+                const float gd = (!RELU || pre > 0.f) ? dv[j] : 0.f;
+                s1[j] += gd;
+                s2[j] = __builtin_fmaf(gd, (xv[j] - mean[j]) * inv[j], s2[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sh[0][rl][4 * cq + j] = s1[j];
+        sh[1][rl][4 * cq + j] = s2[j];
+    }
+    __syncthreads();
+    if (tid < BN_TC && blockIdx.y * BN_TC + tid < C) {
+        float a1 = sh[0][0][tid], a2 = sh[1][0][tid];
+        for (int l = 1; l < 16; ++l) { a1 += sh[0][l][tid]; a2 += sh[1][l][tid]; }
+        const int c = blockIdx.y * BN_TC + tid;
+        part[((int64_t)0 * G + g) * C + c] = a1;
+        part[((int64_t)1 * G + g) * C + c] = a2;
+    }
+}
+
+// dgamma, dbeta and the two means (k[c], k[C + c]) the apply pass needs
+__global__ __launch_bounds__(256) void nw_bn_nhwc_bwd_finalize_kernel(const float* __restrict__ part, int G, int C, float inv_m,
+                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                       float* __restrict__ k) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int g = 0; g < G; ++g) {
+        s1 += part[(int64_t)g * C + c];
+        s2 += part[((int64_t)G + g) * C + c];
+    }
+    dbeta[c] = s1;
+    dgamma[c] = s2;
+    k[c] = s1 * inv_m;
+    k[C + c] = s2 * inv_m;
+}
+
+// dx[r][c] = a (g - k1 - xhat k2) [+ acc[r][c]]; amax record of dx
+template <bool RELU>
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                                     const float* __restrict__ k, const float* __restrict__ acc, int64_t ldacc,
+                                                                     float* __restrict__ dx, float* __restrict__ amax, int64_t R, int C) {
+    extern __shared__ float prm[];   // [6][C]: mean, invstd, a, beta, k1, k2
+    __shared__ float red[16];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float inv = save_invstd[c];
+        prm[c] = save_mean[c];
+        prm[C + c] = inv;
+        prm[2 * C + c] = gamma[c] * inv;
+        prm[3 * C + c] = beta[c];
+        prm[4 * C + c] = k[c];
+        prm[5 * C + c] = k[C + c];
+    }
+    __syncthreads();
+    const int q4 = C >> 2;
+    const int64_t total = R * q4;
+    float mx = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / q4;
+        const int c = (int)(idx - r * q4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 d = *reinterpret_cast<const float4*>(dy + r * C + c);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mean = prm[c + j], inv = prm[C + c + j], a = prm[2 * C + c + j], b = prm[3 * C + c + j];
+            const float pre = __builtin_fmaf(xv[j] - mean, a, b);
+            const float gd = (!RELU || pre > 0.f) ? dv[j] : 0.f;
+            o[j] = a * (gd - prm[4 * C + c + j] - (xv[j] - mean) * inv * prm[5 * C + c + j]);
+        }
+        if (acc) {
+            const float4 e = *reinterpret_cast<const float4*>(acc + r * ldacc + c);
+            o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+        }
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        *reinterpret_cast<float4*>(dx + r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    mx = block_max(mx, red);
+    if (amax && threadIdx.x == 0)
+        for (int kk = blockIdx.x; kk < BN_SLOTS; kk += gridDim.x) amax[kk] = kk == (int)blockIdx.x ? mx : 0.f;
+}
+
+inline void stats_grid(int64_t R, int64_t C, int* G, int64_t* rpc) {
+    const int64_t ctiles = (C + BN_TC - 1) / BN_TC;
+    int64_t g = 2048 / ctiles;                    // ~2048 workgroups in all
+    const int64_t gmax = (R + 63) / 64;           // at least 64 rows (4 per row lane) per chunk
+    if (g > gmax) g = gmax;
+    if (g < 1) g = 1;
+    *rpc = (R + g - 1) / g;
+    *G = (int)((R + *rpc - 1) / *rpc);
+}
+inline int apply_grid(int64_t R, int64_t C) {
+    const int64_t want = (R * (C / 4) + 1023) / 1024;
+    return (int)(want < 1 ? 1 : (want > BN_SLOTS ? BN_SLOTS : want));
+}
+inline bool bad_align(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+             reinterpret_cast<uintptr_t>(d)) & 15) != 0;
+}
+
+}  // namespace
+}  // namespace nw
+
+extern "C" size_t nw_bn_nhwc_workspace_bytes(int64_t rows, int64_t c) {
+    if (rows <= 0 || c <= 0) return 0;
+    int G; int64_t rpc;
+    nw::stats_grid(rows, c, &G, &rpc);
+    return ((size_t)3 * G * c + 2 * c) * sizeof(float);
+}
+
+extern "C" int nw_bn_relu_nhwc_train_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
+                                             float* running_var, float* y, float* save_mean, float* save_invstd,
+                                             int64_t* num_batches_tracked, float* amax_out, void* workspace, size_t workspace_bytes,
+                                             int64_t rows, int64_t c, float momentum, float eps, int relu, void* stream) {
+    using namespace nw;
+    if (rows < 0 || c <= 0 || c % 4 || ldx < c || ldx % 4) return NW_ERR_INVALID_ARG;
+    if (rows == 0) return NW_OK;
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd) return NW_ERR_INVALID_ARG;
+    if (bad_align(x, y, amax_out, workspace) || bad_align(gamma, beta, save_mean, save_invstd)) return NW_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < nw_bn_nhwc_workspace_bytes(rows, c)) return NW_ERR_WORKSPACE;
+    if (c > 2048) return NW_ERR_UNSUPPORTED;   // the per-channel factors live in LDS
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int G; int64_t rpc;
+    stats_grid(rows, c, &G, &rpc);
+    float* part = static_cast<float*>(workspace);
+    const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
+    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(256), 0, st, x, ldx, part, rows, (int)c, G, rpc);
+    hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st, part, G, (int)c, running_mean,
+                       running_var, save_mean, save_invstd, num_batches_tracked, momentum, eps);
+    const int ag = apply_grid(rows, c);
+    const size_t lds = (size_t)3 * c * sizeof(float);
+    if (relu)
+        hipLaunchKernelGGL((nw_bn_nhwc_apply_kernel<true>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, gamma, beta, save_mean,
+                           save_invstd, y, amax_out, rows, (int)c);
+    else
+        hipLaunchKernelGGL((nw_bn_nhwc_apply_kernel<false>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, gamma, beta, save_mean,
+                           save_invstd, y, amax_out, rows, (int)c);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_bn_relu_nhwc_train_bwd_f32(const float* x, int64_t ldx, const float* dy, const float* gamma, const float* beta,
+                                             const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                                             float* dbeta, const float* acc, int64_t ldacc, float* amax_out, void* workspace,
+                                             size_t workspace_bytes, int64_t rows, int64_t c, int relu, void* stream) {
+    using namespace nw;
+    if (rows < 0 || c <= 0 || c % 4 || ldx < c || ldx % 4 || (acc && (ldacc < c || ldacc % 4))) return NW_ERR_INVALID_ARG;
+    if (rows == 0) return NW_OK;
+    if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return NW_ERR_INVALID_ARG;
+    if (bad_align(x, dy, dx, acc) || bad_align(gamma, beta, save_mean, save_invstd) || bad_align(amax_out, workspace))
+        return NW_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < nw_bn_nhwc_workspace_bytes(rows, c)) return NW_ERR_WORKSPACE;
+    if (c > 2048) return NW_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int G; int64_t rpc;
+    stats_grid(rows, c, &G, &rpc);
+    float* part = static_cast<float*>(workspace);
+    float* k = part + (size_t)3 * G * c;
+    const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
+    const int ag = apply_grid(rows, c);
+    const size_t lds = (size_t)6 * c * sizeof(float);
+#define NW_BNB(R_)                                                                                                             \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((nw_bn_nhwc_bwd_stats_kernel<R_>), dim3((unsigned)G, ct), dim3(256), 0, st, x, ldx, dy, gamma, beta, \
+                           save_mean, save_invstd, part, rows, (int)c, G, rpc);                                               \
+        hipLaunchKernelGGL(nw_bn_nhwc_bwd_finalize_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st, part, G, (int)c, \
+                           1.f / (float)rows, dgamma, dbeta, k);                                                               \
+        hipLaunchKernelGGL((nw_bn_nhwc_bwd_apply_kernel<R_>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, dy, gamma, beta,  \
+                           save_mean, save_invstd, k, acc, ldacc, dx, amax_out, rows, (int)c);                                 \
+    } while (0)
+    if (relu) NW_BNB(true); else NW_BNB(false);
+#undef NW_BNB
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}

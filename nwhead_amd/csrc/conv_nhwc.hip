@@ -576,6 +576,8 @@ int launch_conv_cfg(ConvP p, hipStream_t st) {
 }  // namespace
 }  // namespace nw
 
+extern "C" const void* nw_conv_zero_page(void) { return nw::zero_page(); }
+
 extern "C" int nw_absmax_f32(const float* x, int64_t count, float* amax_out, void* stream) {
     if (count < 0 || !amax_out || (count > 0 && !x)) return NW_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(amax_out)) & 15) return NW_ERR_INVALID_ARG;

@@ -1,0 +1,408 @@
+// conv_wgrad.hip -- weight gradient of the backbones' stride-1 convolutions on the fp16 matrix cores at fp32-grade
+// accuracy (gfx950 / MI355X only).  Replaces what autograd derives for the weight of F.conv2d at model/densenet.py:33-60
+// (conv1 1x1, conv2 3x3), :82-91 (transition 1x1) and model/resnet.py:31-66 (3x3) in loss.backward(), train.py:414:
+//
+//     dW[co, ky, kx, ci] = sum_{n, y, x} gy[n, y, x, co] * x[n, y + ky - p, x + kx - p, ci]          (stride 1, p = (k - 1) / 2)
+//
+// A GEMM whose contraction runs over PIXELS: both operands are "k-major" (a pixel is a row of channels), so their LDS
+// images are read with the transposing ds_read_b64_tr_b16 (bwd_split.hip's second product).  fp32 NHWC activations are
+// split into fp16 pairs on the way into LDS with one power of two per tensor (their amax records), like conv_nhwc.hip.
+// The contraction index is a position of a VIRTUAL raster with one zero column behind every image row and one zero row
+// behind every image (the loaders write the zeros): the taps of a 3x3 kernel are then constant row shifts of ONE ring of
+// x rows in LDS (a 32-position stage adds 32 rows to the ring, every row is fetched once), and no border test exists.
+// The position axis is split over workgroups; partial tiles are added in chunk order by a second kernel (deterministic).
+//   WIDE  (1x1): 128 output x 128 input channels per workgroup, 2 x 2 waves of 64 x 64.
+//   TAPS9 (3x3, Cout % 32 == 0): 32 output x 64 input channels x 9 taps per workgroup; wave w takes input-channel block w.
+#include "nw_internal.h"
+#include "tile_dma.h"
+#include <cstdlib>
+
+namespace nw {
+namespace {
+
+typedef __fp16 fp16x4w __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 halfx4w __attribute__((ext_vector_type(4)));
+constexpr int WG_SLOTS = 256;
+
+struct WgradP {
+    const float* x;
+    const float* amax_x;
+    const float* gy;
+    const float* amax_g;
+    float* part;             // [ks][Cout][T][Cin]
+    const float4* zeros;
+    int N, H, W, Cin, Cout, T, KW, pad;
+    int IP, IMG;             // virtual raster: row stride (W + 1 with taps, W without), image stride
+    int nstage;              // 32-position stages in all
+    int ks, spc;             // position chunks, stages per chunk
+    int co_tiles, ci_tiles;
+};
+
+__device__ __forceinline__ float amax_rec(const float* rec, int lane) {   // max of an amax record, by one wave
+    const float4 v = reinterpret_cast<const float4*>(rec)[lane];
+    return wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+}
+__device__ __forceinline__ int unit_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <bool TAPS9>
+struct WgCfg {
+    static constexpr int COT = TAPS9 ? 32 : 128, CIT = TAPS9 ? 64 : 128;
+    static constexpr int GRS = TAPS9 ? 256 : 512;         // bytes of a gy row in LDS (32 channels use half of a 256-byte row)
+    static constexpr int XRS = CIT * 4;                    // bytes of an x row in LDS
+    static constexpr int NBG = 3;                          // gy stage buffers
+    static constexpr int RING = TAPS9 ? 256 : 128;         // x rows in LDS
+    static constexpr int XAHEAD = TAPS9 ? 3 : 1;           // x is written this many stages ahead of gy's stage
+    static constexpr int XBEHIND = TAPS9 ? 3 : 0;          // ... and a stage reads x rows this many stages behind it
+    static constexpr int NSET = 3;                         // register sets of loads in flight
+    static constexpr size_t LDS = (size_t)NBG * 32 * GRS + (size_t)RING * XRS;
+    static constexpr int GP = TAPS9 ? 1 : 2, XP = TAPS9 ? 1 : 2;   // passes of 256 lanes x 8 floats per stage
+};
+
+template <bool TAPS9>
+__global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
+    using C = WgCfg<TAPS9>;
+    constexpr int COT = C::COT, CIT = C::CIT, GRS = C::GRS, XRS = C::XRS, NBG = C::NBG, RING = C::RING, NSET = C::NSET;
+    constexpr int XAHEAD = C::XAHEAD, XBEHIND = C::XBEHIND, GP = C::GP, XP = C::XP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const gbuf = smem;
+    char* const xring = smem + NBG * 32 * GRS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (position chunk, output-channel tile, input-channel tile)
+    int b = blockIdx.x;
+    const int cit = b % p.ci_tiles; b /= p.ci_tiles;
+    const int cot = b % p.co_tiles; b /= p.co_tiles;
+    const int kc = b;
+    const int s0 = kc * p.spc, s1 = min(p.nstage, s0 + p.spc);
+    const int co0 = cot * COT, ci0 = cit * CIT;
+    const int V = p.N * p.IMG;
+
+    if (wave >= 4) {
+        // ============================================================== loaders: global -> registers -> split -> LDS
+        const int lt = tid - 256;
+        const float upg = __builtin_ldexpf(1.f, split_exponent(amax_rec(p.amax_g, lane)));
+        const float upx = __builtin_ldexpf(1.f, split_exponent(amax_rec(p.amax_x, lane)));
+        const uintptr_t zpage = reinterpret_cast<uintptr_t>(p.zeros);
+        // lane -> (row in pass, 8-channel group): COT / 8 (CIT / 8) lanes per row
+        constexpr int GL = COT / 8, XL = CIT / 8, GROWS = 256 / GL, XROWS = 256 / XL;
+        const int g_r = lt / GL, g_c = lt % GL, x_r = lt / XL, x_c = lt % XL;
+        struct Set { float4 g[GP][2]; float4 x[XP][2]; };
+        Set ld[NSET];
+        // A lane's rows move 32 virtual positions per step: (n, y, x) of each is kept and advanced (no division per load).
+        struct Pos { int n, y, x; };
+        const int RI = p.IMG / p.IP, q32 = 32 / p.IP, r32 = 32 - q32 * p.IP;
+        auto pos_of = [&](int v) {               // floor semantics for negative v (rows in front of the first image)
+            int n = v / p.IMG, r = v - n * p.IMG;
+            if (r < 0) { r += p.IMG; --n; }
+            Pos o; o.n = n; o.y = r / p.IP; o.x = r - o.y * p.IP;
+            return o;
+        };
+        auto advance = [&](Pos& o) {
+            o.x += r32; o.y += q32;
+            if (o.x >= p.IP) { o.x -= p.IP; ++o.y; }
+            while (o.y >= RI) { o.y -= RI; ++o.n; }
+        };
+        auto pixel = [&](const Pos& o) {         // pixel index (n H + y) W + x, or -1 for a gap / outside the batch
+            return (o.n >= 0 && o.n < p.N && o.y < p.H && o.x < p.W) ? (o.n * p.H + o.y) * p.W + o.x : -1;
+        };
+        const int jb = s0 - XBEHIND - XAHEAD;
+        Pos pg[GP], px_[XP];
+#pragma unroll
+        for (int q = 0; q < GP; ++q) pg[q] = pos_of(32 * jb + g_r + GROWS * q);
+#pragma unroll
+        for (int q = 0; q < XP; ++q) px_[q] = pos_of(32 * (jb + XAHEAD) + x_r + XROWS * q);
+        auto issue = [&](Set& L, int sg) {        // loads of the NEXT step (gy stage sg, x stage sg + XAHEAD); advances the rows
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const int row = g_r + GROWS * q;
+                const int px = (row < 32 && sg >= s0 && sg < s1) ? pixel(pg[q]) : -1;
+                const int ch = co0 + 8 * g_c;
+                const bool ok = px >= 0 && ch < p.Cout;
+                const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.gy + (size_t)px * p.Cout + ch) : zpage);
+                L.g[q][0] = src[0];
+                L.g[q][1] = src[1];
+                advance(pg[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < XP; ++q) {
+                const int row = x_r + XROWS * q;
+                const int px = row < 32 ? pixel(px_[q]) : -1;
+                const int ch = ci0 + 8 * x_c;
+                const bool ok = px >= 0 && ch < p.Cin;
+                const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.x + (size_t)px * p.Cin + ch) : zpage);
+                L.x[q][0] = src[0];
+                L.x[q][1] = src[1];
+                advance(px_[q]);
+            }
+        };
+        auto split8 = [](const float4& a, const float4& bq, float up, uint4& hv, uint4& lv) {
+            unsigned hh[4], ll[4];
+            const float xv[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                asm volatile(
+                    "v_fma_mixlo_f16 %0, %4, %8, 0\n"
+                    "v_fma_mixlo_f16 %1, %6, %8, 0\n"
+                    "v_fma_mixhi_f16 %0, %5, %8, 0\n"
+                    "v_fma_mixhi_f16 %1, %7, %8, 0\n"
+                    "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n"
+                    "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n"
+                    "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+                    "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
+                    "s_nop 0"
+                    : "=&v"(hh[2 * u]), "=&v"(hh[2 * u + 1]), "=&v"(ll[2 * u]), "=&v"(ll[2 * u + 1])
+                    : "v"(xv[4 * u]), "v"(xv[4 * u + 1]), "v"(xv[4 * u + 2]), "v"(xv[4 * u + 3]), "v"(up));
+            hv = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            lv = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+        };
+        // k-major split image: a row holds, per 32 channels, [16 h | 16 h | 16 l | 16 l] as four 32-byte units; the unit
+        // index is XOR-ed with unit_swz(row) inside its aligned group of eight (transposed reads then spread over the banks)
+        auto store8 = [](char* rowp, int row, int cgrp, const uint4& hv, const uint4& lv) {
+            const int u = 4 * (cgrp >> 2) + ((cgrp >> 1) & 1), f = unit_swz(row);
+            *reinterpret_cast<uint4*>(rowp + (((u ^ f)) << 5) + ((cgrp & 1) << 4)) = hv;
+            *reinterpret_cast<uint4*>(rowp + ((((u + 2) ^ f)) << 5) + ((cgrp & 1) << 4)) = lv;
+        };
+        auto write = [&](const Set& L, int sg, int sx) {
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const int row = g_r + GROWS * q;
+                if (row < 32 && sg >= s0) {
+                    uint4 hv, lv;
+                    split8(L.g[q][0], L.g[q][1], upg, hv, lv);
+                    store8(gbuf + ((unsigned)sg % NBG) * (32 * GRS) + row * GRS, row, g_c, hv, lv);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < XP; ++q) {
+                const int row = x_r + XROWS * q;
+                if (row < 32) {
+                    uint4 hv, lv;
+                    split8(L.x[q][0], L.x[q][1], upx, hv, lv);
+                    const int rr = (32 * sx + row) & (RING - 1);
+                    store8(xring + rr * XRS, rr, x_c, hv, lv);
+                }
+            }
+        };
+        // Loader step j writes gy stage j and x stage j + XAHEAD; consumer stage s reads gy(s) and the x stages
+        // s - XBEHIND .. s + XAHEAD, so it may start once the steps <= s are written.  Step j + 1 is written while the
+        // consumers work on stage j (its gy buffer and the ring rows it overwrites -- x stage j + 1 + XAHEAD - RING / 32 --
+        // are not read then); the loads of step j + NSET are issued into the registers step j leaves.
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) issue(ld[u], jb + u);
+        for (int j = jb; j < s1; j += NSET) {
+#pragma unroll
+            for (int u = 0; u < NSET; ++u) {
+                const int jj = j + u;
+                if (jj >= s1) break;
+                write(ld[u], jj, jj + XAHEAD);
+                issue(ld[u], jj + NSET);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (jj >= s0) __builtin_amdgcn_s_barrier();   // releases consumer stage jj
+            }
+        }
+        __builtin_amdgcn_s_barrier();                          // the consumers' barrier behind their last stage
+        return;
+    }
+
+    // ================================================================== consumers
+    const int i = lane & 15, g = lane >> 4;
+    const int tq = i >> 2, tp = i & 3;
+    const float ig = __builtin_ldexpf(1.f, -split_exponent(wave_max(fmaxf(fmaxf(reinterpret_cast<const float4*>(p.amax_g)[lane].x,
+                          reinterpret_cast<const float4*>(p.amax_g)[lane].y), fmaxf(reinterpret_cast<const float4*>(p.amax_g)[lane].z,
+                          reinterpret_cast<const float4*>(p.amax_g)[lane].w)))));
+    const float ix = __builtin_ldexpf(1.f, -split_exponent(wave_max(fmaxf(fmaxf(reinterpret_cast<const float4*>(p.amax_x)[lane].x,
+                          reinterpret_cast<const float4*>(p.amax_x)[lane].y), fmaxf(reinterpret_cast<const float4*>(p.amax_x)[lane].z,
+                          reinterpret_cast<const float4*>(p.amax_x)[lane].w)))));
+    const float unscale = ig * ix;
+    auto tr4 = [](const char* addr) {
+        return __builtin_bit_cast(halfx4w, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4w*)addr));
+    };
+    // transposed read of 32 k x 16 columns: lane 16 g + 4 q + p supplies row 8 g + q (+ 4), bytes 8 p .. 8 p + 7 of the
+    // block's 32-byte unit; `unit` = index of the h (or l) unit of the 16-column block inside the row
+    auto tr8 = [&](const char* base, int rs, int row0, int ring_mask, int unit) {
+        const int ra = (row0 + 8 * g + tq) & ring_mask, rb = (row0 + 8 * g + tq + 4) & ring_mask;
+        const halfx4w a = tr4(base + ra * rs + ((unit ^ unit_swz(ra)) << 5) + 8 * tp);
+        const halfx4w bq = tr4(base + rb * rs + ((unit ^ unit_swz(rb)) << 5) + 8 * tp);
+        return half8{a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
+    };
+    auto mm = [](const half8& a, const half8& bq, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, c, 0, 0, 0); };
+    auto unit_of = [](int col0, bool low) { return 4 * (col0 >> 5) + ((col0 >> 4) & 1) + (low ? 2 : 0); };
+
+    constexpr int NACC = TAPS9 ? 18 : 16;
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wm = wave >> 1, wn = wave & 1;               // WIDE: 64 x 64 quadrant
+    __builtin_amdgcn_s_barrier();                          // stage s0 (and the x rows around it) is in LDS
+    for (int s = s0; s < s1; ++s) {
+        const char* gb = gbuf + ((unsigned)s % NBG) * (32 * GRS);
+        if (TAPS9) {
+            half8 ah[2], al[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ah[a] = tr8(gb, GRS, 0, 31, unit_of(16 * a, false));
+                al[a] = tr8(gb, GRS, 0, 31, unit_of(16 * a, true));
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int shift = (t / 3 - 1) * p.IP + (t % 3 - 1);
+                const int row0 = 32 * s + shift;
+                const half8 bh = tr8(xring, XRS, row0, RING - 1, unit_of(16 * wave, false));
+                const half8 bl = tr8(xring, XRS, row0, RING - 1, unit_of(16 * wave, true));
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    acc[2 * t + a] = mm(al[a], bh, acc[2 * t + a]);
+                    acc[2 * t + a] = mm(ah[a], bl, acc[2 * t + a]);
+                    acc[2 * t + a] = mm(ah[a], bh, acc[2 * t + a]);
+                }
+            }
+        } else {
+            half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                ah[a] = tr8(gb, GRS, 0, 31, unit_of(64 * wm + 16 * a, false));
+                al[a] = tr8(gb, GRS, 0, 31, unit_of(64 * wm + 16 * a, true));
+                bh[a] = tr8(xring, XRS, 32 * s, RING - 1, unit_of(64 * wn + 16 * a, false));
+                bl[a] = tr8(xring, XRS, 32 * s, RING - 1, unit_of(64 * wn + 16 * a, true));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[4 * a + c] = mm(al[a], bh[c], acc[4 * a + c]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[4 * a + c] = mm(ah[a], bl[c], acc[4 * a + c]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[4 * a + c] = mm(ah[a], bh[c], acc[4 * a + c]);
+        }
+        tile_barrier();
+    }
+    // ---- partial tile: part[kc][co][t][ci]; acc[.][e] of lane (i, g) = C[row 4 g + e of its co block][column i of its ci block]
+    float* out = p.part + (size_t)kc * p.Cout * p.T * p.Cin;
+    if (TAPS9) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = co0 + 16 * a + 4 * g + e, ci = ci0 + 16 * wave + i;
+                    if (co < p.Cout && ci < p.Cin) out[((size_t)co * p.T + t) * p.Cin + ci] = acc[2 * t + a][e] * unscale;
+                }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = co0 + 64 * wm + 16 * a + 4 * g + e, ci = ci0 + 64 * wn + 16 * c + i;
+                    if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[4 * a + c][e] * unscale;
+                }
+    }
+}
+
+// dw[idx] = sum_k part[k][idx], chunk order
+__global__ __launch_bounds__(256) void nw_conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                    int64_t total4, int ks) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    float4 a = reinterpret_cast<const float4*>(part)[idx];
+    for (int k = 1; k < ks; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(part)[(int64_t)k * total4 + idx];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[idx] = a;
+}
+
+struct WgPlan {
+    bool taps9;
+    int co_tiles, ci_tiles, nstage, ks, spc;
+    int IP, IMG;
+};
+
+bool wgrad_plan(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad,
+                WgPlan* pl) {
+    if (n <= 0 || H <= 0 || W <= 0 || stride != 1 || KH != KW || (KH != 1 && KH != 3) || pad != (KH - 1) / 2) return false;
+    if (Cin % 8 || Cout % 8 || Cin < 8 || Cout < 8) return false;
+    pl->taps9 = KH == 3;
+    if (pl->taps9 && W > 78) return false;                 // a tap shift (W + 2 rows) must stay within three 32-row stages
+    pl->IP = (int)(pl->taps9 ? W + 1 : W);
+    pl->IMG = (int)(pl->taps9 ? (H + 1) * (W + 1) : H * W);
+    const int64_t V = n * pl->IMG;
+    if (V >= (1LL << 30) || n * H * W * Cin >= (1LL << 31) || n * H * W * Cout >= (1LL << 31)) return false;
+    pl->nstage = (int)((V + 31) / 32);
+    const int cot = pl->taps9 ? 32 : 128, cit = pl->taps9 ? 64 : 128;
+    pl->co_tiles = (int)((Cout + cot - 1) / cot);
+    pl->ci_tiles = (int)((Cin + cit - 1) / cit);
+    const int64_t tiles = (int64_t)pl->co_tiles * pl->ci_tiles;
+    int64_t ks = (512 + tiles - 1) / tiles;                // ~512 workgroups
+    const int64_t maxks = (pl->nstage + 15) / 16;          // at least 16 stages per chunk
+    if (ks > maxks) ks = maxks;
+    if (ks < 1) ks = 1;
+    pl->spc = (int)((pl->nstage + ks - 1) / ks);
+    pl->ks = (int)((pl->nstage + pl->spc - 1) / pl->spc);
+    return true;
+}
+
+}  // namespace
+}  // namespace nw
+
+extern "C" int nw_conv2d_nhwc_wgrad_supported(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                                              int64_t stride, int64_t pad) {
+    nw::WgPlan pl;
+    return nw::wgrad_plan(n, H, W, Cin, Cout, KH, KW, stride, pad, &pl) ? 1 : 0;
+}
+
+extern "C" size_t nw_conv2d_nhwc_wgrad_workspace_bytes(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH,
+                                                       int64_t KW, int64_t stride, int64_t pad) {
+    nw::WgPlan pl;
+    if (!nw::wgrad_plan(n, H, W, Cin, Cout, KH, KW, stride, pad, &pl)) return 0;
+    return (size_t)pl.ks * Cout * KH * KW * Cin * sizeof(float);
+}
+
+extern "C" const void* nw_conv_zero_page(void);
+
+extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, const float* gy, const float* amax_g, float* dw,
+                                          void* workspace, size_t workspace_bytes, int64_t n, int64_t H, int64_t W, int64_t Cin,
+                                          int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, void* stream) {
+    using namespace nw;
+    WgPlan pl;
+    if (!wgrad_plan(n, H, W, Cin, Cout, KH, KW, stride, pad, &pl)) return NW_ERR_UNSUPPORTED;
+    if (!x || !amax_x || !gy || !amax_g || !dw) return NW_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dw) |
+         reinterpret_cast<uintptr_t>(amax_x) | reinterpret_cast<uintptr_t>(amax_g) | reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return NW_ERR_INVALID_ARG;
+    const size_t need = nw_conv2d_nhwc_wgrad_workspace_bytes(n, H, W, Cin, Cout, KH, KW, stride, pad);
+    if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    WgradP p;
+    p.x = x; p.amax_x = amax_x; p.gy = gy; p.amax_g = amax_g;
+    p.part = pl.ks == 1 ? dw : static_cast<float*>(workspace);
+    p.zeros = static_cast<const float4*>(nw_conv_zero_page());
+    if (!p.zeros) return NW_ERR_LAUNCH;
+    p.N = (int)n; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout; p.T = (int)(KH * KW); p.KW = (int)KW; p.pad = (int)pad;
+    p.IP = pl.IP; p.IMG = pl.IMG; p.nstage = pl.nstage; p.ks = pl.ks; p.spc = pl.spc; p.co_tiles = pl.co_tiles; p.ci_tiles = pl.ci_tiles;
+    const unsigned grid = (unsigned)((int64_t)pl.ks * pl.co_tiles * pl.ci_tiles);
+    if (pl.taps9) {
+        static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(nw_conv_wgrad_kernel<true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgCfg<true>::LDS) == hipSuccess;
+        if (!attr) return NW_ERR_LAUNCH;
+        hipLaunchKernelGGL(nw_conv_wgrad_kernel<true>, dim3(grid), dim3(512), WgCfg<true>::LDS, st, p);
+    } else {
+        static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(nw_conv_wgrad_kernel<false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgCfg<false>::LDS) == hipSuccess;
+        if (!attr) return NW_ERR_LAUNCH;
+        hipLaunchKernelGGL(nw_conv_wgrad_kernel<false>, dim3(grid), dim3(512), WgCfg<false>::LDS, st, p);
+    }
+    if (pl.ks > 1) {
+        const int64_t total4 = Cout * KH * KW * Cin / 4;
+        hipLaunchKernelGGL(nw_conv_wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const float*>(workspace), dw, total4, pl.ks);
+    }
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}

@@ -142,6 +142,10 @@ FUSED_RESNET_CONV3X3 = _os.environ.get("NW_RESNET_OWN_CONV3X3", "0") == "1"
 FUSED_CONV_NHWC = _os.environ.get("NW_CONV_NHWC", "1") != "0"
 FUSED_CONV1X1 = True            # folded inference copies: 1x1 convolutions with their BatchNorm / ReLU neighbours as one kernel (Conv1x1Fused)
 FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.bn_relu_train on the MI355X
+# Training on the MI355X in channels-last layout: every convolution (forward, data and weight gradient) on the fp16 matrix
+# cores with split-fp16 operands (ops.conv2d_nhwc_train, csrc/conv_nhwc.hip + conv_wgrad.hip) and BatchNorm + ReLU through
+# csrc/bn_nhwc.hip; the DenseNets take this path.  NW_NHWC_TRAINING=0: the NCHW path (MIOpen convolutions).
+NHWC_TRAINING = _os.environ.get("NW_NHWC_TRAINING", "1") != "0"
 
 
 def _fused_training(bn, x):
@@ -233,6 +237,20 @@ class _DenseBlock(nn.Module):
         for i in range(num_layers):
             self.add_module(f"denselayer{i + 1}", _DenseLayer(cin + i * growth_rate, growth_rate, bn_size, drop_rate))
 
+    def forward_nhwc_train(self, x):
+        """Channels-last training forward of the block (DenseNet._forward_nhwc_train): the running concatenation passes
+        through norm1's autograd node like in forward() below."""
+        from .. import ops
+        cur = x
+        for layer in self.children():
+            a, cur = ops.bn_relu_train_nhwc(cur, layer.norm1, True, passthrough=True)
+            t = ops.bn_relu_train_nhwc(ops.conv2d_nhwc_train(a, layer.conv1.weight, 1, 0), layer.norm2)
+            new = ops.conv2d_nhwc_train(t, layer.conv2.weight, 1, 1)
+            if layer.drop_rate > 0:
+                new = F.dropout(new, layer.drop_rate, self.training)
+            cur = torch.cat((cur, new), 1)
+        return cur
+
     def forward(self, x):
         layers = list(self.children())
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -307,7 +325,27 @@ class DenseNet(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, x):
+        if (NHWC_TRAINING and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and x.dim() == 4 and x.shape[1] == 3):
+            return self._forward_nhwc_train(x)
         return torch.flatten(F.adaptive_avg_pool2d(F.relu(self.features(x)), (1, 1)), 1)
+
+    def _forward_nhwc_train(self, x):
+        """The training forward in channels-last layout on the MI355X (same values as the reference's module sequence,
+        densenet.py:93-163): activations fp32 NHWC, BatchNorm + ReLU pairs through ops.bn_relu_train_nhwc (they leave the
+        amax record the following convolution scales its operand by), convolutions through ops.conv2d_nhwc_train."""
+        from .. import ops
+        f = self.features
+        y = ops.bn_relu_train_nhwc(ops.conv2d_nhwc_train(x, f.conv0.weight, 2, 3), f.norm0)
+        y = f.pool0(y)
+        for mod in f.children():
+            if isinstance(mod, _DenseBlock):
+                y = mod.forward_nhwc_train(y)
+            elif isinstance(mod, _Transition):
+                z = ops.conv2d_nhwc_train(ops.bn_relu_train_nhwc(y, mod.norm), mod.conv.weight, 1, 0)
+                y = mod.pool(z)
+        y = ops.bn_relu_train_nhwc(y, f.norm5)          # (norm5 + the relu of DenseNet.forward)
+        return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
 
 
 class ScaleShiftReLU(nn.Module):

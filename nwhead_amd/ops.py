@@ -882,3 +882,185 @@ def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0
     if want_amax:
         y.nw_amax = am_out
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Channels-last training path: BatchNorm + ReLU (csrc/bn_nhwc.hip) and the convolution's autograd node.
+def _nhwc_rows(x):
+    """(n, c, h, w) fp32 HIP tensor whose memory is (n h w) rows of >= c floats (channels_last, or a channel prefix /
+    window of a channels_last tensor) -> (tensor, row stride); anything else is made channels_last."""
+    n, c, h, w = x.shape
+    if x.dtype == torch.float32 and x.numel():
+        ld = x.stride(3) if w > 1 else (x.stride(2) if h > 1 else (x.stride(0) if n > 1 else c))
+        if (x.stride(1) == 1 and ld >= c and ld % 4 == 0 and (w == 1 or x.stride(3) == ld) and (h == 1 or x.stride(2) == w * ld)
+                and (n == 1 or x.stride(0) == h * w * ld) and x.data_ptr() % 16 == 0):
+            return x, ld
+    x = x.float().contiguous(memory_format=torch.channels_last)
+    return x, c
+
+
+class _BNReLUNhwcFn(torch.autograd.Function):
+    """relu(batch_norm(x)) in training mode over channels-last activations (nw_bn_relu_nhwc_train_fwd_f32 / _bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu, passthrough=False):
+        lib = _lib.load()
+        xv, ldx = _nhwc_rows(x.detach())
+        n, c, h, w = xv.shape
+        rows = n * h * w
+        dev = xv.device
+        y = torch.empty((n, c, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=dev)
+        track = bn.track_running_stats and bn.running_mean is not None
+        momentum, nbt = 0.0, None
+        if track:
+            if bn.momentum is None:
+                bn.num_batches_tracked += 1
+                momentum = 1.0 / float(bn.num_batches_tracked)
+            else:
+                momentum, nbt = float(bn.momentum), bn.num_batches_tracked
+        wc, bc = _f32c(weight), _f32c(bias)
+        ws_bytes = lib.nw_bn_nhwc_workspace_bytes(rows, c)
+        ws = _workspace(ws_bytes, dev)
+        with _OnDevice(dev):
+            _lib.check(lib.nw_bn_relu_nhwc_train_fwd_f32(_ptr(xv), ldx, _ptr(wc), _ptr(bc),
+                                                         _ptr(bn.running_mean) if track else None,
+                                                         _ptr(bn.running_var) if track else None, _ptr(y), _ptr(mean),
+                                                         _ptr(invstd), _ptr(nbt), _ptr(amax), _ptr(ws), ws_bytes, rows, c,
+                                                         momentum, float(bn.eps), int(relu), _stream(xv)),
+                       "nw_bn_relu_nhwc_train_fwd_f32")
+        ctx.save_for_backward(xv, wc, bc, mean, invstd)
+        ctx.relu, ctx.ldx, ctx.passthrough = relu, ldx, passthrough
+        y.nw_amax = amax
+        if passthrough:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, gpass=None):
+        lib = _lib.load()
+        xv, wc, bc, mean, invstd = ctx.saved_tensors
+        if gy is None:
+            return gpass, None, None, None, None, None
+        n, c, h, w = xv.shape
+        rows = n * h * w
+        dev = xv.device
+        if gy.dtype != torch.float32 or not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.float().contiguous(memory_format=torch.channels_last)
+        acc, ldacc = None, 0
+        if gpass is not None:
+            acc, ldacc = _nhwc_rows(gpass)
+        dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        dg, db = torch.empty_like(mean), torch.empty_like(mean)
+        amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=dev)
+        ws_bytes = lib.nw_bn_nhwc_workspace_bytes(rows, c)
+        ws = _workspace(ws_bytes, dev)
+        with _OnDevice(dev):
+            _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(xv), ctx.ldx, _ptr(gy), _ptr(wc), _ptr(bc), _ptr(mean), _ptr(invstd),
+                                                         _ptr(dx), _ptr(dg), _ptr(db), _ptr(acc), ldacc, _ptr(amax), _ptr(ws),
+                                                         ws_bytes, rows, c, int(ctx.relu), _stream(xv)),
+                       "nw_bn_relu_nhwc_train_bwd_f32")
+        dx.nw_amax = amax
+        return dx, dg, db, None, None, None
+
+
+def bn_relu_train_nhwc(x, bn, relu=True, passthrough=False):
+    """relu(bn(x)) for a BatchNorm2d in training mode over a channels-last fp32 activation on the MI355X; the result is
+    channels_last and carries `.nw_amax` for the convolution that follows.  passthrough: see bn_relu_train."""
+    _need_hip(x, bn.weight, bn.bias)
+    if not (bn.affine and bn.weight is not None):
+        raise ValueError("bn_relu_train_nhwc needs an affine BatchNorm2d")
+    if x.shape[0] * x.shape[2] * x.shape[3] <= 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+    if x.shape[1] % 4:
+        raise ValueError("bn_relu_train_nhwc needs a channel count that is a multiple of 4")
+    return _BNReLUNhwcFn.apply(x, bn.weight, bn.bias, bn, bool(relu), bool(passthrough))
+
+
+_CONV_STATS = {"absmax_fallbacks": 0}
+
+
+def _amax_of(t):
+    """The amax record a tensor carries (conv2d_nhwc / bn_relu_train_nhwc leave one on their results), else one pass."""
+    a = getattr(t, "nw_amax", None)
+    if a is None:
+        _CONV_STATS["absmax_fallbacks"] += 1
+        a = absmax(t)
+    return a
+
+
+class _ConvNhwcFn(torch.autograd.Function):
+    """conv2d over channels-last activations on the fp16 matrix cores: forward and data gradient through
+    nw_conv2d_nhwc_f16x2 (the data gradient of a stride-1 convolution is the convolution with the flipped, transposed
+    weight and padding k - 1 - p), weight gradient through nw_conv2d_nhwc_wgrad_f16x2 when it serves the shape."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, amax):
+        xv = x.detach()
+        if xv.dtype != torch.float32 or not xv.is_contiguous(memory_format=torch.channels_last):
+            xv = xv.float().contiguous(memory_format=torch.channels_last)
+        if amax is None:
+            amax = _amax_of(x)
+        y = conv2d_nhwc(xv, SplitConvWeight(weight), None, None, False, stride, pad, amax=amax)
+        ctx.save_for_backward(xv, weight, amax)
+        ctx.stride, ctx.pad = stride, pad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, weight, amax_x = ctx.saved_tensors
+        stride, pad = ctx.stride, ctx.pad
+        cout, cin, kh, kw = weight.shape
+        g = gy
+        gam = getattr(gy, "nw_amax", None)
+        if g.dtype != torch.float32 or not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.float().contiguous(memory_format=torch.channels_last)
+        if gam is None:
+            _CONV_STATS["absmax_fallbacks"] += 1
+            gam = absmax(g)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1 and kh == kw and kh - 1 - pad >= 0 and cout % 32 == 0 and cin % 32 == 0:
+                wt = weight.detach().flip(2, 3).transpose(0, 1)           # (cin, cout, kh, kw)
+                dx = conv2d_nhwc(g, SplitConvWeight(wt), None, None, False, 1, kh - 1 - pad, amax=gam)
+            else:
+                dx = torch.ops.aten.convolution_backward(g, xv, weight, None, [stride, stride], [pad, pad], [1, 1], False,
+                                                         [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_nhwc_wgrad(xv, g, weight.shape, stride, pad, amax_x, gam)
+        return dx, dw, None, None, None
+
+
+def conv2d_nhwc_wgrad(x, gy, wshape, stride, pad, amax_x=None, amax_g=None):
+    """Weight gradient of conv2d for channels-last x (n, Cin, H, W) and gy (n, Cout, Ho, Wo) -> (Cout, Cin, KH, KW)
+    (channels_last strides).  Stride-1 'same' 1x1 / 3x3 shapes run in nw_conv2d_nhwc_wgrad_f16x2; the rest (the strided
+    stem) goes to torch in NCHW."""
+    lib = _lib.load()
+    cout, cin, kh, kw = wshape
+    n, _, h, w = x.shape
+    if lib.nw_conv2d_nhwc_wgrad_supported(n, h, w, cin, cout, kh, kw, stride, pad):
+        if amax_x is None:
+            amax_x = _amax_of(x)
+        if amax_g is None:
+            amax_g = _amax_of(gy)
+        dw = torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
+        ws_bytes = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, cin, cout, kh, kw, stride, pad)
+        ws = _workspace(ws_bytes, x.device)
+        with _OnDevice(x.device):
+            _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(x), _ptr(amax_x), _ptr(gy), _ptr(amax_g), _ptr(dw), _ptr(ws), ws_bytes,
+                                                      n, h, w, cin, cout, kh, kw, stride, pad, _stream(x)),
+                       "nw_conv2d_nhwc_wgrad_f16x2")
+        return dw.permute(0, 3, 1, 2)
+    return torch.ops.aten.convolution_backward(gy.contiguous(), x.contiguous(), torch.empty(wshape, dtype=x.dtype, device=x.device),
+                                               None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+                                               [False, True, False])[1]
+
+
+def conv2d_nhwc_train(x, weight, stride=1, pad=0, amax=None):
+    """Differentiable conv2d(x, weight, stride=stride, padding=pad) for channels-last fp32 activations on the MI355X
+    (bias-free: the backbones' convolutions have none).  x may carry `.nw_amax`."""
+    _need_hip(x, weight)
+    return _ConvNhwcFn.apply(x, weight, int(stride), int(pad), amax)
