@@ -364,6 +364,17 @@ int nw_bn_relu_train_bwd_f32(const float *x, const float *residual, const float 
                              int64_t acc_batch_stride, int64_t n, int64_t c, int64_t hw,
                              int64_t x_batch_stride, int relu, void *stream);
 
+/* Every convolution weight of a network to the split-row operands nw_conv2d_nhwc_f16x2 reads, in ONE launch (the weights
+ * change with every optimizer step, train.py:414-415).  jobs: device array of njobs x 10 int64 --
+ *   [0] address of a torch-contiguous (Cout, Cin, KH, KW) fp32 weight, [1] offset (floats) of the operand in split_base,
+ *   [2] offset of its row scales in scale_base, [3] index of its first row among all rows (ascending), [4] rows, [5] cols
+ *   (floats per row, % 32 == 0), [6] Cin, [7] Cout, [8] KH * KW, [9] KW | mode << 32 with
+ *   mode 0: the forward operand, rows = Cout, row co = [tap][ci];  mode 1: the data-gradient operand of a stride-1
+ *   convolution, rows = Cin, row ci = [flipped tap][co];  mode 2: few input channels (Cin <= 4), rows = Cout,
+ *   row co = [ky][32 floats: kx * 4 + ci, zero-padded] (the operand of the stems over a 4-channel input). */
+int nw_split_conv_weights_f16x2(const int64_t *jobs, int64_t njobs, int64_t total_rows, float *split_base,
+                                float *scale_base, void *stream);
+
 /* Weight gradient of a stride-1 'same' convolution (1x1, or 3x3 with padding 1) over channels-last activations on the fp16
  * matrix cores (csrc/conv_wgrad.hip): what autograd derives for the weight of F.conv2d at model/densenet.py:33-60, :82-91
  * and model/resnet.py:31-66 in loss.backward() (train.py:414).

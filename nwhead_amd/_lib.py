@@ -58,6 +58,7 @@ SIGNATURES = {
     "nw_to_nhwc_pad_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "nw_conv2d_nhwc_supported": (_int, [_i64] * 9),
     "nw_conv2d_nhwc_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _int, _p, _p] + [_i64] * 9 + [_p]),
+    "nw_split_conv_weights_f16x2": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "nw_conv2d_nhwc_wgrad_supported": (_int, [_i64] * 9),
     "nw_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i64] * 9),
     "nw_conv2d_nhwc_wgrad_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _sz] + [_i64] * 9 + [_p]),

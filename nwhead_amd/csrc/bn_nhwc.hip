@@ -6,10 +6,11 @@
 // include/nwhead_hip.h) for the convolution that reads it next.
 //
 // A tensor is (rows = n h w, C) with a row stride ldx >= C (a channel prefix of a wider NHWC tensor qualifies),
-// C % 4 == 0.  Three launches each way:
+// C % 4 == 0.  Three launches each way (the middle one tiny):
 //   forward : stats (per row chunk and channel: count, mean, M2 -- Welford moments of the chunk, merged pairwise in a
 //             fixed order with Chan's formula: no E[x^2] - E[x]^2 cancellation, deterministic)
-//             -> finalize (merge the chunks; mean, 1/sqrt(var + eps), running statistics, step counter)
+//             -> finalize (64 channels x 16 chunk lanes per workgroup merge the chunks: mean, 1/sqrt(var + eps), running
+//                statistics, step counter; ~3 us -- merged by every apply workgroup instead it cost 9 us per pass)
 //             -> apply (y = max((x - mean) a + beta, 0), a = gamma invstd; amax record of y)
 //   backward: stats (per chunk and channel: sum g, sum g xhat, g = dy [y > 0]) -> finalize (dgamma, dbeta, the two
 //             means) -> apply (dx = a (g - mean(g) - xhat mean(g xhat)) [+ acc]; amax record of dx)
@@ -20,7 +21,9 @@ namespace nw {
 namespace {
 
 constexpr int BN_SLOTS = 256;        // = NW_AMAX_SLOTS
-constexpr int BN_TC = 64;            // channels per stats workgroup (16 float4 lanes) x 16 row lanes
+constexpr int BN_TC = 64;            // channels per stats workgroup: 16 float4 lanes x 64 row lanes
+constexpr int BN_RL = 64;            // row lanes of a stats workgroup (1024 threads)
+constexpr int BN_GC = 16384;         // chunks x channels of the partial moments (196 KB: what every apply workgroup re-reads)
 
 __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float n2, float mean2, float m22) {
     const float nt = n + n2;
@@ -33,9 +36,9 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 }
 
 // partial moments of rows [r0, r1) for the 64 channels of tile blockIdx.y: part[(k * G + g) * C + c], k = 0 count, 1 mean, 2 M2
-__global__ __launch_bounds__(256) void nw_bn_nhwc_stats_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ part,
-                                                                int64_t R, int C, int G, int64_t rows_per_chunk) {
-    __shared__ float sh[3][16][BN_TC + 1];
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_stats_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ part,
+                                                                 int64_t R, int C, int G, int64_t rows_per_chunk) {
+    __shared__ float sh[3][BN_RL][BN_TC + 1];
     const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
     const int c0 = blockIdx.y * BN_TC + 4 * cq;
     const int g = blockIdx.x;
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void nw_bn_nhwc_stats_kernel(const float* __re
             const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c0);
             K[0] = v.x; K[1] = v.y; K[2] = v.z; K[3] = v.w;
         }
-        for (; r < r1; r += 16) {
+        for (; r < r1; r += BN_RL) {
             const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c0);
             const float d[4] = {v.x - K[0], v.y - K[1], v.z - K[2], v.w - K[3]};
 #pragma unroll
@@ -66,26 +69,42 @@ __global__ __launch_bounds__(256) void nw_bn_nhwc_stats_kernel(const float* __re
         sh[2][rl][4 * cq + j] = n > 0.f ? fmaxf(s2[j] - md * s1[j], 0.f) : 0.f;
     }
     __syncthreads();
+    // row lanes merged in a fixed order: 4 x 16 sequential merges, then the four partial results
+    const int c = tid & 63, j4 = tid >> 6;
+    float nn = 0.f, mean = 0.f, m2 = 0.f;
+    if (tid < 256)
+        for (int l = 16 * j4; l < 16 * j4 + 16; ++l) chan_merge(nn, mean, m2, sh[0][l][c], sh[1][l][c], sh[2][l][c]);
+    __syncthreads();
+    if (tid < 256) { sh[0][j4][c] = nn; sh[1][j4][c] = mean; sh[2][j4][c] = m2; }
+    __syncthreads();
     if (tid < BN_TC && blockIdx.y * BN_TC + tid < C) {
-        float nn = sh[0][0][tid], mean = sh[1][0][tid], m2 = sh[2][0][tid];
-        for (int l = 1; l < 16; ++l) chan_merge(nn, mean, m2, sh[0][l][tid], sh[1][l][tid], sh[2][l][tid]);
-        const int c = blockIdx.y * BN_TC + tid;
-        part[((int64_t)0 * G + g) * C + c] = nn;
-        part[((int64_t)1 * G + g) * C + c] = mean;
-        part[((int64_t)2 * G + g) * C + c] = m2;
+        nn = sh[0][0][tid]; mean = sh[1][0][tid]; m2 = sh[2][0][tid];
+        for (int l = 1; l < 4; ++l) chan_merge(nn, mean, m2, sh[0][l][tid], sh[1][l][tid], sh[2][l][tid]);
+        const int cc = blockIdx.y * BN_TC + tid;
+        part[((int64_t)0 * G + g) * C + cc] = nn;
+        part[((int64_t)1 * G + g) * C + cc] = mean;
+        part[((int64_t)2 * G + g) * C + cc] = m2;
     }
 }
 
-__global__ __launch_bounds__(256) void nw_bn_nhwc_finalize_kernel(const float* __restrict__ part, int G, int C,
-                                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                                   int64_t* __restrict__ num_batches_tracked, float momentum, float eps) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
-    if (c >= C) return;
-    float n = part[c], mean = part[(int64_t)G * C + c], m2 = part[(int64_t)2 * G * C + c];
-    for (int g = 1; g < G; ++g)
-        chan_merge(n, mean, m2, part[(int64_t)g * C + c], part[((int64_t)G + g) * C + c], part[((int64_t)2 * G + g) * C + c]);
+// Merge of the G chunk moments: 64 channels x 16 chunk lanes per workgroup -- lane j merges the chunks j, j + 16, ... of
+// its channel (coalesced across channels, <= 16 dependent steps), the 16 partial results are merged in lane order.
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_finalize_kernel(const float* __restrict__ part, int G, int C,
+                                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                    int64_t* __restrict__ num_batches_tracked, float momentum, float eps) {
+    __shared__ float sh[3][16][64];
+    const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C)
+        for (int g = j; g < G; g += 16)
+            chan_merge(n, mean, m2, part[(int64_t)g * C + c], part[((int64_t)G + g) * C + c], part[((int64_t)2 * G + g) * C + c]);
+    sh[0][j][cl] = n; sh[1][j][cl] = mean; sh[2][j][cl] = m2;
+    __syncthreads();
+    if (j != 0 || c >= C) return;
+    for (int k = 1; k < 16; ++k) chan_merge(n, mean, m2, sh[0][k][cl], sh[1][k][cl], sh[2][k][cl]);
     const float var = n > 0.f ? fmaxf(m2 / n, 0.f) : 0.f;
     save_mean[c] = mean;
     save_invstd[c] = 1.f / sqrtf(var + eps);
@@ -131,12 +150,12 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_apply_kernel(const float* __r
 
 // backward partial sums of rows [r0, r1): part[(k * G + g) * C + c], k = 0 sum g, 1 sum g xhat
 template <bool RELU>
-__global__ __launch_bounds__(256) void nw_bn_nhwc_bwd_stats_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
-                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                    const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                                                                    float* __restrict__ part, int64_t R, int C, int G,
-                                                                    int64_t rows_per_chunk) {
-    __shared__ float sh[2][16][BN_TC + 1];
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_stats_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                                     float* __restrict__ part, int64_t R, int C, int G,
+                                                                     int64_t rows_per_chunk) {
+    __shared__ float sh[2][BN_RL][BN_TC + 1];
     const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
     const int c0 = blockIdx.y * BN_TC + 4 * cq;
     const int g = blockIdx.x;
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(256) void nw_bn_nhwc_bwd_stats_kernel(const float* 
                      g4 = *reinterpret_cast<const float4*>(gamma + c0), b4 = *reinterpret_cast<const float4*>(beta + c0);
         const float mean[4] = {m4.x, m4.y, m4.z, m4.w}, inv[4] = {i4.x, i4.y, i4.z, i4.w};
         const float a[4] = {g4.x * i4.x, g4.y * i4.y, g4.z * i4.z, g4.w * i4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
-        for (int64_t r = r0 + rl; r < r1; r += 16) {
+        for (int64_t r = r0 + rl; r < r1; r += BN_RL) {
             const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c0);
             const float4 d = *reinterpret_cast<const float4*>(dy + r * C + c0);
             const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
@@ -168,24 +187,30 @@ __global__ __launch_bounds__(256) void nw_bn_nhwc_bwd_stats_kernel(const float* 
     __syncthreads();
     if (tid < BN_TC && blockIdx.y * BN_TC + tid < C) {
         float a1 = sh[0][0][tid], a2 = sh[1][0][tid];
-        for (int l = 1; l < 16; ++l) { a1 += sh[0][l][tid]; a2 += sh[1][l][tid]; }
+        for (int l = 1; l < BN_RL; ++l) { a1 += sh[0][l][tid]; a2 += sh[1][l][tid]; }
         const int c = blockIdx.y * BN_TC + tid;
         part[((int64_t)0 * G + g) * C + c] = a1;
         part[((int64_t)1 * G + g) * C + c] = a2;
     }
 }
 
-// dgamma, dbeta and the two means (k[c], k[C + c]) the apply pass needs
-__global__ __launch_bounds__(256) void nw_bn_nhwc_bwd_finalize_kernel(const float* __restrict__ part, int G, int C, float inv_m,
-                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                       float* __restrict__ k) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+// dgamma, dbeta and the two means (k[c], k[C + c]) the apply pass needs: the same 64 x 16 split of the chunk sums
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_finalize_kernel(const float* __restrict__ part, int G, int C, float inv_m,
+                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                        float* __restrict__ k) {
+    __shared__ float sh[2][16][64];
+    const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s1 = 0.f, s2 = 0.f;
-    for (int g = 0; g < G; ++g) {
-        s1 += part[(int64_t)g * C + c];
-        s2 += part[((int64_t)G + g) * C + c];
-    }
+    if (c < C)
+        for (int g = j; g < G; g += 16) {
+            s1 += part[(int64_t)g * C + c];
+            s2 += part[((int64_t)G + g) * C + c];
+        }
+    sh[0][j][cl] = s1; sh[1][j][cl] = s2;
+    __syncthreads();
+    if (j != 0 || c >= C) return;
+    for (int kk = 1; kk < 16; ++kk) { s1 += sh[0][kk][cl]; s2 += sh[1][kk][cl]; }
     dbeta[c] = s1;
     dgamma[c] = s2;
     k[c] = s1 * inv_m;
@@ -241,9 +266,9 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_apply_kernel(const float*
 }
 
 inline void stats_grid(int64_t R, int64_t C, int* G, int64_t* rpc) {
-    const int64_t ctiles = (C + BN_TC - 1) / BN_TC;
-    int64_t g = 2048 / ctiles;                    // ~2048 workgroups in all
-    const int64_t gmax = (R + 63) / 64;           // at least 64 rows (4 per row lane) per chunk
+    int64_t g = BN_GC / C;                        // chunks x channels bounded: the apply passes re-read all of them
+    if (g > 256) g = 256;
+    const int64_t gmax = (R + 4 * BN_RL - 1) / (4 * BN_RL);   // at least 4 rows per row lane
     if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     *rpc = (R + g - 1) / g;
@@ -278,14 +303,14 @@ extern "C" int nw_bn_relu_nhwc_train_fwd_f32(const float* x, int64_t ldx, const 
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd) return NW_ERR_INVALID_ARG;
     if (bad_align(x, y, amax_out, workspace) || bad_align(gamma, beta, save_mean, save_invstd)) return NW_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < nw_bn_nhwc_workspace_bytes(rows, c)) return NW_ERR_WORKSPACE;
-    if (c > 2048) return NW_ERR_UNSUPPORTED;   // the per-channel factors live in LDS
+    if (c > 1024) return NW_ERR_UNSUPPORTED;   // the per-channel factors and the merge scratch live in LDS
     hipStream_t st = static_cast<hipStream_t>(stream);
     int G; int64_t rpc;
     stats_grid(rows, c, &G, &rpc);
     float* part = static_cast<float*>(workspace);
     const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
-    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(256), 0, st, x, ldx, part, rows, (int)c, G, rpc);
-    hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st, part, G, (int)c, running_mean,
+    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, part, rows, (int)c, G, rpc);
+    hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, running_mean,
                        running_var, save_mean, save_invstd, num_batches_tracked, momentum, eps);
     const int ag = apply_grid(rows, c);
     const size_t lds = (size_t)3 * c * sizeof(float);
@@ -310,20 +335,20 @@ extern "C" int nw_bn_relu_nhwc_train_bwd_f32(const float* x, int64_t ldx, const 
     if (bad_align(x, dy, dx, acc) || bad_align(gamma, beta, save_mean, save_invstd) || bad_align(amax_out, workspace))
         return NW_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < nw_bn_nhwc_workspace_bytes(rows, c)) return NW_ERR_WORKSPACE;
-    if (c > 2048) return NW_ERR_UNSUPPORTED;
+    if (c > 1024) return NW_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int G; int64_t rpc;
     stats_grid(rows, c, &G, &rpc);
     float* part = static_cast<float*>(workspace);
-    float* k = part + (size_t)3 * G * c;
     const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
     const int ag = apply_grid(rows, c);
     const size_t lds = (size_t)6 * c * sizeof(float);
+    float* k = part + (size_t)3 * G * c;
 #define NW_BNB(R_)                                                                                                             \
     do {                                                                                                                       \
-        hipLaunchKernelGGL((nw_bn_nhwc_bwd_stats_kernel<R_>), dim3((unsigned)G, ct), dim3(256), 0, st, x, ldx, dy, gamma, beta, \
+        hipLaunchKernelGGL((nw_bn_nhwc_bwd_stats_kernel<R_>), dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, dy, gamma, beta, \
                            save_mean, save_invstd, part, rows, (int)c, G, rpc);                                               \
-        hipLaunchKernelGGL(nw_bn_nhwc_bwd_finalize_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st, part, G, (int)c, \
+        hipLaunchKernelGGL(nw_bn_nhwc_bwd_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, \
                            1.f / (float)rows, dgamma, dbeta, k);                                                               \
         hipLaunchKernelGGL((nw_bn_nhwc_bwd_apply_kernel<R_>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, dy, gamma, beta,  \
                            save_mean, save_invstd, k, acc, ldacc, dx, amax_out, rows, (int)c);                                 \

@@ -659,16 +659,21 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
         if (Cout % 64 == 0) return nw::launch_conv_cfg<4, 2, 1, nw::CV_ROWRUN>(p, st);
         return nw::launch_conv_cfg<2, 4, 1, nw::CV_ROWRUN>(p, st);
     }
-    // 128-channel tiles unless they would leave a quarter of the chip idle (7x7 planes: 25 pixel tiles)
-    const int64_t tiles128 = ((int64_t)p.M + 127) / 128 * (Cout / 128);
-    if (Cout % 128 == 0 && tiles128 * 4 >= (int64_t)nw::num_cus() * 3) {
-        if (k33 && patch_fits(128) && !force_gather) return nw::launch_conv_cfg<4, 4, 2, nw::CV_PATCH>(p, st);
-        return nw::launch_conv_cfg<4, 4, 2, nw::CV_GATHER>(p, st);
+    // The largest tile that still gives ~3/4 of the CUs a tile, else the smallest (the 14x14 and 7x7 layers are
+    // latency-bound: 42 x 196 pixels are 33 tiles of 256 pixels, or 129 of 64)
+    const int64_t want = (int64_t)nw::num_cus() * 3 / 4;
+    auto tiles = [&](int bm, int bn) { return ((int64_t)p.M + bm - 1) / bm * (Cout / bn); };
+#define NW_CONV_TRY(NA_, NB_, WM_, BM_, BN_, LAST_)                                                            \
+    if (Cout % BN_ == 0 && (LAST_ || tiles(BM_, BN_) >= want)) {                                               \
+        if (k33 && patch_fits(BM_) && !force_gather) return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_PATCH>(p, st); \
+        return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_GATHER>(p, st);                                       \
     }
-    if (Cout % 64 == 0) {
-        if (k33 && patch_fits(128) && !force_gather) return nw::launch_conv_cfg<4, 2, 1, nw::CV_PATCH>(p, st);
-        return nw::launch_conv_cfg<4, 2, 1, nw::CV_GATHER>(p, st);
-    }
-    if (k33 && patch_fits(256) && !force_gather) return nw::launch_conv_cfg<2, 4, 1, nw::CV_PATCH>(p, st);
-    return nw::launch_conv_cfg<2, 4, 1, nw::CV_GATHER>(p, st);
+    NW_CONV_TRY(4, 4, 2, 128, 128, false)
+    NW_CONV_TRY(4, 2, 1, 128, 64, false)
+    if (Cout % 64 == 0) { NW_CONV_TRY(4, 1, 1, 64, 64, true) }
+    NW_CONV_TRY(2, 4, 1, 256, 32, false)
+    NW_CONV_TRY(2, 2, 1, 128, 32, false)
+    NW_CONV_TRY(2, 1, 1, 64, 32, true)
+#undef NW_CONV_TRY
+    return NW_ERR_UNSUPPORTED;
 }

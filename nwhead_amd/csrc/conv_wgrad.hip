@@ -51,8 +51,8 @@ struct WgCfg {
     static constexpr int XRS = CIT * 4;                    // bytes of an x row in LDS
     static constexpr int NBG = 3;                          // gy stage buffers
     static constexpr int RING = TAPS9 ? 256 : 128;         // x rows in LDS
-    static constexpr int XAHEAD = TAPS9 ? 3 : 1;           // x is written this many stages ahead of gy's stage
-    static constexpr int XBEHIND = TAPS9 ? 3 : 0;          // ... and a stage reads x rows this many stages behind it
+    static constexpr int XAHEAD = TAPS9 ? 2 : 0;           // x is written this many stages ahead of gy's stage
+    static constexpr int XBEHIND = TAPS9 ? 2 : 0;          // ... and a stage reads x rows this many stages behind it
     static constexpr int NSET = 3;                         // register sets of loads in flight
     static constexpr size_t LDS = (size_t)NBG * 32 * GRS + (size_t)RING * XRS;
     static constexpr int GP = TAPS9 ? 1 : 2, XP = TAPS9 ? 1 : 2;   // passes of 256 lanes x 8 floats per stage
@@ -183,10 +183,11 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
                 }
             }
         };
-        // Loader step j writes gy stage j and x stage j + XAHEAD; consumer stage s reads gy(s) and the x stages
-        // s - XBEHIND .. s + XAHEAD, so it may start once the steps <= s are written.  Step j + 1 is written while the
-        // consumers work on stage j (its gy buffer and the ring rows it overwrites -- x stage j + 1 + XAHEAD - RING / 32 --
-        // are not read then); the loads of step j + NSET are issued into the registers step j leaves.
+        // Loader step j writes gy stage j and x stage j + XAHEAD.  Consumer stage s multiplies fragments it read during
+        // stage s - 1 and reads those of stage s + 1 (gy(s + 1), x stages s + 1 - XBEHIND .. s + 1 + XAHEAD), so it may
+        // start once the steps <= s + 1 are written; step s + 2 is written meanwhile (its gy buffer, and the ring rows it
+        // overwrites -- x stage s + 2 + XAHEAD - RING / 32 --, are not read then).  The loads of step j + NSET are issued
+        // into the registers step j leaves.
 #pragma unroll
         for (int u = 0; u < NSET; ++u) issue(ld[u], jb + u);
         for (int j = jb; j < s1; j += NSET) {
@@ -197,9 +198,10 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
                 write(ld[u], jj, jj + XAHEAD);
                 issue(ld[u], jj + NSET);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (jj >= s0) __builtin_amdgcn_s_barrier();   // releases consumer stage jj
+                if (jj >= s0 + 1) __builtin_amdgcn_s_barrier();   // releases consumer stage jj - 1
             }
         }
+        __builtin_amdgcn_s_barrier();                          // releases the last stage (its successor's rows are never used)
         __builtin_amdgcn_s_barrier();                          // the consumers' barrier behind their last stage
         return;
     }
@@ -233,52 +235,88 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
     for (int a = 0; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int wm = wave >> 1, wn = wave & 1;               // WIDE: 64 x 64 quadrant
-    __builtin_amdgcn_s_barrier();                          // stage s0 (and the x rows around it) is in LDS
-    for (int s = s0; s < s1; ++s) {
-        const char* gb = gbuf + ((unsigned)s % NBG) * (32 * GRS);
-        if (TAPS9) {
-            half8 ah[2], al[2];
+    constexpr int NA = TAPS9 ? 2 : 4, NBF = TAPS9 ? 9 : 4; // gy fragments per set; x fragments per stage (one per tap / column block)
+    constexpr int NSLOT = TAPS9 ? 3 : 4;                   // x fragments kept in registers
+    half8 ah[2][NA], al[2][NA], bh[NSLOT], bl[NSLOT];
+    // Fragments roll: the gy fragments of stage s + 1 are read into the other set at the start of stage s; x fragment f
+    // sits in slot f % NSLOT and the slot is refilled with fragment f + NSLOT (of the next stage, past the last one) as
+    // soon as its products have been issued -- every LDS read has NSLOT - 1 fragments' worth of matrix work to land under.
+    // Addresses of the transposed reads.  A lane's first row inside a 32-row stage is lr = 8 g + q, its second lr + 4; the
+    // unit swizzle depends on the row modulo 16 only, so everything but the stage's position in the ring is a per-lane
+    // constant: byte = ((32 st + k) & (RING - 1)) * XRS + c with k, c fixed per fragment; the l half sits 64 bytes from
+    // the h half (unit + 2 = unit ^ 2: h units have bit 1 clear).  (Computed per read this was ~500 VALU instructions per
+    // stage beside 54 MFMAs.)
+    const int lr = 8 * g + tq;
+    auto swz_c = [&](int row, int unit) { return ((unit ^ unit_swz(row)) << 5) + 8 * tp; };
+    int ga[NA], gb_[NA];                                    // gy: offsets inside a stage buffer
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                ah[a] = tr8(gb, GRS, 0, 31, unit_of(16 * a, false));
-                al[a] = tr8(gb, GRS, 0, 31, unit_of(16 * a, true));
-            }
+    for (int a = 0; a < NA; ++a) {
+        const int u = unit_of(TAPS9 ? 16 * a : 64 * wm + 16 * a, false);
+        ga[a] = lr * GRS + swz_c(lr, u);
+        gb_[a] = (lr + 4) * GRS + swz_c(lr + 4, u);
+    }
+    int xk[NBF], xa[NBF], xb[NBF];                          // x: row offset k, constants of the two reads
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int shift = (t / 3 - 1) * p.IP + (t % 3 - 1);
-                const int row0 = 32 * s + shift;
-                const half8 bh = tr8(xring, XRS, row0, RING - 1, unit_of(16 * wave, false));
-                const half8 bl = tr8(xring, XRS, row0, RING - 1, unit_of(16 * wave, true));
+    for (int f = 0; f < NBF; ++f) {
+        const int shift = TAPS9 ? (f / 3 - 1) * p.IP + (f % 3 - 1) : 0;
+        const int u = unit_of(TAPS9 ? 16 * wave : 64 * wn + 16 * f, false);
+        xk[f] = shift + lr;
+        xa[f] = swz_c(shift + lr, u);
+        xb[f] = swz_c(shift + lr + 4, u);
+    }
+    auto rd8 = [&](const char* pa, const char* pb) {
+        const halfx4w a = tr4(pa), bq = tr4(pb);
+        return half8{a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
+    };
+    auto load_a1 = [&](half8& h, half8& l, int a, int st) {
+        const char* gb = gbuf + ((unsigned)st % NBG) * (32 * GRS);
+        h = rd8(gb + ga[a], gb + gb_[a]);
+        l = rd8(gb + (ga[a] ^ 64), gb + (gb_[a] ^ 64));
+    };
+    auto load_a = [&](half8 (&h)[NA], half8 (&l)[NA], int st) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    acc[2 * t + a] = mm(al[a], bh, acc[2 * t + a]);
-                    acc[2 * t + a] = mm(ah[a], bl, acc[2 * t + a]);
-                    acc[2 * t + a] = mm(ah[a], bh, acc[2 * t + a]);
+        for (int a = 0; a < NA; ++a) load_a1(h[a], l[a], a, st);
+    };
+    auto load_b = [&](int slot, int f, int st) {
+        const int r = 32 * st + xk[f];
+        const int oa = ((r & (RING - 1)) * XRS) + xa[f], ob = (((r + 4) & (RING - 1)) * XRS) + xb[f];
+        bh[slot] = rd8(xring + oa, xring + ob);
+        bl[slot] = rd8(xring + (oa ^ 64), xring + (ob ^ 64));
+    };
+    auto stage = [&](half8 (&h)[NA], half8 (&l)[NA], half8 (&hn)[NA], half8 (&ln)[NA], int st) {
+        if (TAPS9) load_a(hn, ln, st + 1);
+#pragma unroll
+        for (int f = 0; f < NBF; ++f) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int k = TAPS9 ? 2 * f + a : 4 * a + f;
+                acc[k] = mm(l[a], bh[f % NSLOT], acc[k]);
+                acc[k] = mm(h[a], bl[f % NSLOT], acc[k]);
+                acc[k] = mm(h[a], bh[f % NSLOT], acc[k]);
+                if (!TAPS9 && f == NBF - 1) {   // WIDE keeps ONE set of gy fragments: each is refilled behind its last product
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_a1(h[a], l[a], a, st + 1);
                 }
             }
-        } else {
-            half8 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                ah[a] = tr8(gb, GRS, 0, 31, unit_of(64 * wm + 16 * a, false));
-                al[a] = tr8(gb, GRS, 0, 31, unit_of(64 * wm + 16 * a, true));
-                bh[a] = tr8(xring, XRS, 32 * s, RING - 1, unit_of(64 * wn + 16 * a, false));
-                bl[a] = tr8(xring, XRS, 32 * s, RING - 1, unit_of(64 * wn + 16 * a, true));
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[4 * a + c] = mm(al[a], bh[c], acc[4 * a + c]);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[4 * a + c] = mm(ah[a], bl[c], acc[4 * a + c]);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[4 * a + c] = mm(ah[a], bh[c], acc[4 * a + c]);
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the refill behind the products that still need the old fragment)
+            if (f + NSLOT < NBF) load_b(f % NSLOT, f + NSLOT, st);
+            else load_b(f % NSLOT, f + NSLOT - NBF, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         tile_barrier();
+    };
+    __builtin_amdgcn_s_barrier();                          // stages s0 and s0 + 1 (and the x rows around them) are in LDS
+    load_a(ah[0], al[0], s0);
+#pragma unroll
+    for (int f = 0; f < NSLOT; ++f) load_b(f, f, s0);
+    if (TAPS9) {
+        for (int s = s0; s < s1; s += 2) {
+            stage(ah[0], al[0], ah[1], al[1], s);
+            if (s + 1 >= s1) break;
+            stage(ah[1], al[1], ah[0], al[0], s + 1);
+        }
+    } else {
+        for (int s = s0; s < s1; ++s) stage(ah[0], al[0], ah[0], al[0], s);
     }
     // ---- partial tile: part[kc][co][t][ci]; acc[.][e] of lane (i, g) = C[row 4 g + e of its co block][column i of its ci block]
     float* out = p.part + (size_t)kc * p.Cout * p.T * p.Cin;
@@ -305,17 +343,28 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
     }
 }
 
-// dw[idx] = sum_k part[k][idx], chunk order
-__global__ __launch_bounds__(256) void nw_conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                    int64_t total4, int ks) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total4) return;
-    float4 a = reinterpret_cast<const float4*>(part)[idx];
-    for (int k = 1; k < ks; ++k) {
-        const float4 v = reinterpret_cast<const float4*>(part)[(int64_t)k * total4 + idx];
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+// dw[idx] = sum_k part[k][idx] in chunk order: 64 float4 columns x 16 chunk lanes per workgroup -- lane j adds the chunks
+// j, j + 16, ... (coalesced across the columns), the 16 partial sums are added in lane order through LDS (deterministic)
+__global__ __launch_bounds__(1024) void nw_conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                     int64_t total4, int ks) {
+    __shared__ float4 sh[16][64];
+    const int col = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int64_t idx = (int64_t)blockIdx.x * 64 + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < total4)
+        for (int k = j; k < ks; k += 16) {
+            const float4 v = reinterpret_cast<const float4*>(part)[(int64_t)k * total4 + idx];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    sh[j][col] = a;
+    __syncthreads();
+    if (j == 0 && idx < total4) {
+        for (int l = 1; l < 16; ++l) {
+            const float4 v = sh[l][col];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4*>(dw)[idx] = a;
     }
-    reinterpret_cast<float4*>(dw)[idx] = a;
 }
 
 struct WgPlan {
@@ -329,7 +378,7 @@ bool wgrad_plan(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int6
     if (n <= 0 || H <= 0 || W <= 0 || stride != 1 || KH != KW || (KH != 1 && KH != 3) || pad != (KH - 1) / 2) return false;
     if (Cin % 8 || Cout % 8 || Cin < 8 || Cout < 8) return false;
     pl->taps9 = KH == 3;
-    if (pl->taps9 && W > 78) return false;                 // a tap shift (W + 2 rows) must stay within three 32-row stages
+    if (pl->taps9 && W > 62) return false;                 // a tap shift (W + 2 rows) must stay within two 32-row stages
     pl->IP = (int)(pl->taps9 ? W + 1 : W);
     pl->IMG = (int)(pl->taps9 ? (H + 1) * (W + 1) : H * W);
     const int64_t V = n * pl->IMG;
@@ -339,8 +388,12 @@ bool wgrad_plan(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int6
     pl->co_tiles = (int)((Cout + cot - 1) / cot);
     pl->ci_tiles = (int)((Cin + cit - 1) / cit);
     const int64_t tiles = (int64_t)pl->co_tiles * pl->ci_tiles;
-    int64_t ks = (512 + tiles - 1) / tiles;                // ~512 workgroups
-    const int64_t maxks = (pl->nstage + 15) / 16;          // at least 16 stages per chunk
+    // ~one workgroup per CU, and no more chunks than the output tile is worth: the partial tiles cross memory twice
+    // (written, read by the reduction), 2 ks Cout T Cin floats against (Cout + Cin) 32 nstage read by the product
+    int64_t ks = (256 + tiles - 1) / tiles;
+    // at least 8 (3x3: 16, a chunk starts with four steps of rows around its first stage) stages per chunk: small planes are
+    // latency-bound and want many workgroups
+    const int64_t maxks = (pl->nstage + (pl->taps9 ? 15 : 7)) / (pl->taps9 ? 16 : 8);
     if (ks > maxks) ks = maxks;
     if (ks < 1) ks = 1;
     pl->spc = (int)((pl->nstage + ks - 1) / ks);
@@ -400,7 +453,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, c
     }
     if (pl.ks > 1) {
         const int64_t total4 = Cout * KH * KW * Cin / 4;
-        hipLaunchKernelGGL(nw_conv_wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(nw_conv_wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(1024), 0, st,
                            static_cast<const float*>(workspace), dw, total4, pl.ks);
     }
     NW_CHECK_LAUNCH();

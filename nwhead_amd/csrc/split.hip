@@ -124,3 +124,69 @@ extern "C" int nw_split_rows_f16x2(const float* x, float* out_split, float* row_
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out_split)) & 15) return NW_ERR_INVALID_ARG;
     return nw::launch_split_rows(x, out_split, row_scale, row_norm2, rows, d, static_cast<hipStream_t>(stream));
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// All convolution weights of a network -> the split-row operands of conv_nhwc.hip, in ONE launch per optimizer step
+// (the weights change every step; per convolution this was a permute, a flip and two split launches).
+// A job reads a torch (Cout, Cin, KH, KW) contiguous weight and writes one operand:
+//   mode 0  forward      rows = Cout, row co = [t][ci]               (the channels_last bytes of the weight)
+//   mode 1  data grad    rows = Cin,  row ci = [T - 1 - t][co]       (flipped taps, transposed channels)
+//   mode 2  few channels rows = Cout, row co = [ky][32: kx * 4 + ci] (ROWRUN4: Cin <= 4 padded to 4, a kernel row per chunk)
+// jobs (device, int64 x 10 per job): src address, split offset (floats), scale offset, first row (prefix sum), rows, cols,
+// Cin, Cout, T, KW | mode << 32
+namespace nw {
+namespace {
+
+__global__ __launch_bounds__(256) void nw_split_conv_weights_kernel(const int64_t* __restrict__ jobs, int njobs, int64_t total_rows,
+                                                                     float* __restrict__ split_base, float* __restrict__ scale_base) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= total_rows) return;
+    int lo = 0, hi = njobs - 1;                     // the job whose row range holds r
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[10 * mid + 3] <= r) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* jb = jobs + 10 * lo;
+    const float* src = reinterpret_cast<const float*>(jb[0]);
+    const int row = (int)(r - jb[3]), cols = (int)jb[5], Cin = (int)jb[6], Cout = (int)jb[7], T = (int)jb[8];
+    const int KW = (int)(jb[9] & 0xffffffff), mode = (int)(jb[9] >> 32);
+    auto at = [&](int k) -> float {
+        if (mode == 0) { const int t = k / Cin, ci = k - t * Cin; return src[((int64_t)row * Cin + ci) * T + t]; }
+        if (mode == 1) { const int t = k / Cout, co = k - t * Cout; return src[((int64_t)co * Cin + row) * T + (T - 1 - t)]; }
+        const int ky = k >> 5, j = k & 31, kx = j >> 2, ci = j & 3;
+        return (kx < KW && ci < Cin) ? src[((int64_t)row * Cin + ci) * T + ky * KW + kx] : 0.f;
+    };
+    float mx = 0.f;
+    for (int k = lane; k < cols; k += 64) mx = fmaxf(mx, fabsf(at(k)));
+    mx = wave_max(mx);
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) {
+        frexpf(mx, &e);
+        e = 14 - e;
+        if (e > 126) e = 126;
+    }
+    const float up = ldexpf(1.f, e);
+    if (lane == 0) scale_base[jb[2] + row] = ldexpf(1.f, -e);
+    _Float16* dst = reinterpret_cast<_Float16*>(split_base + jb[1] + (int64_t)row * cols);
+    for (int k = lane; k < cols; k += 64) {         // element k -> half (k % 32) of the 32-k chunk k / 32; l sits 32 halves on
+        const float v = at(k) * up;
+        const _Float16 h = (_Float16)v;
+        dst[(k >> 5) * 64 + (k & 31)] = h;
+        dst[(k >> 5) * 64 + 32 + (k & 31)] = (_Float16)(v - (float)h);
+    }
+}
+
+}  // namespace
+}  // namespace nw
+
+extern "C" int nw_split_conv_weights_f16x2(const int64_t* jobs, int64_t njobs, int64_t total_rows, float* split_base,
+                                           float* scale_base, void* stream) {
+    if (njobs < 0 || total_rows < 0) return NW_ERR_INVALID_ARG;
+    if (njobs == 0 || total_rows == 0) return NW_OK;
+    if (!jobs || !split_base || !scale_base || njobs > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(nw::nw_split_conv_weights_kernel, dim3((unsigned)((total_rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), jobs, (int)njobs, total_rows, split_base, scale_base);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}

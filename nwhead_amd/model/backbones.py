@@ -237,15 +237,17 @@ class _DenseBlock(nn.Module):
         for i in range(num_layers):
             self.add_module(f"denselayer{i + 1}", _DenseLayer(cin + i * growth_rate, growth_rate, bn_size, drop_rate))
 
-    def forward_nhwc_train(self, x):
+    def forward_nhwc_train(self, x, bank=None):
         """Channels-last training forward of the block (DenseNet._forward_nhwc_train): the running concatenation passes
         through norm1's autograd node like in forward() below."""
         from .. import ops
         cur = x
         for layer in self.children():
             a, cur = ops.bn_relu_train_nhwc(cur, layer.norm1, True, passthrough=True)
-            t = ops.bn_relu_train_nhwc(ops.conv2d_nhwc_train(a, layer.conv1.weight, 1, 0), layer.norm2)
-            new = ops.conv2d_nhwc_train(t, layer.conv2.weight, 1, 1)
+            o1 = bank.operands(layer.conv1.weight) if bank is not None else None
+            o2 = bank.operands(layer.conv2.weight) if bank is not None else None
+            t = ops.bn_relu_train_nhwc(ops.conv2d_nhwc_train(a, layer.conv1.weight, 1, 0, operands=o1), layer.norm2)
+            new = ops.conv2d_nhwc_train(t, layer.conv2.weight, 1, 1, operands=o2)
             if layer.drop_rate > 0:
                 new = F.dropout(new, layer.drop_rate, self.training)
             cur = torch.cat((cur, new), 1)
@@ -336,13 +338,20 @@ class DenseNet(nn.Module):
         amax record the following convolution scales its operand by), convolutions through ops.conv2d_nhwc_train."""
         from .. import ops
         f = self.features
-        y = ops.bn_relu_train_nhwc(ops.conv2d_nhwc_train(x, f.conv0.weight, 2, 3), f.norm0)
+        bank = getattr(self, "_nw_bank", None)
+        if bank is None or bank.weights[0] is not f.conv0.weight:
+            # every convolution weight's split-row operands (forward + data gradient), rebuilt by one launch per step
+            convs = [(m.weight, m is not f.conv0) for m in self.modules() if isinstance(m, nn.Conv2d)]
+            bank = self._nw_bank = ops.ConvWeightBank(convs)
+        bank.refresh()
+        y = ops.bn_relu_train_nhwc(ops.conv2d_nhwc_train(x, f.conv0.weight, 2, 3, operands=bank.operands(f.conv0.weight)), f.norm0)
         y = f.pool0(y)
         for mod in f.children():
             if isinstance(mod, _DenseBlock):
-                y = mod.forward_nhwc_train(y)
+                y = mod.forward_nhwc_train(y, bank)
             elif isinstance(mod, _Transition):
-                z = ops.conv2d_nhwc_train(ops.bn_relu_train_nhwc(y, mod.norm), mod.conv.weight, 1, 0)
+                z = ops.conv2d_nhwc_train(ops.bn_relu_train_nhwc(y, mod.norm), mod.conv.weight, 1, 0,
+                                          operands=bank.operands(mod.conv.weight))
                 y = mod.pool(z)
         y = ops.bn_relu_train_nhwc(y, f.norm5)          # (norm5 + the relu of DenseNet.forward)
         return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)

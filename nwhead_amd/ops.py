@@ -980,6 +980,89 @@ def bn_relu_train_nhwc(x, bn, relu=True, passthrough=False):
     return _BNReLUNhwcFn.apply(x, bn.weight, bn.bias, bn, bool(relu), bool(passthrough))
 
 
+class _WeightOperand:
+    """A split-row convolution operand inside a ConvWeightBank (the interface conv2d_nhwc reads: split, scale, shape)."""
+    __slots__ = ("split", "scale", "shape")
+
+    def __init__(self, split, scale, shape):
+        self.split, self.scale, self.shape = split, scale, shape
+
+
+class ConvWeightBank:
+    """The split-row operands of ALL convolution weights of a network -- forward and, for stride-1 convolutions whose input
+    needs a gradient, data-gradient (flipped taps, transposed channels) -- kept in two flat buffers and rebuilt by ONE
+    launch (nw_split_conv_weights_f16x2) whenever a weight has changed since the last build (an optimizer step)."""
+
+    def __init__(self, convs):
+        """convs: list of (weight parameter (Cout, Cin, KH, KW), needs_dgrad)."""
+        self.weights = [w for w, _ in convs]
+        self._want = [bool(d) for _, d in convs]
+        self._sig = None
+        self._build_tables()
+
+    def _build_tables(self):
+        dev = self.weights[0].device
+        jobs, views = [], []
+        off = soff = rows_total = 0
+        for w, want_dgrad in zip(self.weights, self._want):
+            cout, cin, kh, kw = w.shape
+            t = kh * kw
+            if not (w.is_contiguous() and w.dtype == torch.float32):
+                raise ValueError("ConvWeightBank needs contiguous fp32 weights")
+            entry = [None, None]
+            if cin % 32 == 0:
+                rows, cols, mode, shape = cout, t * cin, 0, (cout, cin, kh, kw)
+            elif cin <= 4 and kw * 4 <= 32:
+                rows, cols, mode, shape = cout, kh * 32, 2, (cout, 4, kh, kw)
+            else:
+                rows = None
+            if rows is not None:
+                jobs.append([w.data_ptr(), off, soff, rows_total, rows, cols, cin, cout, t, kw | (mode << 32)])
+                entry[0] = (off, soff, rows, cols, shape)
+                off, soff, rows_total = off + rows * cols, soff + rows, rows_total + rows
+            if want_dgrad and cin % 32 == 0 and cout % 32 == 0:
+                rows, cols = cin, t * cout
+                jobs.append([w.data_ptr(), off, soff, rows_total, rows, cols, cin, cout, t, kw | (1 << 32)])
+                entry[1] = (off, soff, rows, cols, (cin, cout, kh, kw))
+                off, soff, rows_total = off + rows * cols, soff + rows, rows_total + rows
+            views.append(entry)
+        self.split = torch.empty(max(off, 4), dtype=torch.float32, device=dev)
+        self.scale = torch.empty(max(soff, 4), dtype=torch.float32, device=dev)
+        self.jobs = torch.tensor(jobs, dtype=torch.int64).to(dev)
+        self.total_rows = rows_total
+        self._ops = {}
+        for w, entry in zip(self.weights, views):
+            made = []
+            for e in entry:
+                if e is None:
+                    made.append(None)
+                else:
+                    o_, so_, rows, cols, shape = e
+                    made.append(_WeightOperand(self.split[o_:o_ + rows * cols].view(rows, cols), self.scale[so_:so_ + rows], shape))
+            self._ops[id(w)] = tuple(made)
+        self._ptrs = tuple(w.data_ptr() for w in self.weights)
+
+    def refresh(self):
+        """Rebuild the operands if any weight changed (in place: its version; replaced: its address)."""
+        ptrs = tuple(w.data_ptr() for w in self.weights)
+        if ptrs != self._ptrs:
+            self._build_tables()
+            self._sig = None
+        sig = tuple(w._version for w in self.weights)
+        if sig == self._sig:
+            return
+        dev = self.split.device
+        with _OnDevice(dev):
+            _lib.check(_lib.load().nw_split_conv_weights_f16x2(_ptr(self.jobs), self.jobs.shape[0], self.total_rows,
+                                                               _ptr(self.split), _ptr(self.scale), _stream(self.split)),
+                       "nw_split_conv_weights_f16x2")
+        self._sig = sig
+
+    def operands(self, w):
+        """(forward operand, data-gradient operand or None) of weight parameter w."""
+        return self._ops[id(w)]
+
+
 _CONV_STATS = {"absmax_fallbacks": 0}
 
 
@@ -998,15 +1081,17 @@ class _ConvNhwcFn(torch.autograd.Function):
     weight and padding k - 1 - p), weight gradient through nw_conv2d_nhwc_wgrad_f16x2 when it serves the shape."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, amax):
+    def forward(ctx, x, weight, stride, pad, amax, operands):
         xv = x.detach()
         if xv.dtype != torch.float32 or not xv.is_contiguous(memory_format=torch.channels_last):
             xv = xv.float().contiguous(memory_format=torch.channels_last)
-        if amax is None:
+        fw = operands[0] if operands is not None and operands[0] is not None else SplitConvWeight(weight)
+        if amax is None and not (xv.shape[1] == 3 and fw.shape[1] == 4):   # (an RGB stem gets its record from the padding pass)
             amax = _amax_of(x)
-        y = conv2d_nhwc(xv, SplitConvWeight(weight), None, None, False, stride, pad, amax=amax)
-        ctx.save_for_backward(xv, weight, amax)
+        y = conv2d_nhwc(xv, fw, None, None, False, stride, pad, amax=amax)
+        ctx.save_for_backward(xv, weight, amax if amax is not None else torch.empty(0, device=xv.device))
         ctx.stride, ctx.pad = stride, pad
+        ctx.dgrad_operand = operands[1] if operands is not None else None
         return y
 
     @staticmethod
@@ -1024,14 +1109,16 @@ class _ConvNhwcFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if stride == 1 and kh == kw and kh - 1 - pad >= 0 and cout % 32 == 0 and cin % 32 == 0:
-                wt = weight.detach().flip(2, 3).transpose(0, 1)           # (cin, cout, kh, kw)
-                dx = conv2d_nhwc(g, SplitConvWeight(wt), None, None, False, 1, kh - 1 - pad, amax=gam)
+                dg = ctx.dgrad_operand
+                if dg is None:
+                    dg = SplitConvWeight(weight.detach().flip(2, 3).transpose(0, 1))     # (cin, cout, kh, kw)
+                dx = conv2d_nhwc(g, dg, None, None, False, 1, kh - 1 - pad, amax=gam)
             else:
                 dx = torch.ops.aten.convolution_backward(g, xv, weight, None, [stride, stride], [pad, pad], [1, 1], False,
                                                          [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = conv2d_nhwc_wgrad(xv, g, weight.shape, stride, pad, amax_x, gam)
-        return dx, dw, None, None, None
+            dw = conv2d_nhwc_wgrad(xv, g, weight.shape, stride, pad, amax_x if amax_x.numel() else None, gam)
+        return dx, dw, None, None, None, None
 
 
 def conv2d_nhwc_wgrad(x, gy, wshape, stride, pad, amax_x=None, amax_g=None):
@@ -1059,8 +1146,9 @@ def conv2d_nhwc_wgrad(x, gy, wshape, stride, pad, amax_x=None, amax_g=None):
                                                [False, True, False])[1]
 
 
-def conv2d_nhwc_train(x, weight, stride=1, pad=0, amax=None):
+def conv2d_nhwc_train(x, weight, stride=1, pad=0, amax=None, operands=None):
     """Differentiable conv2d(x, weight, stride=stride, padding=pad) for channels-last fp32 activations on the MI355X
-    (bias-free: the backbones' convolutions have none).  x may carry `.nw_amax`."""
+    (bias-free: the backbones' convolutions have none).  x may carry `.nw_amax`; operands: ConvWeightBank.operands(weight)
+    (else the weight is split inside the call, forward and backward)."""
     _need_hip(x, weight)
-    return _ConvNhwcFn.apply(x, weight, int(stride), int(pad), amax)
+    return _ConvNhwcFn.apply(x, weight, int(stride), int(pad), amax, operands)

@@ -1,0 +1,342 @@
+"""The channels-last convolution path on the fp16 matrix cores (csrc/conv_nhwc.hip, conv_wgrad.hip, bn_nhwc.hip; split-fp16
+operands, fp32-grade accuracy) against torch in fp64: forward (3x3 PATCH mode, 1x1 / strided GATHER mode, the stems' ROWRUN
+mode), weight gradient, data gradient, BatchNorm + ReLU forward / backward, the amax records, the batched weight split, and
+the backbones that use them (folded channels_last ResNets: BASELINE config 2 end to end; DenseNet training step)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 3e-6          # relative to the largest output: K up to 4608 products of fp32-grade (2^-22) accuracy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad, bias, res, relu
+    (2, 32, 8, 8, 32, 3, 1, 1, False, False, False),       # PATCH, 256-pixel tiles of 32 channels
+    (3, 64, 9, 7, 64, 3, 1, 1, True, True, True),          # PATCH, tiles crossing rows and images, ragged tail
+    (2, 64, 56, 56, 64, 3, 1, 1, True, True, True),        # ResNet layer1
+    (4, 128, 28, 28, 128, 3, 1, 1, True, True, True),      # layer2, 128 x 128 tiles
+    (9, 512, 7, 7, 512, 3, 1, 1, True, True, True),        # layer4: K = 4608
+    (3, 128, 56, 56, 32, 3, 1, 1, False, False, False),    # DenseNet conv2
+    (2, 64, 56, 56, 128, 1, 1, 0, True, False, True),      # GATHER: 1x1
+    (3, 256, 28, 28, 128, 1, 1, 0, False, False, False),
+    (2, 64, 56, 56, 128, 3, 2, 1, True, True, True),       # strided 3x3
+    (2, 64, 56, 56, 128, 1, 2, 0, True, False, False),     # strided 1x1 projection
+    (3, 992, 7, 7, 128, 1, 1, 0, False, False, False),     # DenseNet block 4 conv1
+    (2, 96, 10, 12, 64, 5, 1, 2, True, True, True),        # another kernel size through GATHER
+    (2, 32, 30, 30, 96, 3, 1, 0, True, True, True),        # 3x3 without padding
+    (3, 3, 64, 64, 64, 7, 2, 3, True, False, True),        # ROWRUN: the 7x7 / 2 stem over RGB (4-channel padded input)
+    (5, 3, 32, 32, 64, 3, 1, 1, True, False, True),        # CIFAR stem
+    (2, 1, 28, 28, 32, 5, 1, 2, True, False, True),        # one input channel: the scalar ROWRUN path
+]
+
+
+def _conv_case(dev, ops, case, seed=0):
+    n, cin, h, w, cout, k, stride, pad, bias, res, relu = case
+    g = torch.Generator().manual_seed(seed + 13 * cin + h)
+    x = _cl((torch.randn(n, cin, h, w, generator=g) * 1.7 + 0.3).to(dev))
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
+    b = torch.randn(cout, generator=g).to(dev) if bias else None
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    r = _cl(torch.randn(n, cout, ho, wo, generator=g).to(dev)) if res else None
+    y = ops.conv2d_nhwc(x, ops.SplitConvWeight(wt), b, r, relu, stride, pad)
+    ref = F.conv2d(x.double(), wt.double(), None if b is None else b.double(), stride, pad)
+    if r is not None:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.relu()
+    return y, ref
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_nhwc_against_torch_fp64(dev, case):
+    from nwhead_amd import ops
+    y, ref = _conv_case(dev, ops, case)
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.shape == ref.shape
+    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < TOL, err
+    # the amax record the store leaves: its maximum is max|y| exactly (per-workgroup maxima, no atomics)
+    assert y.nw_amax.shape == (ops.AMAX_SLOTS,)
+    assert float(y.nw_amax.max()) == float(y.abs().max())
+
+
+def test_conv2d_nhwc_many_tiles_per_workgroup():
+    """The persistent tile loop (loaders running ahead across tile boundaries) with 8 workgroups for up to 196 tiles:
+    NW_CONV_MAX_WGS is read once per process, hence the subprocess."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+            "import torch\nfrom nwhead_amd import ops\nimport test_conv_nhwc_gpu as t\n"
+            "dev = torch.device('cuda:0')\n"
+            "for case in t.CONV_CASES:\n"
+            "    y, ref = t._conv_case(dev, ops, case, seed=5)\n"
+            "    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()\n"
+            "    assert err < t.TOL, (case, err)\nprint('OK')\n" % (ROOT, ROOT))
+    env = dict(os.environ, NW_CONV_MAX_WGS="8")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_conv_scale_follows_the_amax_record(dev):
+    """One power of two per tensor from the amax record: a bound 1000x too large costs accuracy but stays finite and
+    close; activations of magnitude 1e-20 and 1e+20 go through (the scale brings them into fp16's range)."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(3)
+    wt = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(dev)
+    sw = ops.SplitConvWeight(wt)
+    for mag in (1e-20, 1.0, 1e20):
+        x = _cl((torch.randn(2, 64, 12, 12, generator=g) * mag).to(dev))
+        y = ops.conv2d_nhwc(x, sw, None, None, False, 1, 1)
+        ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+        assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < TOL
+    x = _cl(torch.randn(2, 64, 12, 12, generator=g).to(dev))
+    loose = ops.absmax(x) * 1000.0
+    y = ops.conv2d_nhwc(x, sw, None, None, False, 1, 1, amax=loose)
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-4
+
+
+def test_absmax_and_channel_padding(dev):
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(5, 3, 37, 41, generator=g).to(dev)
+    x[3, 1, 20, 7] = -9.5
+    for t in (x, _cl(x)):
+        a = ops.absmax(t)
+        assert a.shape == (ops.AMAX_SLOTS,) and float(a.max()) == 9.5
+        p = ops.to_nhwc_pad(t, 4)
+        assert p.shape == (5, 4, 37, 41) and p.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(p[:, :3], x) and float(p[:, 3].abs().max()) == 0.0 and float(p.nw_amax.max()) == 9.5
+
+
+WGRAD_CASES = [(2, 64, 8, 8, 128, 1), (3, 96, 14, 14, 128, 1), (2, 256, 28, 28, 128, 1), (2, 1024, 7, 7, 512, 1),
+               (2, 128, 8, 8, 32, 3), (3, 128, 14, 14, 32, 3), (2, 128, 56, 56, 32, 3), (5, 128, 7, 7, 32, 3),
+               (2, 64, 28, 28, 64, 3), (3, 40, 9, 11, 24, 3), (3, 40, 9, 11, 24, 1)]
+
+
+@pytest.mark.parametrize("n,cin,h,w,cout,k", WGRAD_CASES)
+def test_conv_weight_gradient_against_torch_fp64(dev, n, cin, h, w, cout, k):
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(n + cin + h)
+    x = _cl((torch.randn(n, cin, h, w, generator=g) + 0.2).to(dev))
+    gy = _cl(torch.randn(n, cout, h, w, generator=g).to(dev))
+    pad = (k - 1) // 2
+    dw = ops.conv2d_nhwc_wgrad(x, gy, (cout, cin, k, k), 1, pad)
+    assert dw.shape == (cout, cin, k, k)
+    ref = torch.ops.aten.convolution_backward(gy.double().contiguous(), x.double().contiguous(),
+                                              torch.empty(cout, cin, k, k, dtype=torch.float64, device=dev), None, [1, 1],
+                                              [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert (dw.double() - ref).abs().max().item() / ref.abs().max().item() < TOL
+    dw2 = ops.conv2d_nhwc_wgrad(x, gy, (cout, cin, k, k), 1, pad)
+    assert torch.equal(dw, dw2)                            # chunk sums added in a fixed order
+
+
+@pytest.mark.parametrize("n,cin,h,w,cout,k,stride,pad", [(3, 64, 14, 14, 128, 1, 1, 0), (2, 128, 28, 28, 32, 3, 1, 1),
+                                                         (2, 160, 14, 14, 128, 1, 1, 0), (2, 64, 28, 28, 128, 3, 2, 1),
+                                                         (2, 3, 32, 32, 64, 7, 2, 3)])
+def test_conv_autograd_node(dev, n, cin, h, w, cout, k, stride, pad):
+    """ops.conv2d_nhwc_train: forward, data gradient (the same kernel on the flipped, transposed weight; torch for the
+    strided shapes) and weight gradient against fp64 autograd, with and without a ConvWeightBank."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(cin + k)
+    x0 = _cl(torch.randn(n, cin, h, w, generator=g).to(dev))
+    w0 = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
+    x64, w64 = x0.double().requires_grad_(cin != 3), w0.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, stride, pad)
+    t = torch.randn(y64.shape, generator=g).to(dev)
+    (y64 * t.double()).sum().backward()
+    wp = torch.nn.Parameter(w0.clone())
+    for bank in (None, ops.ConvWeightBank([(wp, cin != 3)])):
+        wp.grad = None
+        x = x0.clone().requires_grad_(cin != 3)
+        if bank is not None:
+            bank.refresh()
+        y = ops.conv2d_nhwc_train(x, wp, stride, pad, operands=None if bank is None else bank.operands(wp))
+        (y * _cl(t)).sum().backward()
+        assert (y.double() - y64).abs().max().item() / y64.abs().max().item() < TOL
+        assert (wp.grad.double() - w64.grad).abs().max().item() / w64.grad.abs().max().item() < 2e-5
+        if cin != 3:
+            assert (x.grad.double() - x64.grad).abs().max().item() / x64.grad.abs().max().item() < 2e-5
+
+
+def test_weight_bank_operands_equal_the_per_weight_split(dev):
+    """nw_split_conv_weights_f16x2 (one launch for all weights) writes the very bytes SplitConvWeight does, forward and
+    data-gradient layouts, and follows in-place updates."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(9)
+    ws = [torch.nn.Parameter((torch.randn(s, generator=g) * 10 ** float(e)).to(dev))
+          for s, e in (((64, 3, 7, 7), 0), ((128, 64, 1, 1), -3), ((32, 128, 3, 3), 2), ((96, 160, 1, 1), 0))]
+    bank = ops.ConvWeightBank([(w, i > 0) for i, w in enumerate(ws)])
+    for rnd in range(2):
+        bank.refresh()
+        for i, w in enumerate(ws):
+            fw, dg = bank.operands(w)
+            one = ops.SplitConvWeight(w)
+            assert fw.shape == one.shape and torch.equal(fw.split.view(-1), one.split.view(-1)) and torch.equal(fw.scale, one.scale)
+            if i > 0 and w.shape[0] % 32 == 0:
+                t = ops.SplitConvWeight(w.detach().flip(2, 3).transpose(0, 1))
+                assert dg.shape == t.shape and torch.equal(dg.split.view(-1), t.split.view(-1)) and torch.equal(dg.scale, t.scale)
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.5).add_(0.01)
+
+
+@pytest.mark.parametrize("n,c,h,w,prefix,relu", [(4, 64, 12, 12, 0, True), (3, 160, 7, 7, 32, True), (2, 32, 30, 17, 0, False),
+                                                (6, 256, 14, 14, 0, True), (2, 1024, 7, 7, 0, True)])
+def test_bn_relu_nhwc_train_against_fp64(dev, n, c, h, w, prefix, relu):
+    """nw_bn_relu_nhwc_train_fwd/bwd: outputs, running statistics, dx, dgamma, dbeta against fp64 torch, also on a channel
+    prefix of a wider channels-last tensor (row stride > c) and with a pass-through gradient."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(c + h)
+    full = _cl((torch.randn(n, c + prefix, h, w, generator=g) * 2.0 + 0.7).to(dev))
+    x0 = full[:, :c]
+    bn = torch.nn.BatchNorm2d(c).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    ref = torch.nn.BatchNorm2d(c).to(dev).double().train()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    x = x0.detach().clone().requires_grad_(True) if prefix == 0 else x0.detach().requires_grad_(True)
+    y = ops.bn_relu_train_nhwc(x, bn, relu)
+    t = torch.randn(y.shape, generator=g).to(dev)
+    (y * t).sum().backward()
+    x64 = x0.detach().double().requires_grad_(True)
+    y64 = ref(x64)
+    y64 = y64.relu() if relu else y64
+    (y64 * t.double()).sum().backward()
+    sc = lambda a: max(float(a.detach().abs().max()), 1e-12)
+    assert (y.double() - y64).abs().max().item() < 2e-6 * sc(y64)
+    assert float(y.nw_amax.max()) == float(y.detach().abs().max())
+    assert (x.grad.double() - x64.grad).abs().max().item() < 1e-5 * sc(x64.grad)
+    assert (bn.weight.grad.double() - ref.weight.grad).abs().max().item() < 1e-5 * sc(ref.weight.grad)
+    assert (bn.bias.grad.double() - ref.bias.grad).abs().max().item() < 1e-5 * sc(ref.bias.grad)
+    assert (bn.running_mean.double() - ref.running_mean).abs().max().item() < 1e-6 * sc(ref.running_mean)
+    assert (bn.running_var.double() - ref.running_var).abs().max().item() < 1e-5 * sc(ref.running_var)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_bn_nhwc_statistics_on_awkward_channels(dev):
+    """Constant channels, an offset 1e3 with spread 1e-2, a rounding-sized ripple: the chunk moments (shifted sums merged
+    with Chan's formula) keep the variance where E[x^2] - E[x]^2 loses it."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 8, 24, 24, generator=g)
+    x[:, 0] = 3.25
+    x[:, 1] = 1000.0 + 0.01 * torch.randn(8, 24, 24, generator=g)
+    x[:, 2] = 7.0 + 1e-6 * torch.randn(8, 24, 24, generator=g)
+    x[:, 3] = 1e-3 * torch.randn(8, 24, 24, generator=g) - 50.0
+    xd = _cl(x.to(dev))
+    bn = torch.nn.BatchNorm2d(8).to(dev).train()
+    y = ops.bn_relu_train_nhwc(xd, bn, False)
+    ref = F.batch_norm(x.double(), None, None, bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu(), True, 0.1, bn.eps)
+    # the 1e3-offset channel: an fp32 mean near 1000 is known to 3e-5, i.e. 3e-3 of the channel's spread of 1e-2
+    assert (y.detach().cpu().double() - ref).abs().max().item() < 6e-3
+    # (channels 2 and 3: spreads of 1e-6 / 1e-3 under eps = 1e-5, so 1 / sqrt(var + eps) ~ 300 multiplies the half-ulp of an
+    #  fp32 mean near 7 / 50)
+    assert (y.detach().cpu().double()[:, [2, 3]] - ref[:, [2, 3]]).abs().max().item() < 1e-3
+    assert (y.detach().cpu().double()[:, [0, 4, 5, 6, 7]] - ref[:, [0, 4, 5, 6, 7]]).abs().max().item() < 2e-5
+    var = x.double().var((0, 2, 3), unbiased=True)
+    assert ((bn.running_var.cpu().double() - (0.9 + 0.1 * var)).abs() / (0.9 + 0.1 * var)).max().item() < 1e-4
+
+
+def test_densenet_training_step_nhwc_against_fp64(dev):
+    """DenseNet-121's training forward + backward on the channels-last path (own convolutions: forward, data and weight
+    gradient; own BatchNorm + ReLU) against the same network in fp64 (torch, NCHW) -- and it is at least as close to it
+    as the NCHW path (MIOpen convolutions) is.  96x96 inputs, batch 6: 3x3 maps at the end, well-conditioned enough."""
+    import copy
+    import nwhead_amd.model.backbones as BB
+    from nwhead_amd.model import load_model
+    torch.manual_seed(0)
+    net = load_model("densenet121").to(dev).train()
+    x = torch.randn(6, 3, 96, 96, device=dev)
+    t = torch.randn(6, net.num_features, device=dev)
+
+    def run(model, xx, tt, nhwc):
+        old = BB.NHWC_TRAINING
+        BB.NHWC_TRAINING = nhwc
+        try:
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.reset_running_stats()
+            model.zero_grad(set_to_none=True)
+            out = model(xx)
+            (out * tt).sum().backward()
+        finally:
+            BB.NHWC_TRAINING = old
+        return out.detach().double(), torch.cat([p.grad.detach().double().flatten() for p in model.parameters()])
+
+    net64 = copy.deepcopy(net).double()
+    old = BB.FUSED_BN_RELU_TRAINING
+    BB.FUSED_BN_RELU_TRAINING = False
+    try:
+        o64, g64 = run(net64, x.double(), t.double(), False)
+    finally:
+        BB.FUSED_BN_RELU_TRAINING = old
+    o0, g0 = run(net, x, t, False)
+    o1, g1 = run(net, x, t, True)
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))
+    e0 = ((o0 - o64).abs().max() / o64.abs().max()).item()
+    e1 = ((o1 - o64).abs().max() / o64.abs().max()).item()
+    assert e1 < 1e-4 and e1 < 3 * e0 + 1e-6, (e0, e1)
+    c0, c1 = cos(g0, g64), cos(g1, g64)
+    assert c1 > 0.9999 and (1 - c1) < 3 * (1 - c0) + 1e-7, (c0, c1)
+
+
+@pytest.mark.parametrize("folding", [False, True])
+def test_k2_resnet18_plus_head_end_to_end(dev, folding):
+    """BASELINE configs[1] end to end: load_model('resnet18') @224, 64 queries, a bank of N = 1000
+    supports in C = 200 classes through NWNet.precompute() + predict('full') -- plain, and with enable_bn_folding (the
+    channels-last copy whose every convolution runs in nw_conv2d_nhwc_f16x2) -- against the same network on the host with
+    the oracle head (reference call order: train.py:290-297, nw.py:118-160).  Tolerance: an fp64 run of the network sits
+    ~2e-6 (relative, features) from the host's fp32 run; the log-probabilities see that through distances of ~30."""
+    from oracle import nw_oracle as O
+    from nwhead_amd.model import load_model
+    from nwhead_amd.nwhead.nw import NWNet
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(2)
+    n_sup, C = 1000, 200
+    sup_x = torch.randn(n_sup, 3, 64, 64, generator=g)       # the bank's images (64x64: 1000 images @224 would be 600 MB)
+    sup_y = torch.arange(n_sup) % C
+
+    class DS(torch.utils.data.Dataset):
+        targets = sup_y.tolist()
+
+        def __len__(self):
+            return n_sup
+
+        def __getitem__(self, i):
+            return sup_x[i], int(sup_y[i])
+
+    net = NWNet(load_model("resnet18"), C, support_dataset=DS(), feat_dim=512, n_shot_full=5, device="cuda:0").to(dev).eval()
+    if folding:
+        net.enable_bn_folding(True)
+    host = load_model("resnet18").eval()
+    host.load_state_dict(net.featurizer.state_dict())
+    xq = torch.randn(64, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        net.precompute()
+        out = net.predict(xq.to(dev), mode="full")
+        torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+        fq = host(xq)
+        order = np.argsort(np.asarray(sup_y), kind="stable")   # the balanced, class-sorted bank of precompute()
+        fs = host(sup_x[order])
+        ref = O.nw_head_f64(fq, fs, sup_y[order], C)
+    assert out.shape == (64, C) and net.full_feat.shape == (n_sup, 512)
+    assert torch.equal(net.full_y.cpu(), sup_y[order])
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-3, err
+    assert (out.argmax(-1).cpu() == ref.argmax(-1)).float().mean().item() > 0.98

@@ -108,4 +108,15 @@ if __name__ == "__main__":
         timeit(42, 512, 28, 28, 128, 1, 1, 0)
         timeit(42, 128, 28, 28, 32, 3, 1, 1)
         timeit(42, 1024, 14, 14, 128, 1, 1, 0)
+    if mode == "small":      # the latency-bound layers of DenseNet-121's last blocks (forward, and the data-gradient shapes)
+        timeit(42, 128, 14, 14, 32, 3, 1, 1)
+        timeit(42, 32, 14, 14, 128, 3, 1, 1)
+        timeit(42, 512, 14, 14, 128, 1, 1, 0)
+        timeit(42, 128, 14, 14, 512, 1, 1, 0)
+        timeit(42, 128, 7, 7, 32, 3, 1, 1)
+        timeit(42, 32, 7, 7, 128, 3, 1, 1)
+        timeit(42, 800, 7, 7, 128, 1, 1, 0)
+        timeit(42, 128, 7, 7, 800, 1, 1, 0)
+        timeit(42, 32, 56, 56, 128, 3, 1, 1)
+        timeit(42, 128, 56, 56, 256, 1, 1, 0)
     sys.exit(0 if ok else 1)
