@@ -44,21 +44,33 @@ def make_inputs(B, N, d, C, dev, seed=0):
     return q.to(dev), s.to(dev), sy.to(dev)
 
 
-PMC_FILE = "profiles/r02_bench_pmc.json"   # rocprofv3 --pmc passes of `bench.py --skip-extras` (tools/prof_bench.sh)
+PMC_FILE = "profiles/r03_bench_pmc.json"   # rocprofv3 --pmc passes of `bench.py --skip-extras` (tools/prof_bench.sh)
+PMC_FILE_T = "profiles/r03_T_forward_pmc.json"   # ... of the T-shape forward (tools/prof.sh)
 
 
-def pmc_traffic(kernel):
+def pmc_entry(kernel, pmc_file=None):
+    """The committed rocprofv3 PMC record of `kernel` (tools/save_profile.py: counters per full-size dispatch, the
+    dispatch duration inside the counter passes, the clock and matrix-pipe occupancy derived from them), or None."""
+    try:
+        for k, v in json.load(open(os.path.join(ROOT, pmc_file or PMC_FILE))).items():
+            if kernel in k:
+                return v
+    except Exception:
+        pass
+    return None
+
+
+def pmc_traffic(kernel, pmc_file=None):
     """(HBM bytes per launch of `kernel`, source) from the committed rocprofv3 PMC passes of this very command
     (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE; counters cannot be collected inside a timed run), or
     (None, why).  The file belongs to one round: a stale profile is named, never silently mixed with fresh timings."""
-    path = os.path.join(ROOT, PMC_FILE)
-    try:
-        for k, v in json.load(open(path)).items():
-            if kernel in k and "hbm_bytes_per_launch" in v:
-                return v["hbm_bytes_per_launch"], PMC_FILE
-    except Exception as e:
-        return None, f"{PMC_FILE}: {type(e).__name__}"
-    return None, f"{PMC_FILE}: no entry for {kernel}"
+    pmc_file = pmc_file or PMC_FILE
+    v = pmc_entry(kernel, pmc_file)
+    if v is None:
+        return None, f"{pmc_file}: no entry for {kernel}"
+    if "hbm_bytes_per_launch" not in v:
+        return None, f"{pmc_file}: no HBM counters for {kernel}"
+    return v["hbm_bytes_per_launch"], pmc_file
 
 
 def time_kernel_events(fn, iters, warmup=3, min_warm_ms=30.0):
@@ -96,7 +108,19 @@ def measure_shape(B, N, d, C, dev, iters):
     t_gen = time_kernel_events(lambda: ops.nw_head(q, s, sy, C), iters)
     t_sc = t_fwd
     fl = alg_flops(B, N, d)
+    # the tile kernel alone (HIP events on its launch stream inside the library, nw_debug_tile_timing)
+    import ctypes
+    from nwhead_amd import _lib
+    lib = _lib.load()
+    lib.nw_debug_tile_timing(1)
+    for _ in range(20):
+        ops.nw_head(q, s, sy, C, support_cache=cache)
+    tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    lib.nw_debug_tile_timing_read(ctypes.byref(tot), ctypes.byref(cnt))
+    lib.nw_debug_tile_timing(0)
+    t_tile = tot.value / max(cnt.value, 1) * 1e-6
     return {"B": B, "N": N, "d": d, "C": C, "ms_per_call": t_fwd * 1e3, "query_pred_per_s": B / t_fwd,
+            "tile_kernel_us": t_tile * 1e6, "tile_kernel_us_note": "HIP-event pair around the tile kernel: ~5 us of event overhead at this size",
             "ms_per_call_fp32_mfma_cached_norms": t_n32 * 1e3,
             "ms_per_call_generic_forward_no_cache": t_gen * 1e3,
             "alg_GBps": alg_bytes(B, N, d, C) / t_fwd / 1e9, "frac_hbm": alg_bytes(B, N, d, C) / t_fwd / 1e9 / PEAK_HBM_GBS,
@@ -234,9 +258,11 @@ def measure_latency(bank, q, iters=50):
 
 
 def measure_backbone_configs(dev):
-    """BASELINE configs[1] and [3] end to end (backbones are torch/MIOpen fp32: plumbing around the head):
-    K2 = ResNet-18 + head, predict over 64 images @224 against a 1000-row bank; K4 = DenseNet-121 training
-    step (joint forward of 32 queries + 10 supports @224, NLL loss, backward through the HIP head, SGD)."""
+    """BASELINE configs[1] and [3] end to end: K2 = ResNet-18 + head, predict over 64 images @224 against a 1000-row
+    bank (plain: torch / MIOpen; what NWNet.predict runs after enable_bn_folding: the channels_last copy whose every
+    convolution is nw_conv2d_nhwc_f16x2); K4 = DenseNet-121 training step (joint forward of 32 queries + 10 supports
+    @224 on the channels-last path: own convolutions forward / data / weight gradient, own BatchNorm + ReLU; NLL loss,
+    backward through the HIP head, SGD), with NW_NHWC_TRAINING-off (NCHW, MIOpen convolutions) beside it."""
     import torch.nn.functional as F
     from nwhead_amd.model import load_model
     from nwhead_amd.nwhead.kernel import get_kernel
@@ -269,6 +295,8 @@ def measure_backbone_configs(dev):
                                                "backbone_TFLOPs": gf / t / 1e3,
                                                "frac_of_fp32_mfma_peak": gf / t / 1e3 / PEAK_F32_MFMA_TFLOPS,
                                                "ms_per_call_bn_folded_channels_last": tf * 1e3,
+                                               "backbone_bn_folded_channels_last": "nw_conv2d_nhwc_f16x2 (split-fp16 MFMA, fp32-grade)",
+                                               "backbone_TFLOPs_bn_folded_channels_last": gf / tf / 1e3,
                                                "images_per_s_bn_folded_channels_last": 64 / tf,
                                                "frac_of_fp32_mfma_peak_bn_folded_channels_last":
                                                    gf / tf / 1e3 / PEAK_F32_MFMA_TFLOPS}
@@ -290,11 +318,23 @@ def measure_backbone_configs(dev):
             loss = F.nll_loss(head(feats[:32], feats[32:], ys), yq)
             loss.backward()
             opt.step()
-        t = time_kernel_events(k4, 8, warmup=10)    # MIOpen's first calls of a configuration run slow stand-in kernels
+        t = time_kernel_events(k4, 8, warmup=10)
         gf4 = 5.67 * 3 * 42                                   # GFLOP, DenseNet-121 fwd+bwd over 32 + 10 images @224
+        import nwhead_amd.model.backbones as BB
+        t_nchw = None
+        if BB.NHWC_TRAINING:                                  # the NCHW path (MIOpen convolutions) beside it
+            BB.NHWC_TRAINING = False
+            try:
+                t_nchw = time_kernel_events(k4, 5, warmup=10)   # MIOpen's first calls of a configuration run slow stand-in kernels
+            finally:
+                BB.NHWC_TRAINING = True
         out["config_K4_densenet121_train_step"] = {"B": 32, "n_way": 10, "n_shot": 1, "ms_per_step": t * 1e3,
-                                                   "backbone": "torch/MIOpen fp32", "backbone_TFLOPs": gf4 / t / 1e3,
-                                                   "frac_of_fp32_mfma_peak": gf4 / t / 1e3 / PEAK_F32_MFMA_TFLOPS}
+                                                   "backbone": "channels-last: nw_conv2d_nhwc_f16x2 / nw_conv2d_nhwc_wgrad_f16x2 "
+                                                               "(split-fp16 MFMA, fp32-grade) + nw_bn_relu_nhwc_train_*"
+                                                               if BB.NHWC_TRAINING else "torch/MIOpen fp32 (NCHW)",
+                                                   "backbone_TFLOPs": gf4 / t / 1e3,
+                                                   "frac_of_fp32_mfma_peak": gf4 / t / 1e3 / PEAK_F32_MFMA_TFLOPS,
+                                                   "ms_per_step_nchw_miopen": None if t_nchw is None else t_nchw * 1e3}
         # the inference side of the same backbone (precompute / predict): plain eval vs the folded copy whose
         # BatchNorm -> ReLU pairs run in nw_scale_shift_relu_f32
         from nwhead_amd.model import fold_batchnorm
@@ -376,6 +416,8 @@ def main():
                          "launch is 6.1 tiles per CU, i.e. 7 rounds for the work of 6.1")
     ap.add_argument("--min-warmup-ms", type=float, default=40.0,
                     help="the untimed warm-up lasts at least this long (device time): post-idle clock ramp")
+    ap.add_argument("--min-timed-ms", type=float, default=100.0, help="the timed region lasts at least this long")
+    ap.add_argument("--min-launches", type=int, default=100, help="... and at least this many coalesced launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="only the timed workload (for profiling)")
     args = ap.parse_args()
@@ -385,6 +427,8 @@ def main():
     # measurement); `steps` in the JSON line is what was timed, `steps_requested` what was asked for.
     steps_requested = args.steps
     args.steps = max(4 * args.bucket, -(-args.steps // args.bucket) * args.bucket)
+    # ... --steps is a MINIMUM: the timed region also lasts at least --min-timed-ms and --min-launches coalesced launches
+    # (fixed below, once a step's duration is known); `steps` in the line is what was timed
     # Library banners (RCCL prints its version block to stdout when the first communicator comes up)
     # must not land next to the JSON line: stdout is pointed at stderr until the line is printed.
     sys.stdout.flush()
@@ -480,6 +524,14 @@ def main():
         run(extra)
         warm_steps += 8 * args.bucket + extra
     warm_steps += args.bucket   # (the bucket in front of the collection)
+    # the timed region: at least --steps steps, --min-launches whole launches and --min-timed-ms of device time
+    want = max(args.steps, args.min_launches * args.bucket, int(args.min_timed_ms / per_step_ms) + 1)
+    want = -(-want // args.bucket) * args.bucket
+    if use_dist:                                       # one count for all ranks
+        cnt = torch.tensor([want], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        want = int(cnt.item())
+    args.steps = want
     # ... and one untimed rehearsal of the timed call itself (same number of steps, same chunking): whatever the
     # caching allocator or the exchange ring still has to grow for THIS pattern grows here (measured: a 30 ms stall
     # inside an 8.7 ms timed region when the first 32-bucket chunk of a process was the timed one)
@@ -524,6 +576,7 @@ def main():
         persistent = fast and Bl * n_shard >= 64 * 128 * 1024
         kname = "nw_fused_f16p_kernel" if persistent else "nw_fused_kernel"
         traffic, traffic_src = pmc_traffic(kname)
+        pmc = pmc_entry(kname) or {}
         ach = flops / t_sc / 1e12
         roof = {"bound": "mfma",
                 "kernel": kname,
@@ -543,6 +596,12 @@ def main():
                 "alg_frac_fp16_peak": ach / PEAK_F16_MFMA_TFLOPS,
                 "achieved_vs_fp32_mfma_peak": flops / t_sc / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "kernel_us": t_sc * 1e6, "kernel_launches_timed": cnt.value,
+                # from the committed counter passes of this command (cannot be collected inside a timed run): the shader
+                # clock the kernel's waves saw, the share of their cycles the matrix pipe was busy, the dispatch duration
+                # in those passes; an s_memtime / s_memrealtime diagnostic build of the same launch agrees
+                "clock_GHz": pmc.get("clock_GHz_from_wave_cycles"), "clock_GHz_grbm": pmc.get("clock_GHz_from_grbm"),
+                "mfma_busy_frac": pmc.get("mfma_busy_frac_of_wave_cycles"),
+                "kernel_us_in_pmc_passes": pmc.get("duration_us_in_pmc_passes"), "clock_source": PMC_FILE,
                 "launch_us": t_all * 1e6,
                 "launch_note": "launch_us = query split + run tables + tile kernel + run merge (one partial forward)",
                 "alg_flops_per_launch": flops,
@@ -564,7 +623,33 @@ def main():
                            "B": B, "N_support": N, "d": d, "C": C, "parallelism": f"support-shard x{world}"},
                 "roofline": roof}
         if world == 1 and not args.skip_extras:
-            line["north_star_T"] = measure_shape(256, 10000, 512, 200, dev, 100)
+            line["north_star_T"] = T_ = measure_shape(256, 10000, 512, 200, dev, 100)
+            # the north-star shape as a roofline block of its own: the tile kernel at T
+            kT = "nw_fused_kernel"
+            trT, trT_src = pmc_traffic(kT, PMC_FILE_T)
+            flT = 2.0 * 256 * 10000 * 512
+            # the kernel's own duration: from the committed rocprofv3 kernel trace of this shape (an event pair around a
+            # 17 us kernel adds ~5 us of its own: `tile_kernel_us_events` in north_star_T); live figure: the whole op
+            kus, kus_src = T_["tile_kernel_us"], "HIP events around the launch (includes ~5 us of event overhead)"
+            try:
+                import csv
+                for r in csv.DictReader(open(os.path.join(ROOT, "profiles/r03_T_forward_stats.csv"))):
+                    if r["kernel"].startswith(kT + "<"):
+                        kus, kus_src = float(r["avg_us"]), "profiles/r03_T_forward_stats.csv (rocprofv3 --kernel-trace --stats)"
+                        break
+            except Exception:
+                pass
+            achT = flT / (kus * 1e-6) / 1e12
+            line["roofline_T"] = {"bound": "mfma", "kernel": kT, "kernel_us": kus, "kernel_us_source": kus_src,
+                                  "whole_op_us": T_["ms_per_call"] * 1e3,
+                                  "achieved": achT, "unit": "TFLOP/s", "peak": PEAK_SPLIT_F16_TFLOPS, "frac": achT / PEAK_SPLIT_F16_TFLOPS,
+                                  "frac_vs_fp32_mfma_bound": achT / PEAK_F32_MFMA_TFLOPS,
+                                  "whole_op_frac_split_fp16": flT / (T_["ms_per_call"] * 1e-3) / 1e12 / PEAK_SPLIT_F16_TFLOPS,
+                                  "whole_op_frac_vs_fp32_mfma_bound": flT / (T_["ms_per_call"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                  "alg_bytes": alg_bytes(256, 10000, 512, 200), "alg_flops": flT,
+                                  "traffic": trT, "traffic_source": trT_src, "operands": "split-fp16x2",
+                                  "peak_note": "peak = 2500 / 3 TFLOP/s as in `roofline` (three fp16 products per fp32 multiply-add); "
+                                               "frac_vs_fp32_mfma_bound is against SURVEY 8d's fp32 compute bound (16.7 us at T)"}
             line["config_K2_head"] = measure_shape(64, 1000, 512, 200, dev, 100)
             line["config_K5_support_influence"] = measure_influence(256, 10000, 200, dev)
             line["config_K5_support_influence"]["B4096"] = {k: v for k, v in measure_influence(4096, 10000, 200, dev, iters=20).items()

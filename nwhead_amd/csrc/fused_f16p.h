@@ -30,6 +30,7 @@ namespace {
 
 #ifdef NW_DIAG_FUSED  // diagnostic build only (tools/bench_fused.hip): per-workgroup phase totals
 __device__ unsigned long long nw_diag_p[8 * 1024];
+__device__ unsigned long long nw_diag_rt[2 * 1024];   // s_memrealtime (100 MHz) at the first / last stamp of a workgroup
 #define NW_PSTAMP(k)                                                                         \
     do {                                                                                     \
         unsigned long long now_;                                                             \
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
         int par = 0;     // header buffer of the current tile
 #ifdef NW_DIAG_FUSED
         unsigned long long diag_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-        const unsigned long long first_ = last_;
+        const unsigned long long first_ = last_, first_rt_ = __builtin_amdgcn_s_memrealtime();
 #endif
         for (int T = cu; T < n_local; T += n_cu) {
             int qt, st;
@@ -587,6 +588,8 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
         if (tid == 0 && blockIdx.x < 1024) {
             for (int k = 0; k < 7; ++k) nw_diag_p[8 * blockIdx.x + k] = diag_[k];
             nw_diag_p[8 * blockIdx.x + 7] = last_ - first_;
+            nw_diag_rt[2 * blockIdx.x] = first_rt_;
+            nw_diag_rt[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         }
 #endif
     }

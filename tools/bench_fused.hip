@@ -88,6 +88,17 @@ int main(int argc, char** argv) {
         double ph[8] = {0}; int n = 0;
         const int nwg = persistent_variant() == 1 ? 512 : 256;
         for (int b = 0; b < nwg; ++b) { ++n; for (int k = 0; k < 8; ++k) ph[k] += (double)hp[8 * b + k]; }
+        {   // the clock the kernel itself saw: shader ticks per 100 MHz real-time tick, per workgroup (LAST launch)
+            std::vector<unsigned long long> rt(2 * 1024);
+            hipMemcpyFromSymbol(rt.data(), HIP_SYMBOL(nw_diag_rt), rt.size() * 8);
+            std::vector<double> ghz;
+            for (int b = 0; b < nwg; ++b)
+                if (rt[2 * b + 1] > rt[2 * b]) ghz.push_back((double)hp[8 * b + 7] / (double)(rt[2 * b + 1] - rt[2 * b]) * 0.1);
+            std::sort(ghz.begin(), ghz.end());
+            if (!ghz.empty())
+                printf("in-kernel clock (ticks / s_memrealtime, per workgroup): median %.3f GHz, min %.3f, max %.3f; wave lifetime %.1f us\n",
+                       ghz[ghz.size() / 2], ghz.front(), ghz.back(), ph[7] / n / (ghz[ghz.size() / 2] * 1e3));
+        }
         printf("persistent kernel %.2f us | per WG (s_memtime ticks): main loops %.0f | epilogue: header reads %.0f, scores %.0f, mask+max+exp+den %.0f, run sums+stores %.0f, m/den stores %.0f, rest %.0f | total %.0f\n",
                ms * 10, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, ph[7] / n);
         return 0;
