@@ -465,6 +465,12 @@ def main():
     lo, hi = shard_bounds(N, world, rank)
     bank = ShardedBank(s[lo:hi].clone(), sy[lo:hi].clone(), C)
     del s
+    if use_dist:   # every rank must ship the same row layout: one class-window width for all (ShardedBank's all-gather)
+        cls = torch.tensor([bank.CL], dtype=torch.int64, device=dev)
+        allc = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, cls)
+        assert bool((allc == bank.CL).all()), f"class-window widths differ across ranks: {allc.tolist()}"
+    backend_used = (os.environ.get("NW_DIST_BACKEND", "nccl") if use_dist else None)
     # one bucket of distinct query batches, back to back in one staging buffer (predict_stream then hands the
     # bucket to the kernels as a view instead of concatenating it)
     gq = torch.Generator().manual_seed(123)
@@ -610,6 +616,8 @@ def main():
                 "alg_GBps": alg_bytes(Bl, n_shard, d, C) / t_all / 1e9}
         line = {"metric": "query-predictions/sec", "value": args.steps * B / dt, "unit": "query-predictions/s",
                 "n_gpus": world, "steps": args.steps, "steps_requested": steps_requested, "warmup": args.warmup,
+                "rccl_ranks": world if backend_used == "nccl" else 0, "dist_backend": backend_used,
+                "class_window": bank.CL, "persistent_wgs": bank.persistent_wgs,
                 "warmup_steps_run": warm_steps,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f32", "operands": "split-fp16x2 (fp32 accumulate)" if fast else "f32",

@@ -15,7 +15,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue
  *     work on it: they never synchronise, never allocate, never free;
  *   - return value: NW_OK (0) or a negative nw_status; nothing is thrown;
- *   - stateless and thread-safe: safe from any host thread with its own stream;
+ *   - stateless and thread-safe: safe from any host thread with its own stream; every option of a call is an argument
+ *     of that call (nw_fwd_opts), and the library never reads the process environment.  The one piece of process state is
+ *     the table of diagnostic knobs (nw_debug_set, nw_debug_tile_timing): timing experiments, unset in normal use;
  *   - scratch memory is supplied by the caller; ask nw_*_workspace_bytes() for the size.
  */
 #ifndef NWHEAD_HIP_H
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NW_ABI_VERSION 1
+#define NW_ABI_VERSION 2
 
 /* score functions = the reference's kernel modules, nwhead/kernel.py:80-97 (get_kernel) */
 typedef enum {
@@ -103,6 +105,23 @@ int nw_split_rows_f16x2(const float *x, float *out_split, float *row_scale, floa
  *   weights_out optional (B,N): softmax weights  (the `sweights` of util/metric.py:23)
  *   workspace   nw_fwd_workspace_bytes(B,N,d,C) bytes of scratch (may be NULL if that is 0)
  * ------------------------------------------------------------------------------------------- */
+/* Options of one forward call (NULL = all defaults).  struct_size = sizeof(nw_fwd_opts) of the caller's header.
+ *   tables / tables_bytes  run tables of a RESIDENT bank (labels that do not change between calls), built once with
+ *               nw_bank_tables_build(sy, N, C, ...) for the very sy, N and C of this call: on large launches the forward
+ *               walks the bank in tiles of 128 supports and needs, per tile, the runs of equal consecutive labels; without
+ *               tables it builds them in its workspace on every call (~5 us + a kernel boundary)
+ *   persistent_wgs  workgroups of the persistent tile kernel, a multiple of 8; 0 = one per CU.  Sharded inference passes
+ *               CUs - 8 (one CU per XCD left to the concurrent RCCL kernel)
+ *   force_split nonzero: the split-fp16 path whenever the bank is prepared, also below ~2e8 multiply-adds */
+typedef struct nw_fwd_opts {
+    uint32_t struct_size;
+    int32_t persistent_wgs;
+    int32_t force_split;
+    int32_t reserved;
+    const void *tables;
+    size_t tables_bytes;
+} nw_fwd_opts;
+
 size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C);
 int nw_fwd_f32(const float *q, const float *s, const int64_t *sy, const float *s_norm2,
                const float *s_split, const float *s_scale,
@@ -110,7 +129,7 @@ int nw_fwd_f32(const float *q, const float *s, const int64_t *sy, const float *s
                void *workspace, size_t workspace_bytes,
                int64_t B, int64_t N, int64_t d, int64_t C,
                int kind, const float *logit_scale_dev,
-               int sup_batched, int labels_batched, void *stream);
+               int sup_batched, int labels_batched, const nw_fwd_opts *opts, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sharded 'full' inference (new capability): per-shard partials of the same
@@ -133,22 +152,18 @@ int nw_fwd_partial_f32(const float *q, const float *s, const int64_t *sy, const 
                        float *m, float *den, float *num,
                        void *workspace, size_t workspace_bytes,
                        int64_t B, int64_t N, int64_t d, int64_t C,
-                       int kind, const float *logit_scale_dev, void *stream);
+                       int kind, const float *logit_scale_dev, const nw_fwd_opts *opts, void *stream);
 int nw_merge_finalize_f32(const float *m, const float *den, const float *num, float *out,
                           int64_t G, int64_t B, int64_t C,
                           int64_t stride_m, int64_t stride_den, int64_t stride_num,
                           const int64_t *class_lo, int64_t C_local, void *stream);
 
-/* Run tables of a RESIDENT bank (labels that do not change between calls).  On large launches the forward walks the
- * bank in tiles of 128 supports and needs, per tile, the runs of equal consecutive labels; it builds these tables in
- * its workspace on every call (~5 us + a kernel boundary) unless the caller has built them once:
- *     tables = malloc(nw_bank_tables_bytes(N));  nw_bank_tables_build(sy, N, C, tables, bytes, stream);
- *     ... per call:  nw_bank_tables_hint(tables, bytes, sy, N, C);  nw_fwd_f32(...) / nw_fwd_partial_f32(...)
- * The hint names the tables for the NEXT forward call of the calling thread only (thread-local, dropped when that
- * call returns, used only if sy / N / C are the ones it is called with); passing tables == NULL drops it. */
+/* Run tables of a RESIDENT bank for nw_fwd_opts.tables:
+ *     tables = malloc(nw_bank_tables_bytes(N));  nw_bank_tables_build(sy, N, C, tables, bytes, stream);   (once)
+ *     opts.tables = tables; opts.tables_bytes = bytes;  nw_fwd_f32(..., &opts, stream)                     (per call)
+ * Labels outside [0, C) are kept out of the tables like everywhere else (they contribute nothing). */
 size_t nw_bank_tables_bytes(int64_t N);
 int nw_bank_tables_build(const int64_t *sy, int64_t N, int64_t C, void *tables, size_t tables_bytes, void *stream);
-int nw_bank_tables_hint(const void *tables, size_t tables_bytes, const int64_t *sy, int64_t N, int64_t C);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -223,7 +238,7 @@ int nw_fwd_influence_f32(const float *q, const float *s, const int64_t *sy, cons
                          float *out, float *lse_out, float *infl_out,
                          void *workspace, size_t workspace_bytes,
                          int64_t B, int64_t N, int64_t d, int64_t C,
-                         int kind, const float *logit_scale_dev, void *stream);
+                         int kind, const float *logit_scale_dev, const nw_fwd_opts *opts, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The k best supports per query.  Replaces the full descending argsort that the reference cuts to
@@ -419,6 +434,11 @@ int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, 
  * summed elapsed time and the number of launches since the last read, and clears both.
  * ------------------------------------------------------------------------------------------- */
 int nw_debug_tile_timing(int enable);
+/* Diagnostic knobs (timing experiments; process-wide; never needed in normal use).  Names: pvar, qg, tile_rs, merge_mq,
+ * merge_per_query, merge_no_global_tables, persistent_any_rs, no_persistent, split_queries, bwd_no_mfma, bwd_split,
+ * coeff_threads, xgemm_wgs, xgemm_nbuf, split_lbits, conv_gather, conv_max_wgs.  The Python layer forwards
+ * the NW_<NAME> environment variables once, when it loads the library; the library itself never reads the environment. */
+int nw_debug_set(const char *name, int value);
 int nw_debug_tile_timing_read(double *total_us, int64_t *launches);
 
 #ifdef __cplusplus

@@ -29,12 +29,11 @@ SIGNATURES = {
     "nw_fwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "nw_row_norm2_f32": (_int, [_p, _p, _i64, _i64, _p]),
     "nw_split_rows_f16x2": (_int, [_p, _p, _p, _p, _i64, _i64, _p]),
-    "nw_fwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
-    "nw_fwd_partial_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _p]),
+    "nw_fwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p, _p]),
+    "nw_fwd_partial_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i64, _i64, _i64, _i64, _int, _p, _p, _p]),
     "nw_merge_finalize_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     "nw_bank_tables_bytes": (_sz, [_i64]),
     "nw_bank_tables_build": (_int, [_p, _i64, _i64, _p, _sz, _p]),
-    "nw_bank_tables_hint": (_int, [_p, _sz, _p, _i64, _i64]),
     "nw_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int, _int]),
     "nw_bwd_f32": (_int, [_p] * 10 + [_p, _sz, _i64, _i64, _i64, _i64, _int, _p, _int, _int, _p]),
     "nw_bwd_uses_split": (_int, [_i64, _i64, _i64, _i64, _int]),
@@ -42,7 +41,7 @@ SIGNATURES = {
     "nw_support_influence_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "nw_aggregate_f32": (_int, [_p] * 5 + [_i64, _i64, _i64, _int, _p]),
     "nw_aggregate_bwd_f32": (_int, [_p] * 6 + [_i64, _i64, _i64, _int, _p]),
-    "nw_fwd_influence_f32": (_int, [_p] * 11 + [_sz, _i64, _i64, _i64, _i64, _int, _p, _p]),
+    "nw_fwd_influence_f32": (_int, [_p] * 11 + [_sz, _i64, _i64, _i64, _i64, _int, _p, _p, _p]),
     "nw_topk_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "nw_scale_shift_relu_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "nw_bias_act_nhwc_f32": (_int, [_p, _p, _p, _int, _p, _i64, _i64, _p]),
@@ -66,6 +65,7 @@ SIGNATURES = {
     "nw_bn_nhwc_workspace_bytes": (_sz, [_i64, _i64]),
     "nw_bn_relu_nhwc_train_fwd_f32": (_int, [_p, _i64] + [_p] * 10 + [_sz, _i64, _i64, C.c_float, C.c_float, _int, _p]),
     "nw_bn_relu_nhwc_train_bwd_f32": (_int, [_p, _i64] + [_p] * 9 + [_i64, _p, _p, _sz, _i64, _i64, _int, _p]),
+    "nw_debug_set": (_int, [C.c_char_p, _int]),
     "nw_debug_tile_timing": (_int, [_int]),
     "nw_debug_tile_timing_read": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
@@ -95,10 +95,47 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.nw_abi_version() != 1:
+    if lib.nw_abi_version() != 2:
         raise NWHipError("libnwhead_hip.so ABI version mismatch")
     _lib = lib
+    sync_knobs()
     return lib
+
+
+class FwdOpts(C.Structure):
+    """nw_fwd_opts (include/nwhead_hip.h): the options of ONE forward call."""
+    _fields_ = [("struct_size", C.c_uint32), ("persistent_wgs", C.c_int32), ("force_split", C.c_int32),
+                ("reserved", C.c_int32), ("tables", C.c_void_p), ("tables_bytes", C.c_size_t)]
+
+
+# Environment switches of the Python layer (the C library never reads the environment).  NW_SPLIT_ALWAYS travels in every
+# forward call's nw_fwd_opts; the others are diagnostic knobs, forwarded once at load time (and again by sync_knobs()).
+KNOBS = ("pvar", "qg", "tile_rs", "merge_mq", "merge_per_query", "merge_no_global_tables", "persistent_any_rs", "no_persistent",
+         "split_queries", "bwd_no_mfma", "bwd_split", "coeff_threads", "xgemm_wgs", "xgemm_nbuf", "split_lbits", "conv_gather",
+         "conv_max_wgs")
+_KNOB_UNSET = -2 ** 31
+_knob_state = {}
+
+
+def sync_knobs():
+    """Forward the NW_<KNOB> environment variables to the library's diagnostic knobs (nw_debug_set)."""
+    if _lib is None:
+        return
+    for k in KNOBS:
+        v = os.environ.get("NW_" + k.upper())
+        val = _KNOB_UNSET if v is None or v == "" else int(v)
+        if _knob_state.get(k, _KNOB_UNSET) != val:
+            _lib.nw_debug_set(k.encode(), val)
+            _knob_state[k] = val
+
+
+def force_split():
+    return os.environ.get("NW_SPLIT_ALWAYS", "") == "1"
+
+
+def fwd_opts(tables=None, tables_bytes=0, persistent_wgs=0):
+    """An nw_fwd_opts for one forward call (a ctypes object: keep it alive across the call)."""
+    return FwdOpts(C.sizeof(FwdOpts), int(persistent_wgs), int(force_split()), 0, tables, int(tables_bytes))
 
 
 def check(status: int, what: str):

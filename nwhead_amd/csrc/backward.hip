@@ -551,7 +551,7 @@ struct BwdWs {
 };
 // Shared support, float4-able rows and enough work to fill the chip: the two products run on the matrix cores.
 bool bwd_use_mfma(int64_t B, int64_t N, int64_t d, int sup_batched) {
-    static const bool off = [] { const char* e = getenv("NW_BWD_NO_MFMA"); return e && e[0] == '1'; }();
+    const bool off = knob(KNOB_BWD_NO_MFMA) == 1;
     return !off && !sup_batched && d % 4 == 0 && B * N * d >= (int64_t)1 << 22;
 }
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -560,8 +560,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // supports and the queries) have to pay: at B=256, N=10000, d=512 the backward's kernels take 64 us against 157 on the
 // fp32 cores.
 bool bwd_use_split(int64_t B, int64_t N, int64_t d, int64_t C, int sup_batched) {
-    const char* env = getenv("NW_BWD_SPLIT");   // 0 off, 1 wherever possible; read per call (tests switch it)
-    const int mode = env ? atoi(env) : -1;
+    const int mode = knob(KNOB_BWD_SPLIT) == KNOB_UNSET ? -1 : knob(KNOB_BWD_SPLIT);   // 0 off, 1 wherever possible
     if (mode == 0 || !bwd_use_mfma(B, N, d, sup_batched) || d % 32 != 0) return false;
     const int64_t ld = (N + 31) / 32 * 32;
     if ((size_t)(80 + ld + C) * sizeof(float) > 150 * 1024) return false;
@@ -676,7 +675,7 @@ extern "C" int nw_bwd_bank_f32(const float* q, const float* s, const float* s_no
     const size_t need = bwd_layout(B, N, d, C, sup_batched, static_cast<char*>(workspace), &ws);
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
     const size_t lds = (80 + (size_t)C + (ws.split ? (size_t)ws.ld : 0)) * sizeof(float);
-    static const int coeff_env = [] { const char* e = getenv("NW_COEFF_THREADS"); return e ? atoi(e) : 0; }();   // timing experiments
+    const int coeff_env = knob(KNOB_COEFF_THREADS);   // timing experiments
     const unsigned coeff_threads = (coeff_env == 256 || coeff_env == 512 || coeff_env == 1024) ? (unsigned)coeff_env : (N >= 2048 ? 1024 : 256);
     if (lds > 160 * 1024) return NW_ERR_UNSUPPORTED;
     const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(s) |

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void nw_xgemm_reduce_kernel(const float* __res
 }
 
 int xgemm_target_wgs() {
-    static const int v = [] { const char* e = getenv("NW_XGEMM_WGS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
-    return v;
+    const int v = knob(KNOB_XGEMM_WGS);
+    return v > 0 ? v : 256;
 }
 
 }  // namespace
@@ -390,7 +390,7 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
     if (nwg + pend.blocks > 0x7fffffffLL || gy * gz > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
     const dim3 grid((unsigned)(nwg + pend.blocks));
     // ring depth: deep and one workgroup per CU when there are at most ~one workgroup per CU anyway and K is long
-    static const int nbuf_env = [] { const char* e = getenv("NW_XGEMM_NBUF"); return e ? atoi(e) : 0; }();
+    const int nbuf_env = knob(KNOB_XGEMM_NBUF) == KNOB_UNSET ? 0 : knob(KNOB_XGEMM_NBUF);
     const bool deep = nbuf_env ? nbuf_env == 6 : (gx * gy * gz <= 320 && p.k_chunk >= 6 * XK);
     // more than two workgroups per CU's worth of tiles: two stages each, so that three are resident per CU and the whole
     // grid runs in one round (second product at T, 632 workgroups of 8 stages: 17.7 us against 20.3 with three stages)

@@ -10,10 +10,50 @@ inline bool bad_kind(int kind) { return kind < NW_SCORE_EUCLIDEAN || kind > NW_S
 
 // Below ~2e8 multiply-adds the fp32-MFMA path with cached norms was the shorter one while the split-fp16 path
 // had a query-split launch in front (measured then: B=64 N=1000 d=512 19.7 vs 29.8 us; B=256 N=10000 d=512
-// 36.1 vs 23.9 us).  NW_SPLIT_ALWAYS=1 forces the split path.
+// 36.1 vs 23.9 us).  nw_fwd_opts.force_split takes the split path at every size.
 static bool split_pays(int64_t B, int64_t N, int64_t d) {
-    static const bool always = [] { const char* e = getenv("NW_SPLIT_ALWAYS"); return e && e[0] == '1'; }();
-    return always || (double)B * (double)N * (double)d >= 2.0e8;
+    return nw::fwd_opts().force_split || (double)B * (double)N * (double)d >= 2.0e8;
+}
+
+namespace nw {
+namespace {
+thread_local FwdOpts tl_fwd_opts;     // of the forward entry point this thread is inside (OptsGuard), defaults outside
+int g_knobs[KNOB_COUNT];
+bool g_knobs_init = [] { for (int& k : g_knobs) k = KNOB_UNSET; return true; }();
+const char* const knob_names[KNOB_COUNT] = {
+    "pvar", "qg", "tile_rs", "merge_mq", "merge_per_query", "merge_no_global_tables", "persistent_any_rs", "no_persistent",
+    "split_queries", "bwd_no_mfma", "bwd_split", "coeff_threads", "xgemm_wgs", "xgemm_nbuf", "split_lbits", "conv_gather",
+    "conv_max_wgs"};
+}  // namespace
+const FwdOpts& fwd_opts() { return tl_fwd_opts; }
+int knob(int id) { return (id >= 0 && id < KNOB_COUNT) ? __atomic_load_n(&g_knobs[id], __ATOMIC_RELAXED) : KNOB_UNSET; }
+}  // namespace nw
+
+namespace {
+struct OptsGuard {   // the call's options are visible to the launch code of this thread until the entry point returns
+    nw::FwdOpts saved;
+    explicit OptsGuard(const nw_fwd_opts* o) : saved(nw::tl_fwd_opts) {
+        nw::FwdOpts f;
+        if (o && o->struct_size >= sizeof(nw_fwd_opts)) {
+            f.tables = static_cast<const char*>(o->tables);
+            f.tables_bytes = o->tables_bytes;
+            f.persistent_wgs = o->persistent_wgs;
+            f.force_split = o->force_split;
+        }
+        nw::tl_fwd_opts = f;
+    }
+    ~OptsGuard() { nw::tl_fwd_opts = saved; }
+};
+}  // namespace
+
+extern "C" int nw_debug_set(const char* name, int value) {
+    if (!name) return NW_ERR_INVALID_ARG;
+    for (int k = 0; k < nw::KNOB_COUNT; ++k)
+        if (!strcmp(name, nw::knob_names[k])) {
+            __atomic_store_n(&nw::g_knobs[k], value, __ATOMIC_RELAXED);
+            return NW_OK;
+        }
+    return NW_ERR_INVALID_ARG;
 }
 
 extern "C" int nw_abi_version(void) { return NW_ABI_VERSION; }
@@ -72,18 +112,12 @@ extern "C" int nw_row_norm2_f32(const float* x, float* n2, int64_t rows, int64_t
     return nw::launch_rownorm2(x, n2, rows, d, static_cast<hipStream_t>(stream));
 }
 
-namespace {
-struct HintGuard {   // the run-table hint names tables for ONE forward call
-    ~HintGuard() { nw::bank_tables_drop(); }
-};
-}  // namespace
-
 extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, const float* s_norm2,
                           const float* s_split, const float* s_scale, float* out, float* scores_out, float* lse_out, float* weights_out, void* workspace,
                           size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C,
                           int kind, const float* logit_scale_dev, int sup_batched,
-                          int labels_batched, void* stream) {
-    HintGuard hint_guard;
+                          int labels_batched, const nw_fwd_opts* opts, void* stream) {
+    OptsGuard opts_guard(opts);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (bad_kind(kind)) return NW_ERR_UNSUPPORTED;
@@ -104,7 +138,7 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, con
             if (!lse) lse = reinterpret_cast<float*>(static_cast<char*>(workspace) + nw_fwd_workspace_bytes(B, N, d, C) -
                                                      align256((size_t)B * sizeof(float)));
             const int rc = nw_fwd_f32(q, s, sy, s_norm2, s_split, s_scale, out, sc_buf, lse, nullptr, workspace,
-                                      workspace_bytes, B, N, d, C, kind, logit_scale_dev, 0, 0, stream);
+                                      workspace_bytes, B, N, d, C, kind, logit_scale_dev, 0, 0, opts, stream);
             if (rc != NW_OK) return rc;
             return nw::launch_weights_from_scores(sc_buf, lse, weights_out, B, N, st);
         }
@@ -132,8 +166,8 @@ extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t*
                                   const float* s_norm2, const float* s_split, const float* s_scale,
                                   float* m, float* den, float* num, void* workspace, size_t workspace_bytes,
                                   int64_t B, int64_t N, int64_t d, int64_t C, int kind,
-                                  const float* logit_scale_dev, void* stream) {
-    HintGuard hint_guard;
+                                  const float* logit_scale_dev, const nw_fwd_opts* opts, void* stream) {
+    OptsGuard opts_guard(opts);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (bad_kind(kind)) return NW_ERR_UNSUPPORTED;
@@ -186,21 +220,21 @@ extern "C" int nw_fwd_influence_f32(const float* q, const float* s, const int64_
                                     const float* s_split, const float* s_scale, const int64_t* qy, float* out,
                                     float* lse_out, float* infl_out, void* workspace, size_t workspace_bytes,
                                     int64_t B, int64_t N, int64_t d, int64_t C, int kind,
-                                    const float* logit_scale_dev, void* stream) {
-    HintGuard hint_guard;
+                                    const float* logit_scale_dev, const nw_fwd_opts* opts, void* stream) {
+    OptsGuard opts_guard(opts);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (B < 0 || N < 0 || d < 0 || C < 0) return NW_ERR_INVALID_ARG;
     if (B == 0) return NW_OK;
     if (N == 0 || C == 0)   // no supports: log(0 + 1e-12) and nothing to score
         return nw_fwd_f32(q, s, sy, s_norm2, s_split, s_scale, out, nullptr, lse_out, nullptr, workspace, workspace_bytes,
-                          B, N, d, C, kind, logit_scale_dev, 0, 0, stream);
+                          B, N, d, C, kind, logit_scale_dev, 0, 0, opts, stream);
     if (!qy || !infl_out || !out) return NW_ERR_INVALID_ARG;
     const size_t need = nw_fwd_workspace_bytes(B, N, d, C);   // its last B floats: the log-sum-exp slot
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
     float* lse = lse_out ? lse_out : reinterpret_cast<float*>(static_cast<char*>(workspace) + need - align256((size_t)B * sizeof(float)));
     // scores into infl_out (fused tile kernel when eligible, else the score kernel of the two-kernel path)
     const int rc = nw_fwd_f32(q, s, sy, s_norm2, s_split, s_scale, out, infl_out, lse, nullptr, workspace,
-                              workspace_bytes, B, N, d, C, kind, logit_scale_dev, 0, 0, stream);
+                              workspace_bytes, B, N, d, C, kind, logit_scale_dev, 0, 0, opts, stream);
     if (rc != NW_OK) return rc;
     return nw::launch_influence(out, qy, infl_out, sy, lse, infl_out, B, N, C, st);
 }

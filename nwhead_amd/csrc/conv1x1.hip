@@ -422,7 +422,7 @@ extern "C" int nw_conv1x1_f32(const float* x, int64_t x_batch_stride, const floa
     if (x_batch_stride < cin * hw || out_batch_stride < cout * hw) return NW_ERR_INVALID_ARG;
     const int64_t ncols = n * hw;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const bool no_dma = [] { const char* e = getenv("NW_CONV1X1_NO_DMA"); return e && e[0] == '1'; }();
+    const bool no_dma = false;   // (the generic register-staged kernel serves the shapes the LDS-DMA kernel refuses)
     if (cin > 0 && !no_dma && conv1x1_dma_ok(x, x_batch_stride, w_t, cout, hw, ncols)) {
         const bool v16 = conv1x1_vec16(x, x_batch_stride, out, out_batch_stride, hw);
         const int tn = conv1x1_tn(ncols, cout, v16);

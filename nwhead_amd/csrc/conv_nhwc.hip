@@ -559,7 +559,7 @@ int launch_conv_cfg(ConvP p, hipStream_t st) {
     p.ntiles = p.Cout / C::BN;
     const int64_t total = (int64_t)p.mtiles * p.ntiles;
     int64_t grid = num_cus() < CV_AMAX_SLOTS ? num_cus() : CV_AMAX_SLOTS;
-    static const int cap = [] { const char* e = getenv("NW_CONV_MAX_WGS"); return e ? atoi(e) : 0; }();   // tests: many tiles per workgroup
+    const int cap = knob(KNOB_CONV_MAX_WGS);   // tests: many tiles per workgroup (diagnostic knob "conv_max_wgs")
     if (cap > 0 && grid > cap) grid = cap;
     if (grid > total) grid = total;
     grid = (grid + 7) / 8 * 8;
@@ -650,7 +650,7 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
         const int64_t rc = (BM - 1 + W - 1) / W, ic = (BM - 1 + H * W - 1) / (H * W);
         return BM + rc * (p.IP - W) + ic * pad * p.IP + 2 * p.IP + 2 <= BM + 192;
     };
-    static const int force_gather = [] { const char* e = getenv("NW_CONV_GATHER"); return e && e[0] == '1'; }();
+    const int force_gather = nw::knob(nw::KNOB_CONV_GATHER) == 1;
     if (Cin % 32) {   // ROWRUN: w_split is the split form of the (Cout, KH, 32) matrix [co][ky][kx * Cin + ci], zero-padded
         if (Cin == 4 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
             if (Cout % 64 == 0) return nw::launch_conv_cfg<4, 2, 1, nw::CV_ROWRUN4>(p, st);

@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 #include "fused_impl.h"
+#include <cstring>
 
 namespace nw {
 
@@ -83,21 +84,13 @@ int tile_timer_read(double* total_us, int64_t* launches) {
 }
 
 int persistent_variant() {
-    static int v = [] {
-        const char* e = getenv("NW_PVAR");
-        const int x = e ? atoi(e) : -1;
-        return (x >= 0 && x <= 2) ? x : -1;  // -1: chosen per launch
-    }();
-    return v;
+    const int x = knob(KNOB_PVAR);
+    return (x >= 0 && x <= 2) ? x : -1;  // -1: chosen per launch
 }
 
 int persistent_qgroup() {
-    static int v = [] {
-        const char* e = getenv("NW_QG");
-        const int x = e ? atoi(e) : 0;
-        return (x >= 1 && x <= 64) ? x : 8;
-    }();
-    return v;
+    const int x = knob(KNOB_QG);
+    return (x >= 1 && x <= 64) ? x : 8;
 }
 
 int device_cu_count() {
@@ -109,9 +102,13 @@ int device_cu_count() {
     }();
     return n;
 }
-bool env_flag(const char* name) {
-    const char* e = getenv(name);
-    return e && e[0] == '1';
+bool env_flag(const char* name) {   // (named after the variables the Python layer forwards: diagnostic knobs)
+    static const struct { const char* n; int k; } map[] = {
+        {"NW_MERGE_PER_QUERY", KNOB_MERGE_PER_QUERY}, {"NW_MERGE_NO_GLOBAL_TABLES", KNOB_MERGE_NO_GLOBAL_TABLES},
+        {"NW_PERSISTENT_ANY_RS", KNOB_PERSISTENT_ANY_RS}, {"NW_NO_PERSISTENT", KNOB_NO_PERSISTENT}};
+    for (const auto& m : map)
+        if (!strcmp(m.n, name)) return knob(m.k) == 1;
+    return false;
 }
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -451,11 +448,8 @@ __global__ __launch_bounds__(64) void nw_run_tables_kernel(const int64_t* __rest
 }
 
 int env_rs() {
-    static int v = [] {
-        const char* e = getenv("NW_TILE_RS");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
+    const int v = knob(KNOB_TILE_RS);
+    return v == KNOB_UNSET ? 0 : v;
 }
 
 }  // namespace
@@ -481,17 +475,9 @@ int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_
 }
 
 // A resident bank's run tables, built once (nw_bank_tables_build) instead of once per forward.  They depend on the
-// labels, N, C and the tile height only; the persistent kernel's tile is 128 supports.  The caller names them for ITS
-// NEXT forward call on this thread (nw_bank_tables_hint); the forward takes them if they are the tables of the very
-// label array, N and C it was given, and every forward entry point drops the hint when it returns.
+// labels, N, C and the tile height only; the persistent kernel's tile is 128 supports.  The caller passes them with the
+// call (nw_fwd_opts.tables): they must be the tables of the very label array, N and C of that call.
 constexpr int BANK_BS = 128;
-struct BankTablesHint {
-    const char* base = nullptr;
-    size_t bytes = 0;
-    const int64_t* sy = nullptr;
-    int64_t N = 0, C = 0;
-};
-thread_local BankTablesHint tl_hint;
 
 size_t bank_tables_layout(int64_t n_stiles, char* base, FusedWs* ws) {
     size_t off = 0;
@@ -514,13 +500,13 @@ size_t bank_tables_layout(int64_t n_stiles, char* base, FusedWs* ws) {
 }
 
 bool bank_tables_take(const int64_t* sy, int N, int C, int n_stiles, int BS, FusedWs* ws) {
-    const BankTablesHint h = tl_hint;
-    if (!h.base || BS != BANK_BS || h.sy != sy || h.N != N || h.C != C) return false;
-    if (h.bytes < bank_tables_layout(n_stiles, nullptr, nullptr)) return false;
-    bank_tables_layout(n_stiles, const_cast<char*>(h.base), ws);
+    (void)sy; (void)N; (void)C;
+    const FwdOpts& o = fwd_opts();
+    if (!o.tables || BS != BANK_BS) return false;
+    if (o.tables_bytes < bank_tables_layout(n_stiles, nullptr, nullptr)) return false;
+    bank_tables_layout(n_stiles, const_cast<char*>(o.tables), ws);
     return true;
 }
-void bank_tables_drop() { tl_hint = BankTablesHint(); }
 
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st) {
@@ -532,7 +518,7 @@ int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float
     // 32 queries x 16 tile lanes per workgroup when a query has few tiles (a shard of the bank), else 16 x 32;
     // below 512 queries one workgroup per query (T: 256 workgroups, one per CU)
     int mq = 1;
-    static const int force_mq = [] { const char* e = getenv("NW_MERGE_MQ"); return e ? atoi(e) : 0; }();   // timing experiments
+    const int force_mq = knob(KNOB_MERGE_MQ) == KNOB_UNSET ? 0 : knob(KNOB_MERGE_MQ);   // timing experiments
     if (force_mq == 1 || force_mq == 16 || force_mq == 32) {
         mq = force_mq;
         if (lds_bytes(mq, true) > cap) mq = 1;
@@ -656,17 +642,5 @@ extern "C" int nw_bank_tables_build(const int64_t* sy, int64_t N, int64_t C, voi
     FusedWs ws;
     if (tables_bytes < bank_tables_layout(n_stiles, static_cast<char*>(tables), &ws)) return NW_ERR_WORKSPACE;
     return launch_run_tables(ws, sy, (int)N, (int)C, (int)n_stiles, BANK_BS, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int nw_bank_tables_hint(const void* tables, size_t tables_bytes, const int64_t* sy, int64_t N, int64_t C) {
-    nw::bank_tables_drop();
-    if (!tables) return NW_OK;
-    if (!sy || N <= 0 || C < 0 || tables_bytes < nw_bank_tables_bytes(N)) return NW_ERR_INVALID_ARG;
-    nw::tl_hint.base = static_cast<const char*>(tables);
-    nw::tl_hint.bytes = tables_bytes;
-    nw::tl_hint.sy = sy;
-    nw::tl_hint.N = N;
-    nw::tl_hint.C = C;
-    return NW_OK;
 }
 

@@ -23,7 +23,6 @@ struct FusedWs {  // views into the caller's workspace
 size_t fused_layout(int64_t B, int64_t n_stiles, int BS, char* base, FusedWs* ws, int64_t C = 0);
 int launch_run_tables(const FusedWs& ws, const int64_t* sy, int N, int C, int n_stiles, int BS, hipStream_t st);
 bool bank_tables_take(const int64_t* sy, int N, int C, int n_stiles, int BS, FusedWs* ws);   // the caller's cached tables, if named for this call
-void bank_tables_drop();
 int launch_merge_runs(const FusedWs& ws, float* out, float* lse, float* m, float* den, float* num,
                       int B, int C, int n_stiles, int BS, hipStream_t st);
 // split form of the query batch in the tail of the forward workspace (fused.hip)
@@ -411,7 +410,7 @@ int launch_fused_rs(const float* q, const float* s, const int64_t* sy, const flo
         // (~5.4 k cycles at T); the split launch costs ~4.4 us + a kernel boundary once.  Measured per forward
         // (N = 10000, d = 512; raw / split launch): B = 256 20.2 / 21.8 us, 512 40.6 / 40.1, 768 52.7 / 50.4, 1000
         // 62.4 / 62.3: raw up to 1.5 workgroups per CU.  NW_SPLIT_QUERIES=1 / 0 forces either.
-        static const int force_split = [] { const char* e = getenv("NW_SPLIT_QUERIES"); return e ? atoi(e) : -1; }();
+        const int force_split = knob(KNOB_SPLIT_QUERIES) == KNOB_UNSET ? -1 : knob(KNOB_SPLIT_QUERIES);
         const bool raw_ok = force_split == 0 || (force_split < 0 && 2 * grid <= 3 * device_cu_count());
         if (persistent || !raw_ok) {
             float *qr, *qsc, *qn;
@@ -480,9 +479,9 @@ int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* 
     if constexpr (RS > 5) {
         (void)sy; (void)C;  // the run tables (launch_run_tables) are the caller's job
         int cus = device_cu_count() & ~7;  // the same number of workgroups on every XCD
-        // NW_PERSISTENT_WGS: fewer workgroups than CUs (a multiple of 8), e.g. to leave CUs to a concurrent RCCL kernel
-        // of the sharded path -- an experiment for a multi-GPU box, never measured here (one GPU)
-        static const int wg_cap = [] { const char* e = getenv("NW_PERSISTENT_WGS"); return e ? atoi(e) & ~7 : 0; }();
+        // nw_fwd_opts.persistent_wgs: fewer workgroups than CUs (a multiple of 8), to leave CUs to a concurrent RCCL kernel
+        // of the sharded path (ShardedBank leaves one CU per XCD when there is more than one rank)
+        const int wg_cap = fwd_opts().persistent_wgs & ~7;
         if (wg_cap >= 8 && wg_cap < cus) cus = wg_cap;
         // 0: 64-query tiles, one workgroup per CU; 1: two per CU; 2: 128-query tiles.  Measured at B = 2048,
         // N = 50000, d = 512 (tools/bench_fused.hip, same device): 387 / 353 / 337 us.  128-query tiles

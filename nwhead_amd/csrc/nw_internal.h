@@ -60,8 +60,25 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
                  const float* Xo, float* out, int64_t M, int64_t Nn, int64_t K, hipStream_t st,
                  XgemmReduce* defer = nullptr, const XgemmReduce* pending = nullptr);
 
+// Options of the forward call in progress on this thread (nw_fwd_opts of the ABI, set for the duration of the call by
+// the entry point): explicit arguments, not process state.
+struct FwdOpts {
+    const char* tables = nullptr;   // run tables of the call's labels (nw_bank_tables_build), or null
+    size_t tables_bytes = 0;
+    int persistent_wgs = 0;         // workgroups of the persistent tile kernel (0: one per CU)
+    int force_split = 0;            // split-fp16 path at every size
+};
+const FwdOpts& fwd_opts();
+// Diagnostic knobs (nw_debug_set; timing experiments, never needed in normal use).  KNOB_UNSET when not set.  The library
+// itself never reads the environment: the Python layer forwards NW_* variables once, at load time (_lib.py).
+constexpr int KNOB_UNSET = -2147483647 - 1;
+enum Knob { KNOB_PVAR, KNOB_QG, KNOB_TILE_RS, KNOB_MERGE_MQ, KNOB_MERGE_PER_QUERY, KNOB_MERGE_NO_GLOBAL_TABLES,
+            KNOB_PERSISTENT_ANY_RS, KNOB_NO_PERSISTENT, KNOB_SPLIT_QUERIES, KNOB_BWD_NO_MFMA, KNOB_BWD_SPLIT,
+            KNOB_COEFF_THREADS, KNOB_XGEMM_WGS, KNOB_XGEMM_NBUF, KNOB_SPLIT_LBITS, KNOB_CONV_GATHER, KNOB_CONV_MAX_WGS,
+            KNOB_COUNT };
+int knob(int id);
+
 // fused forward (fused.hip)
-void bank_tables_drop();   // forget the caller's run-table hint (nw_bank_tables_hint): every forward entry point, on return
 int launch_topk(const float* scores, int64_t* idx, float* vals, int64_t B, int64_t N, int64_t k, hipStream_t st);  // topk.hip
 int tile_timer_enable(bool on);
 int tile_timer_read(double* total_us, int64_t* launches);

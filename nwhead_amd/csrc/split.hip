@@ -98,15 +98,13 @@ int launch_split_rows(const float* x, float* out, float* scale, float* norm2, in
                       hipStream_t st) {
     if (rows <= 0) return NW_OK;
     if ((rows + 3) / 4 > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
-    static const unsigned lmask = [] {
-        // Mantissa bits kept in the low halves (default 10 = all: the split is exact to 22 bits).  The tile
-        // kernel is power-limited and its power follows the operands' bit activity: K3 launch 583 us at 10
-        // bits, 572 at 6, 563 at 3, 556 at 0 (max error vs fp64 0.9 / 1.1 / 3.7 / 24 e-6).  Not taken: the
-        // large-norm, small-distance cases (golden G8) need the bits.
-        const char* e = getenv("NW_SPLIT_LBITS");
-        const int keep = e ? atoi(e) : 10;
-        return keep >= 10 ? 0xffffu : (0xffffu << (10 - (keep < 0 ? 0 : keep))) & 0xffffu;
-    }();
+    // Mantissa bits kept in the low halves (default 10 = all: the split is exact to 22 bits).  The tile kernel's pace
+    // follows the operands' bit activity: K3 launch 583 us at 10 bits, 572 at 6, 563 at 3, 556 at 0 (max error vs fp64
+    // 0.9 / 1.1 / 3.7 / 24 e-6).  Not taken: the large-norm, small-distance cases (golden G8) need the bits.  (Diagnostic
+    // knob "split_lbits".)
+    const int kb = knob(KNOB_SPLIT_LBITS);
+    const int keep = kb == KNOB_UNSET ? 10 : kb;
+    const unsigned lmask = keep >= 10 ? 0xffffu : (0xffffu << (10 - (keep < 0 ? 0 : keep))) & 0xffffu;
     hipLaunchKernelGGL(nw_split_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, out, scale,
                        norm2, rows, d, lmask);
     NW_CHECK_LAUNCH();

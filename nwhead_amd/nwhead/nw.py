@@ -53,9 +53,13 @@ class NWNet(nn.Module):
     def __init__(self, featurizer, n_classes, support_dataset=None, feat_dim=None, proj_dim=0,
                  kernel_type='euclidean', train_type='random', n_way=None, n_shot=1,
                  n_shot_random=1, n_shot_full=100, n_shot_cluster=1, n_neighbors=10,
-                 env_array=None, debug_mode=False, device='cuda:0', return_mask=False, cluster_backend='auto'):
+                 env_array=None, debug_mode=False, device='cuda:0', return_mask=False, cluster_backend='auto',
+                 loader_workers=0, pin_memory=False):
         super().__init__()
         self.cluster_backend = cluster_backend   # not in the reference: where 'cluster' mode's k-means runs (utils.compute_clusters)
+        # not in the reference either (its bank loaders are single-process, support.py:164-165): DataLoader workers and
+        # pinned staging for the loaders precompute() featurises the bank from; same row order whatever they are
+        self.loader_workers, self.pin_memory = int(loader_workers), bool(pin_memory)
         if support_dataset is not None:
             assert hasattr(support_dataset, 'targets'), 'Support set must have .targets attribute'
         if proj_dim > 0:
@@ -124,7 +128,8 @@ class NWNet(nn.Module):
         self.support_eval = SupportSetEval(support_dataset, self.n_classes, self.n_shot_random,
                                            self.n_shot_full, n_shot_cluster=self.n_shot_cluster,
                                            n_neighbors=self.n_neighbors, env_array=self.env_array,
-                                           cluster_backend=self.cluster_backend)
+                                           cluster_backend=self.cluster_backend, loader_workers=self.loader_workers,
+                                           pin_memory=self.pin_memory)
 
     @torch.no_grad()
     def _compute_all_support_feats(self):
@@ -134,7 +139,7 @@ class NWNet(nn.Module):
         for loader in self.support_eval.support_loaders:
             f, y, m = [], [], []
             for img, label, meta in loader:
-                f.append(featurizer(img.to(self.device)).detach())
+                f.append(featurizer(img.to(self.device, non_blocking=self.pin_memory)).detach())
                 y.append(label.to(self.device))
                 m.append(meta.to(self.device))
             per_env.append((torch.cat(f), torch.cat(y), torch.cat(m)))
@@ -175,8 +180,9 @@ class NWNet(nn.Module):
             start += len(ds)
             if a >= b:
                 continue
-            for img, label, _meta in DataLoader(Subset(ds, range(a, b)), batch_size=128, shuffle=False):
-                feats.append(featurizer(img.to(self.device)).detach())
+            for img, label, _meta in DataLoader(Subset(ds, range(a, b)), batch_size=128, shuffle=False,
+                                                num_workers=self.loader_workers, pin_memory=self.pin_memory):
+                feats.append(featurizer(img.to(self.device, non_blocking=self.pin_memory)).detach())
                 labels.append(label.to(self.device))
         d = feats[0].shape[1] if feats else featurizer(ds[0][0][None].to(self.device)).shape[1]
         feat = torch.cat(feats) if feats else torch.empty(0, d, device=self.device)

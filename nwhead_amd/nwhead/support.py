@@ -72,14 +72,18 @@ class SupportSetEval(SupportSet):
     MODES = ('random', 'full', 'cluster', 'ensemble', 'knn', 'hnsw')
 
     def __init__(self, support_set, n_classes, n_shot_random, n_shot_full, n_shot_cluster=3,
-                 n_neighbors=20, env_array=None, cluster_backend="auto"):
+                 n_neighbors=20, env_array=None, cluster_backend="auto", loader_workers=0, pin_memory=False):
         super().__init__(support_set, n_classes, env_array)
         self.cluster_backend = cluster_backend        # utils.compute_clusters: 'auto' | 'sklearn' | 'device'
         self.n_shot_random, self.n_shot_full = n_shot_random, n_shot_full
         self.n_shot_cluster, self.n_neighbors = n_shot_cluster, n_neighbors
         self.full_datasets = [FullDataset(env, n_shot_full) for env in self.env_datasets]
-        self.support_loaders = [DataLoader(ds, batch_size=128, shuffle=False, num_workers=0)
-                                for ds in self.full_datasets]
+        # the reference's loaders (support.py:164-165: batch 128, in order, num_workers = 0).  Decoding the bank's images is
+        # what bounds precompute() on a real dataset, so the worker count and pinned staging buffers are the caller's to
+        # raise (NWNet(..., loader_workers=, pin_memory=)); the row order does not depend on them (shuffle=False)
+        self.loader_workers, self.pin_memory = int(loader_workers), bool(pin_memory)
+        self.support_loaders = [DataLoader(ds, batch_size=128, shuffle=False, num_workers=self.loader_workers,
+                                           pin_memory=self.pin_memory) for ds in self.full_datasets]
 
     def build_infer_iters(self, sfeat, sy, smeta, sfeat_env, sy_env, smeta_env):
         self.full_feat, self.full_y, self.full_meta = sfeat, sy, smeta

@@ -87,6 +87,21 @@ def _kind_id(kind):
 
 
 _WS_CACHE = {}
+_OPTS = {}
+
+
+def _default_opts(persistent_wgs=0):
+    """The nw_fwd_opts of a call without cached run tables (kept alive here; NW_SPLIT_ALWAYS read when first needed)."""
+    key = (int(persistent_wgs), _lib.force_split())
+    op = _OPTS.get(key)
+    if op is None:
+        op = _OPTS[key] = _lib.fwd_opts(persistent_wgs=persistent_wgs)
+    return C_addr(op)
+
+
+def C_addr(op):
+    import ctypes
+    return ctypes.addressof(op)
 
 
 def _workspace(nbytes, device, stream=None):
@@ -128,7 +143,7 @@ def nw_scores(q, s, kind="euclidean", logit_scale=None, support_cache=None):
         with _OnDevice(q.device):
             _lib.check(lib.nw_fwd_f32(_ptr(q), _ptr(s), _ptr(zeros), _ptr(support_cache.norm2), _ptr(support_cache.split),
                                       _ptr(support_cache.scale), _ptr(out1), _ptr(out), None, None, _ptr(ws), ws_bytes,
-                                      B, N, d, 1, _kind_id(kind), _ptr(ls), 0, 0, _stream(q)), "nw_fwd_f32")
+                                      B, N, d, 1, _kind_id(kind), _ptr(ls), 0, 0, _default_opts(), _stream(q)), "nw_fwd_f32")
         return out
     with torch.cuda.device(q.device):
         _lib.check(lib.nw_scores_f32(_ptr(q), _ptr(s), _ptr(out), B, N, d, _kind_id(kind), _ptr(ls),
@@ -215,6 +230,7 @@ class SplitBank:
             self.norm2 = row_norm2(sc)
         self.tables = self._tables_src = None
         self.tables_label_max = -1
+        self._opts = {}
         if labels is not None and labels.dim() == 1 and self.split is not None:
             self.build_tables(self.sorted_labels if self.sorted_labels is not None else labels)
 
@@ -230,23 +246,28 @@ class SplitBank:
         lo, hi = (int(v) for v in torch.aminmax(lab64))
         if lo < 0:
             raise ValueError("support labels must be non-negative class indices (F.one_hot, nw.py:276, raises too)")
-        self.tables_label_max = hi      # the tables hold every label as a real class: n_classes must exceed it (hint_tables)
+        self.tables_label_max = hi      # the tables hold every label as a real class: n_classes must exceed it (call_opts)
         nbytes = lib.nw_bank_tables_bytes(N)
         tables = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=lab64.device)
         with torch.cuda.device(lab64.device):
             # C: any bound above the labels gives the same tables (nw_head refuses labels >= n_classes)
             _lib.check(lib.nw_bank_tables_build(_ptr(lab64), N, 0x7fffffff, _ptr(tables), nbytes, _stream(lab64)),
                        "nw_bank_tables_build")
-        self.tables, self._tables_src = tables, _sig(labels)
+        self.tables, self._tables_src, self._opts = tables, _sig(labels), {}
 
-    def hint_tables(self, lib, sy, syc, n_classes):
-        """Name the cached run tables for the forward call that follows, if ``sy`` is the label tensor they were built
-        from (``syc``: the int64 contiguous form handed to the library)."""
+    def call_opts(self, sy, n_classes, persistent_wgs=0):
+        """Address of the nw_fwd_opts for a forward call with labels ``sy``: names the cached run tables when ``sy`` is the
+        label tensor they were built from (same storage, unmodified) -- the object stays alive in this bank."""
         if self.tables is not None and _sig(sy) == self._tables_src:
             if self.tables_label_max >= int(n_classes):
                 raise ValueError(f"support label {self.tables_label_max} is outside [0, n_classes={int(n_classes)}) "
                                  "(the reference's F.one_hot, nw.py:276, raises)")
-            lib.nw_bank_tables_hint(_ptr(self.tables), self.tables.numel(), _ptr(syc), self.shape[0], int(n_classes))
+            key = (int(persistent_wgs), _lib.force_split())
+            op = self._opts.get(key)
+            if op is None:
+                op = self._opts[key] = _lib.fwd_opts(self.tables.data_ptr(), self.tables.numel(), persistent_wgs)
+            return C_addr(op)
+        return _default_opts(persistent_wgs)
 
     def matches(self, s):
         """True when `s` is the very tensor (storage, shape, no in-place update since) this bank was prepared from."""
@@ -304,6 +325,8 @@ class _NWHeadFn(torch.autograd.Function):
         N = sc.shape[-2]
         dev = qc.device
         need_bwd = any(ctx.needs_input_grad[:2]) or (logit_scale is not None and ctx.needs_input_grad[3])
+        if need_bwd:
+            _lib.sync_knobs()          # (NW_BWD_SPLIT and the other diagnostic switches may be flipped between steps)
         if (need_bwd and ssplit is None and not sup_b and N > 0
                 and lib.nw_bwd_uses_split(B, N, d, n_classes, 0)):
             # a training step at a size where the backward's products run on split rows: split the supports once,
@@ -321,13 +344,12 @@ class _NWHeadFn(torch.autograd.Function):
         ws_bytes = _fwd_ws_bytes(lib, B, N, d, n_classes)
         st = _stream(qc)
         ws = _workspace(ws_bytes, dev, st) if ws_bytes else None
-        if cache is not None:
-            cache.hint_tables(lib, sy, syc, n_classes)
+        opts = cache.call_opts(sy, n_classes) if cache is not None else _default_opts()
         with _OnDevice(dev):
             rc = lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale), _ptr(out),
                                 _ptr(scores), _ptr(lse),
                                 _ptr(weights), _ptr(ws), ws_bytes, B, N, d, n_classes, kind_id,
-                                _ptr(ls), int(sup_b), int(lab_b), st)
+                                _ptr(ls), int(sup_b), int(lab_b), opts, st)
         if rc:
             _lib.check(rc, "nw_fwd_f32")
         if need_bwd:
@@ -402,6 +424,8 @@ def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weig
     needs_grad = torch.is_grad_enabled() and (q.requires_grad or s.requires_grad or
                                               (logit_scale is not None and logit_scale.requires_grad))
     d_now = q.shape[-1]
+    if needs_grad:
+        _lib.sync_knobs()              # (NW_BWD_SPLIT and the other diagnostic switches may be flipped between steps)
     if (needs_grad and support_cache is None and s.dim() == 2 and d_now % 32 and d_now >= 256
             and _lib.load().nw_bwd_uses_split(q.shape[0], s.shape[0], d_now + (-d_now) % 32, int(n_classes), 0)):
         # a training step at a width that is not a multiple of 32: zero columns take it to the split-row kernels of the
@@ -434,7 +458,7 @@ def nw_partials(q, s, sy, n_classes, kind="euclidean", logit_scale=None, support
 
 
 def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_scale=None, ws=None, sn2=None,
-                     cache=None):
+                     cache=None, persistent_wgs=0):
     """Write partials into ``packed`` laid out as [m (B) | den (B) | num (B*C)] (flat, contiguous):
     one buffer = one collective.  Inputs must already be fp32/int64 contiguous HIP tensors."""
     lib = _lib.load()
@@ -454,11 +478,11 @@ def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_sca
             raise ValueError("this SplitBank holds a class-sorted copy of its support: pass cache.sorted_rows / "
                              "cache.sorted_labels (or call nw_partials, which does)")
         sn2, ssplit, sscale = cache.norm2, cache.split, cache.scale
-        cache.hint_tables(lib, syc, syc, C)
+    opts = cache.call_opts(syc, C, persistent_wgs) if cache is not None else _default_opts(persistent_wgs)
     with torch.cuda.device(qc.device):
         _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale),
                                           _ptr(m), _ptr(den), _ptr(num),
-                                          _ptr(ws), ws.numel(), B, N, d, C, _kind_id(kind), _ptr(ls),
+                                          _ptr(ws), ws.numel(), B, N, d, C, _kind_id(kind), _ptr(ls), opts,
                                           _stream(qc)), "nw_fwd_partial_f32")
     return packed
 
@@ -760,7 +784,7 @@ def nw_head_influence(q, s, sy, n_classes, qy, kind="euclidean", logit_scale=Non
     with torch.cuda.device(dev):
         _lib.check(lib.nw_fwd_influence_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale), _ptr(qyc),
                                             _ptr(out), None, _ptr(infl), _ptr(ws), ws.numel(), B, N, d, C, kid, _ptr(ls),
-                                            _stream(qc)), "nw_fwd_influence_f32")
+                                            _default_opts(), _stream(qc)), "nw_fwd_influence_f32")
     return out, infl
 
 

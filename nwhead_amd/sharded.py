@@ -40,7 +40,11 @@ def _coalesce(chunk):
 
 class ShardedBank:
     def __init__(self, feat_shard, y_shard, n_classes, kind="euclidean", logit_scale=None, group=None,
-                 partial_fn=None, merge_fn=None):
+                 partial_fn=None, merge_fn=None, persistent_wgs=None):
+        """persistent_wgs: workgroups of the persistent tile kernel (nw_fwd_opts.persistent_wgs, a multiple of 8; 0 = one per
+        CU).  Default: with more than one rank, all CUs but one per XCD (count - 8) -- the all-gather of bucket i runs
+        under the kernels of bucket i + 1, and a kernel that holds one 160 KB-LDS workgroup on EVERY CU would leave RCCL's
+        kernel nowhere to run until it ends; with one rank, one per CU."""
         self.feat = feat_shard.detach().to(torch.float32).contiguous()
         self.y = y_shard.detach().to(torch.int64).contiguous()
         self.C = int(n_classes)
@@ -49,6 +53,12 @@ class ShardedBank:
         self._partial = partial_fn or self._hip_partial
         self._merge = merge_fn or self._hip_merge
         self._ws = None
+        if persistent_wgs is None:
+            persistent_wgs = 0
+            if self.world > 1 and self.feat.is_cuda:
+                cus = torch.cuda.get_device_properties(self.feat.device).multi_processor_count
+                persistent_wgs = max(8, (cus - 8) // 8 * 8)
+        self.persistent_wgs = int(persistent_wgs)
         # Class windows: a contiguous slice of a class-sorted bank holds only ~C/G classes, so its
         # partial forward runs on labels shifted by the slice's lowest class with CL = widest window
         # over the ranks; the exchanged rows are (2 + CL) instead of (2 + C) floats per query.
@@ -80,7 +90,7 @@ class ShardedBank:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=q.device)
         ops.nw_partials_into(packed_row, q, self.feat, self.y_local, self.CL, self.kind, self.logit_scale,
-                             ws=self._ws, cache=self.cache)
+                             ws=self._ws, cache=self.cache, persistent_wgs=self.persistent_wgs)
 
     def _hip_merge(self, gathered_rows, B):
         return ops.nw_merge(gathered_rows, B, self.C, class_lo=self.class_lo, c_local=self.CL)

@@ -43,28 +43,28 @@ int main() {
     EXPECT(nw_scores_f32(F, F, F, 4, 4, 4, NW_SCORE_CLIP, nullptr, 0, nullptr), NW_ERR_INVALID_ARG);
     // forward
     EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, -1, 4, 4, 3,
-                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3, -3,
-                      nullptr, 0, 0, nullptr), NW_ERR_UNSUPPORTED);
+                      nullptr, 0, 0, nullptr, nullptr), NW_ERR_UNSUPPORTED);
     EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3,
-                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_fwd_f32(nullptr, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3,
-                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3,
-                      NW_SCORE_CLIP, nullptr, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+                      NW_SCORE_CLIP, nullptr, 0, 0, nullptr, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 4, 4, 4, 3,
-                      NW_SCORE_EUCLIDEAN, nullptr, 0, 1, nullptr), NW_ERR_INVALID_ARG);   // batched labels, shared support
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 1, nullptr, nullptr), NW_ERR_INVALID_ARG);   // batched labels, shared support
     EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, nullptr, 0, 0, 4, 4, 3,
-                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_OK);                // B == 0
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr, nullptr), NW_OK);                // B == 0
     EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 8, 64, 16, 3,
-                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_WORKSPACE);     // fused path, workspace too small
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr, nullptr), NW_ERR_WORKSPACE);     // fused path, workspace too small
     EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, nullptr, 0, 8, 64, 16, 3,
-                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr), NW_ERR_WORKSPACE);
+                      NW_SCORE_EUCLIDEAN, nullptr, 0, 0, nullptr, nullptr), NW_ERR_WORKSPACE);
     // partials / merge
     EXPECT(nw_fwd_partial_f32(F, F, Y, nullptr, nullptr, nullptr, nullptr, F, F, ws, sizeof ws, 4, 4, 4, 3,
-                              NW_SCORE_EUCLIDEAN, nullptr, nullptr), NW_ERR_INVALID_ARG);
+                              NW_SCORE_EUCLIDEAN, nullptr, nullptr, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_fwd_partial_f32(F, F, Y, nullptr, nullptr, nullptr, F, F, F, ws, 8, 8, 64, 16, 3, NW_SCORE_EUCLIDEAN,
-                              nullptr, nullptr), NW_ERR_WORKSPACE);
+                              nullptr, nullptr, nullptr), NW_ERR_WORKSPACE);
     EXPECT(nw_merge_finalize_f32(F, F, F, F, -1, 4, 3, 4, 4, 12, nullptr, 0, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_merge_finalize_f32(F, F, F, nullptr, 2, 4, 3, 4, 4, 12, nullptr, 0, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_merge_finalize_f32(F, F, F, F, 2, 4, 3, 4, 4, 12, Y, 0, nullptr), NW_ERR_INVALID_ARG);  // window without width
@@ -104,9 +104,18 @@ int main() {
     EXPECT(nw_bank_tables_build(nullptr, 10, 5, ws, sizeof ws, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_bank_tables_build(Y, 10, 5, ws, 8, nullptr), NW_ERR_WORKSPACE);
     EXPECT(nw_bank_tables_build(Y, 0, 5, nullptr, 0, nullptr), NW_OK);
-    EXPECT(nw_bank_tables_hint(ws, 8, Y, 10, 5), NW_ERR_INVALID_ARG);
-    EXPECT(nw_bank_tables_hint(ws, sizeof ws, nullptr, 10, 5), NW_ERR_INVALID_ARG);
-    EXPECT(nw_bank_tables_hint(nullptr, 0, nullptr, 0, 0), NW_OK);
+    {   // the options of a forward call: a short struct (older header) is ignored, tables too small are ignored
+        nw_fwd_opts o = {};
+        o.struct_size = 4; o.tables = ws; o.tables_bytes = 8;
+        EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, nullptr, 0, 0, 4, 4, 3,
+                          NW_SCORE_EUCLIDEAN, nullptr, 0, 0, &o, nullptr), NW_OK);
+        o.struct_size = sizeof o;
+        EXPECT(nw_fwd_f32(F, F, Y, nullptr, nullptr, nullptr, F, nullptr, nullptr, nullptr, ws, sizeof ws, 8, 64, 16, 3,
+                          NW_SCORE_EUCLIDEAN, nullptr, 0, 0, &o, nullptr), NW_ERR_WORKSPACE);
+    }
+    EXPECT(nw_debug_set(nullptr, 1), NW_ERR_INVALID_ARG);
+    EXPECT(nw_debug_set("no_such_knob", 1), NW_ERR_INVALID_ARG);
+    EXPECT(nw_debug_set("qg", 8), NW_OK);
     // split rows, norms, influence, top-k, aggregate
     EXPECT(nw_split_rows_f16x2(F, F, F, F, 4, 48, nullptr), NW_ERR_UNSUPPORTED);      // d % 32 != 0
     EXPECT(nw_split_rows_f16x2(F, F, F, F, -1, 32, nullptr), NW_ERR_INVALID_ARG);
@@ -119,9 +128,9 @@ int main() {
     EXPECT(nw_support_influence_f32(F, Y, nullptr, Y, F, 2, 4, 3, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_support_influence_f32(F, Y, F, Y, F, 0, 4, 3, nullptr), NW_OK);
     EXPECT(nw_fwd_influence_f32(F, F, Y, nullptr, nullptr, nullptr, nullptr, F, nullptr, F, ws, sizeof ws, 4, 8, 4, 3,
-                                NW_SCORE_EUCLIDEAN, nullptr, nullptr), NW_ERR_INVALID_ARG);   // no query labels
+                                NW_SCORE_EUCLIDEAN, nullptr, nullptr, nullptr), NW_ERR_INVALID_ARG);   // no query labels
     EXPECT(nw_fwd_influence_f32(F, F, Y, nullptr, nullptr, nullptr, Y, F, nullptr, F, ws, 8, 4, 8, 4, 3,
-                                NW_SCORE_EUCLIDEAN, nullptr, nullptr), NW_ERR_WORKSPACE);
+                                NW_SCORE_EUCLIDEAN, nullptr, nullptr, nullptr), NW_ERR_WORKSPACE);
     EXPECT(nw_topk_f32(nullptr, Y, nullptr, 2, 8, 2, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_topk_f32(F, Y, nullptr, -1, 8, 2, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_aggregate_f32(nullptr, Y, F, nullptr, nullptr, 2, 8, 3, 0, nullptr), NW_ERR_INVALID_ARG);

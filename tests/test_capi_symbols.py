@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_status_strings_and_argument_checks_without_gpu():
     from nwhead_amd import _lib
     lib = _lib.load()
-    assert lib.nw_abi_version() == 1
+    assert lib.nw_abi_version() == 2
     assert lib.nw_status_string(0) == b"ok"
     assert b"workspace" in lib.nw_status_string(-3)
     # argument validation happens before any HIP call

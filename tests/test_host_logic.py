@@ -125,3 +125,37 @@ def test_bucket_coalescing_views():
     other = [torch.ones(4, 3), torch.zeros(4, 3)]              # different storages: copy
     assert torch.equal(_coalesce(other), torch.cat(other))
     assert torch.equal(_coalesce([parts[3], parts[2]]), torch.cat([parts[3], parts[2]]))   # wrong order: copy
+
+
+def test_bank_loader_workers_keep_the_row_order():
+    """NWNet(..., loader_workers=2): the bank precompute() builds has the rows, in the order, of the single-process loader
+    (the reference's loaders are num_workers = 0, support.py:164-165)."""
+    import torch
+    from nwhead_amd.nwhead.nw import NWNet
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self):
+            g = torch.Generator().manual_seed(3)
+            self.x = torch.randn(90, 3, 4, 4, generator=g)
+            self.targets = [i % 6 for i in range(90)]
+
+        def __len__(self):
+            return 90
+
+        def __getitem__(self, i):
+            return self.x[i], self.targets[i]
+
+    banks = []
+    for workers in (0, 2):
+        torch.manual_seed(1)
+        feat = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(48, 8))
+        net = NWNet(feat, 6, support_dataset=DS(), n_shot_full=9, device="cpu", loader_workers=workers).eval()
+        f, y = [], []
+        for loader in net.support_eval.support_loaders:
+            assert loader.num_workers == workers
+            for img, label, _meta in loader:
+                f.append(feat(img).detach())
+                y.append(label)
+        banks.append((torch.cat(f), torch.cat(y)))
+    assert torch.equal(banks[0][1], banks[1][1]) and torch.equal(banks[0][0], banks[1][0])
+    assert banks[0][1].tolist() == sorted(banks[0][1].tolist())
