@@ -162,32 +162,34 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[QB][RS], const float* hd
                 for (int r = 0; r < RS; ++r) {
                     S0[r & 1] += (sc[r][0] + sc[r][1]) + (sc[r][2] + sc[r][3]);
                 }
-            } else if (nrun == 2) {
-                const float L1 = (float)(bnd.x - 4 * g), M1 = 1.f - L1;
-#pragma unroll
-                for (int r = 0; r < RS; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float c = (float)(16 * r + e), ev = sc[r][e];
-                        const float w1 = __builtin_amdgcn_fmed3f(L1 - c, 0.f, 1.f);  // [t <  b1]
-                        const float u1 = __builtin_amdgcn_fmed3f(c + M1, 0.f, 1.f);  // [t >= b1]
-                        S0[e & 1] = __builtin_fmaf(w1, ev, S0[e & 1]);
-                        S1[e & 1] = __builtin_fmaf(u1, ev, S1[e & 1]);
-                    }
             } else {
-                const float L1 = (float)(bnd.x - 4 * g);
-                const float M2 = 1.f - (float)(bnd.y - 4 * g);
+                // A run is a range of rows and the boundaries b1 <= b2 are wave-uniform, so a 16-row block lies
+                // inside ONE run unless a boundary cuts it: whole blocks add their lanes' four-row sums with a
+                // scalar 0 / 1 weight (3 adds + 3 fmas per block); only the one or two blocks a boundary cuts take
+                // the per-element clamped-difference weights (7 ops per element) -- 384 -> ~80 ops per query block.
+                const int b1 = bnd.x, b2 = (nrun == 3) ? bnd.y : BS;
+                const float L1 = (float)(b1 - 4 * g);
+                const float M2 = 1.f - (float)(b2 - 4 * g);
 #pragma unroll
-                for (int r = 0; r < RS; ++r)
+                for (int r = 0; r < RS; ++r) {
+                    const int lo = 16 * r, hi = 16 * r + 16;
+                    const bool in0 = hi <= b1, in2 = lo >= b2, in1 = lo >= b1 && hi <= b2;
+                    const float quad = (sc[r][0] + sc[r][1]) + (sc[r][2] + sc[r][3]);
+                    S0[r & 1] = __builtin_fmaf(in0 ? 1.f : 0.f, quad, S0[r & 1]);
+                    S1[r & 1] = __builtin_fmaf(in1 ? 1.f : 0.f, quad, S1[r & 1]);
+                    S2[r & 1] = __builtin_fmaf(in2 ? 1.f : 0.f, quad, S2[r & 1]);
+                    if (!(in0 || in1 || in2)) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float c = (float)(16 * r + e), ev = sc[r][e];
-                        const float w1 = __builtin_amdgcn_fmed3f(L1 - c, 0.f, 1.f);  // [t <  b1]
-                        const float u2 = __builtin_amdgcn_fmed3f(c + M2, 0.f, 1.f);  // [t >= b2]
-                        S0[e & 1] = __builtin_fmaf(w1, ev, S0[e & 1]);
-                        S2[e & 1] = __builtin_fmaf(u2, ev, S2[e & 1]);
-                        S1[e & 1] = __builtin_fmaf((1.f - w1) - u2, ev, S1[e & 1]);  // exact 0 / 1
+                        for (int e = 0; e < 4; ++e) {
+                            const float c = (float)(16 * r + e), ev = sc[r][e];
+                            const float w1 = __builtin_amdgcn_fmed3f(L1 - c, 0.f, 1.f);  // [t <  b1]
+                            const float u2 = __builtin_amdgcn_fmed3f(c + M2, 0.f, 1.f);  // [t >= b2]
+                            S0[e & 1] = __builtin_fmaf(w1, ev, S0[e & 1]);
+                            S2[e & 1] = __builtin_fmaf(u2, ev, S2[e & 1]);
+                            S1[e & 1] = __builtin_fmaf((1.f - w1) - u2, ev, S1[e & 1]);  // exact 0 / 1
+                        }
                     }
+                }
             }
             const float s0v = red4(S0[0] + S0[1]);
             float s1v = 0.f, s2v = 0.f;
@@ -464,77 +466,100 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
 #pragma unroll
                 for (int r = 0; r < RS; ++r) acc[j][r] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (QB > 1) {
-                // half-double-buffered: the operands of a stage's first MFMA group (al, bh) are read one
-                // stage ahead, those of the other two groups (ah, bl) at the start of the stage, under
-                // the first group's MFMAs -- no LDS latency in front of a stage, 40 VGPRs instead of 80.
+                // Hand-ordered stage.  The operands of a stage's first MFMA group (al, bh: F1) are double-
+                // buffered and read one stage ahead, one ds_read behind each of the previous stage's first ten
+                // MFMAs; those of the other two groups (ah, bl: F2) are single-buffered and re-read for the next
+                // stage as the last group frees them (bl at its start, ah[r] behind the pair that used it), so
+                // every LDS read has at least the 16 MFMAs of a group between its issue and its first use and
+                // nothing is waited for at the barrier: the reads still in flight there belong to the NEXT
+                // stage's buffer, and every read of the buffer the barrier releases has been consumed by an MFMA
+                // issued in front of it.  (hipcc, left to itself, sank the fragment reads to the end of the
+                // stage, in front of the barrier's lgkmcnt(0), and waited for two fresh reads at the top of the
+                // stage: two exposed LDS latencies per stage, MFMA pipe idle -- 1211 ticks per stage for 768
+                // cycles of MFMA.)  sched_barrier(0) after every step pins the order.
                 struct F1 { float4 bh[QB]; float4 al[RS]; };
                 struct F2 { float4 bl[QB]; float4 ah[RS]; };
-                auto load1 = [&](F1& f, int buf) {
-                    const float4* Qs = stage + ((unsigned)buf % NB) * TILE_F4;
-                    const float4* Ss = Qs + BQP * ROW_F4;
-                    const int sh = g ^ rsw, sl = (4 + g) ^ rsw;
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) f.bh[j] = Qs[(16 * (QB * wave + j) + i) * ROW_F4 + sh];
-#pragma unroll
-                    for (int r = 0; r < RS; ++r) f.al[r] = Ss[(16 * r + i) * ROW_F4 + sl];
-                };
-                auto load2 = [&](F2& f, int buf) {
-                    const float4* Qs = stage + ((unsigned)buf % NB) * TILE_F4;
-                    const float4* Ss = Qs + BQP * ROW_F4;
-                    const int sh = g ^ rsw, sl = (4 + g) ^ rsw;
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) f.bl[j] = Qs[(16 * (QB * wave + j) + i) * ROW_F4 + sl];
-#pragma unroll
-                    for (int r = 0; r < RS; ++r) f.ah[r] = Ss[(16 * r + i) * ROW_F4 + sh];
-                };
-                // MFMA order: a boustrophedon walk over the (support block, query block) grid, so that
-                // consecutive MFMAs share one of their two operand registers
-                auto group1 = [&](const F1& a) {
+                const int sh = g ^ rsw, sl = (4 + g) ^ rsw;
+                const int qoff = (16 * QB * wave + i) * ROW_F4, soff = (BQP + i) * ROW_F4;
+                auto stage_base = [&](int buf) { return stage + ((unsigned)buf % NB) * TILE_F4; };
+                auto rd_bh = [&](const float4* S, int j) { return S[qoff + 16 * j * ROW_F4 + sh]; };
+                auto rd_bl = [&](const float4* S, int j) { return S[qoff + 16 * j * ROW_F4 + sl]; };
+                auto rd_ah = [&](const float4* S, int r) { return S[soff + 16 * r * ROW_F4 + sh]; };
+                auto rd_al = [&](const float4* S, int r) { return S[soff + 16 * r * ROW_F4 + sl]; };
+                auto pin = []() { __builtin_amdgcn_sched_barrier(0); };
+                // one stage: ac = this stage's F1, an = the next stage's (filled here), b = this stage's F2 on
+                // entry, the next stage's on exit
+                auto run_stage = [&](const F1& ac, F1& an, F2& b, int buf_next, auto has_next) {
+                    constexpr bool NXT = decltype(has_next)::value;
+                    const float4* Sn = stage_base(buf_next);
+                    int n = 0;
 #pragma unroll
                     for (int r = 0; r < RS; ++r)
 #pragma unroll
-                        for (int jx = 0; jx < QB; ++jx) {
+                        for (int jx = 0; jx < QB; ++jx) {       // group 1: al x bh
                             const int j = (r & 1) ? QB - 1 - jx : jx;
-                            acc[j][r] = mm(a.al[r], a.bh[j], acc[j][r]);
+                            acc[j][r] = mm(ac.al[r], ac.bh[j], acc[j][r]);
+                            if (NXT && n < QB + RS) {
+                                if (n < QB) an.bh[n] = rd_bh(Sn, n);
+                                else an.al[n - QB] = rd_al(Sn, n - QB);
+                            }
+                            ++n;
+                            pin();
                         }
-                };
-                auto group23 = [&](const F1& a, const F2& b) {
 #pragma unroll
                     for (int r = 0; r < RS; ++r)
 #pragma unroll
-                        for (int jx = 0; jx < QB; ++jx) {
+                        for (int jx = 0; jx < QB; ++jx) {       // group 2: ah x bl
                             const int j = (r & 1) ? QB - 1 - jx : jx;
                             acc[j][r] = mm(b.ah[r], b.bl[j], acc[j][r]);
+                            pin();
                         }
+                    if (NXT) {
 #pragma unroll
-                    for (int r = RS - 1; r >= 0; --r)
+                        for (int j = 0; j < QB; ++j) b.bl[j] = rd_bl(Sn, j);
+                        pin();
+                    }
+#pragma unroll
+                    for (int r = RS - 1; r >= 0; --r) {         // group 3: ah x bh, ah[r] re-read behind its pair
 #pragma unroll
                         for (int jx = 0; jx < QB; ++jx) {
                             const int j = (r & 1) ? jx : QB - 1 - jx;
-                            acc[j][r] = mm(b.ah[r], a.bh[j], acc[j][r]);
+                            acc[j][r] = mm(b.ah[r], ac.bh[j], acc[j][r]);
                         }
+                        pin();
+                        if (NXT) {
+                            b.ah[r] = rd_ah(Sn, r);
+                            pin();
+                        }
+                    }
                 };
+                using Yes = std::integral_constant<bool, true>;
+                using No = std::integral_constant<bool, false>;
                 F1 a0, a1;
                 F2 b0;
-                load1(a0, gi);
-                int kt = 0;
-                for (; kt + 1 < nk; kt += 2) {
-                    load2(b0, gi + kt);
-                    group1(a0);
-                    load1(a1, gi + kt + 1);
-                    group23(a0, b0);
-                    tile_barrier();
-                    load2(b0, gi + kt + 1);
-                    group1(a1);
-                    if (kt + 2 < nk) load1(a0, gi + kt + 2);
-                    group23(a1, b0);
-                    tile_barrier();
+                {
+                    const float4* S0 = stage_base(gi);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) { a0.bh[j] = rd_bh(S0, j); b0.bl[j] = rd_bl(S0, j); }
+#pragma unroll
+                    for (int r = 0; r < RS; ++r) { a0.al[r] = rd_al(S0, r); b0.ah[r] = rd_ah(S0, r); }
+                    pin();
                 }
-                if (kt < nk) {  // odd stage count
-                    load2(b0, gi + kt);
-                    group1(a0);
-                    group23(a0, b0);
-                    tile_barrier();
+                int kt = 0;
+                for (; kt + 2 < nk; kt += 2) {
+                    run_stage(a0, a1, b0, gi + kt + 1, Yes{});
+                    tile_barrier_nowait();
+                    run_stage(a1, a0, b0, gi + kt + 2, Yes{});
+                    tile_barrier_nowait();
+                }
+                if (kt + 2 == nk) {
+                    run_stage(a0, a1, b0, gi + kt + 1, Yes{});
+                    tile_barrier_nowait();
+                    run_stage(a1, a0, b0, 0, No{});
+                    tile_barrier_nowait();
+                } else {
+                    run_stage(a0, a1, b0, 0, No{});
+                    tile_barrier_nowait();
                 }
             } else if constexpr (SINGLE) {
                 Frag f0;

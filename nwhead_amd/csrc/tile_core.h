@@ -71,6 +71,16 @@ __device__ __forceinline__ void tile_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// The same barrier for a wave whose LDS reads of the buffer being released have all been CONSUMED (an MFMA
+// that uses them has been issued in front of the barrier) and whose reads still in flight belong to another
+// buffer: nothing to wait for (fused_f16p.h, hand-ordered stage).
+__device__ __forceinline__ void tile_barrier_nowait() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 __device__ __forceinline__ float dot4(const float4 v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 

@@ -15,6 +15,8 @@ int device_cu_count() { return 256; }
 bool env_flag(const char*) { return false; }
 int persistent_variant() { const char* e = getenv("NW_PVAR"); return e ? atoi(e) : 2; }
 int persistent_qgroup() { const char* e = getenv("NW_QG"); return e ? atoi(e) : 8; }
+const FwdOpts& fwd_opts() { static FwdOpts o{}; return o; }
+int knob(int) { return KNOB_UNSET; }
 int launch_split_rows(const float* x, float* out, float* scale, float* norm2, int64_t rows, int64_t d, hipStream_t st);
 }
 int main(int argc, char** argv) {
