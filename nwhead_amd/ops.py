@@ -4,6 +4,8 @@ autograd bookkeeping); every arithmetic step runs in libnwhead_hip.so.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -1099,6 +1101,21 @@ def _amax_of(t):
     return a
 
 
+# Measured and left OFF: with the weight gradient of every convolution on a side stream beside its data gradient a
+# DenseNet-121 step takes 24.9-26.5 ms against 20.8-22.0 (same box, alternated): the two cross-stream dependencies per
+# node (event + barrier packet each way) cost more than the overlap of two kernels that both want every CU returns.
+WGRAD_SIDE_STREAM = os.environ.get("NW_WGRAD_STREAM", "0") == "1"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class _ConvNhwcFn(torch.autograd.Function):
     """conv2d over channels-last activations on the fp16 matrix cores: forward and data gradient through
     nw_conv2d_nhwc_f16x2 (the data gradient of a stride-1 convolution is the convolution with the flipped, transposed
@@ -1131,6 +1148,17 @@ class _ConvNhwcFn(torch.autograd.Function):
             _CONV_STATS["absmax_fallbacks"] += 1
             gam = absmax(g)
         dx = dw = None
+        # The weight gradient is off the backward's critical path (the data gradient feeds the next node): it goes to a
+        # side stream and runs beside the data gradient; the main stream waits for it before the node returns, so the
+        # tensors autograd sees afterwards are complete on the stream it uses.
+        side = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[0] and WGRAD_SIDE_STREAM:
+            main = torch.cuda.current_stream(g.device)
+            side = _side_stream(g.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw = conv2d_nhwc_wgrad(xv, g, weight.shape, stride, pad, amax_x if amax_x.numel() else None, gam)
+            dw.record_stream(main)
         if ctx.needs_input_grad[0]:
             if stride == 1 and kh == kw and kh - 1 - pad >= 0 and cout % 32 == 0 and cin % 32 == 0:
                 dg = ctx.dgrad_operand
@@ -1140,7 +1168,9 @@ class _ConvNhwcFn(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(g, xv, weight, None, [stride, stride], [pad, pad], [1, 1], False,
                                                          [0, 0], 1, [True, False, False])[0]
-        if ctx.needs_input_grad[1]:
+        if side is not None:
+            main.wait_stream(side)
+        elif ctx.needs_input_grad[1]:
             dw = conv2d_nhwc_wgrad(xv, g, weight.shape, stride, pad, amax_x if amax_x.numel() else None, gam)
         return dx, dw, None, None, None, None
 
