@@ -335,6 +335,9 @@ int nw_conv1x1_f32(const float *x, int64_t x_batch_stride, const float *pre_scal
  *             through nw_split_rows_f16x2 (its third output, the row norms, is not used); Cout % 32 == 0
  *   bias      optional (Cout,);  residual optional (n, Ho, Wo, Cout);  relu != 0: max(., 0) (NaN kept)
  *   y         (n, Ho, Wo, Cout) fp32;  amax_out optional: the amax record of y (NW_AMAX_SLOTS floats, all written)
+ *   ldx, ldy  floats between consecutive pixels of x / y (0: Cin / Cout, dense): a channel window of a wider NHWC tensor
+ *             as input or output (a dense block's slab, model/densenet.py:62-80, takes each layer's 32 channels in place);
+ *             residual stays dense
  * nw_conv2d_nhwc_supported: 1 when the shape is served (else nw_conv2d_nhwc_f16x2 returns NW_ERR_UNSUPPORTED).
  * ------------------------------------------------------------------------------------------- */
 #define NW_AMAX_SLOTS 256
@@ -349,7 +352,7 @@ int nw_conv2d_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t Cin, int64
 int nw_conv2d_nhwc_f16x2(const float *x, const float *amax_in, const float *w_split, const float *w_scale,
                          const float *bias, const float *residual, int relu, float *y, float *amax_out,
                          int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
-                         int64_t stride, int64_t pad, void *stream);
+                         int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ ReLU) in front of / behind the backbones' convolutions, forward and
@@ -394,7 +397,8 @@ int nw_split_conv_weights_f16x2(const int64_t *jobs, int64_t njobs, int64_t tota
  * matrix cores (csrc/conv_wgrad.hip): what autograd derives for the weight of F.conv2d at model/densenet.py:33-60, :82-91
  * and model/resnet.py:31-66 in loss.backward() (train.py:414).
  *     dw[co, ky, kx, ci] = sum_{n,y,x} gy[n, y, x, co] * x[n, y + ky - pad, x + kx - pad, ci]
- *   x (n, H, W, Cin), gy (n, H, W, Cout) fp32 with their amax records; Cin % 8 == 0, Cout % 8 == 0
+ *   x (n, H, W, Cin), gy (n, H, W, Cout) fp32 with their amax records; Cin % 8 == 0, Cout % 8 == 0; ldx, ldg: floats
+ *   between consecutive pixels of x / gy (0: dense)
  *   dw (Cout, KH, KW, Cin) fp32: the bytes of a channels_last (Cout, Cin, KH, KW) tensor
  *   workspace: nw_conv2d_nhwc_wgrad_workspace_bytes(...) (partial tiles of the position chunks, added in order)
  * nw_conv2d_nhwc_wgrad_supported: 1 when the shape is served, else the call returns NW_ERR_UNSUPPORTED. */
@@ -404,7 +408,8 @@ size_t nw_conv2d_nhwc_wgrad_workspace_bytes(int64_t n, int64_t H, int64_t W, int
                                             int64_t KW, int64_t stride, int64_t pad);
 int nw_conv2d_nhwc_wgrad_f16x2(const float *x, const float *amax_x, const float *gy, const float *amax_g, float *dw,
                                void *workspace, size_t workspace_bytes, int64_t n, int64_t H, int64_t W, int64_t Cin,
-                               int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, void *stream);
+                               int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int64_t ldx, int64_t ldg,
+                               void *stream);
 /* device address of 32 bytes of zeros the convolution kernels read in place of pixels that do not exist (internal) */
 const void *nw_conv_zero_page(void);
 
@@ -413,7 +418,8 @@ const void *nw_conv_zero_page(void);
  * nw_conv2d_nhwc_f16x2: x is (rows = n h w, c) with row stride ldx >= c floats (a channel prefix of a wider NHWC
  * tensor qualifies), c % 4 == 0, y / dy / dx dense (rows, c).  Moments per row chunk merged in a fixed order (Chan),
  * deterministic; amax_out (nullable): the amax record (NW_AMAX_SLOTS floats) of y / dx for the convolution that reads
- * it next.  acc (nullable, backward): a second gradient of x with row stride ldacc, added into dx.
+ * it next.  acc (nullable, backward): a second gradient of x with row stride ldacc, added into dx; lddx: row stride of
+ * dx (0: dense); dx may be acc itself (the gradient slab of a dense block accumulates in place).
  * workspace: nw_bn_nhwc_workspace_bytes(rows, c).
  * ------------------------------------------------------------------------------------------- */
 size_t nw_bn_nhwc_workspace_bytes(int64_t rows, int64_t c);
@@ -423,8 +429,8 @@ int nw_bn_relu_nhwc_train_fwd_f32(const float *x, int64_t ldx, const float *gamm
                                   int64_t rows, int64_t c, float momentum, float eps, int relu, void *stream);
 int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, const float *gamma, const float *beta,
                                   const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
-                                  float *dbeta, const float *acc, int64_t ldacc, float *amax_out, void *workspace,
-                                  size_t workspace_bytes, int64_t rows, int64_t c, int relu, void *stream);
+                                  float *dbeta, const float *acc, int64_t ldacc, int64_t lddx, float *amax_out,
+                                  void *workspace, size_t workspace_bytes, int64_t rows, int64_t c, int relu, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): device time of the TILE kernel alone -- the kernel the

@@ -56,15 +56,15 @@ SIGNATURES = {
     "nw_absmax_f32": (_int, [_p, _i64, _p, _p]),
     "nw_to_nhwc_pad_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "nw_conv2d_nhwc_supported": (_int, [_i64] * 9),
-    "nw_conv2d_nhwc_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _int, _p, _p] + [_i64] * 9 + [_p]),
+    "nw_conv2d_nhwc_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _int, _p, _p] + [_i64] * 11 + [_p]),
     "nw_split_conv_weights_f16x2": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "nw_conv2d_nhwc_wgrad_supported": (_int, [_i64] * 9),
     "nw_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i64] * 9),
-    "nw_conv2d_nhwc_wgrad_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _sz] + [_i64] * 9 + [_p]),
+    "nw_conv2d_nhwc_wgrad_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _sz] + [_i64] * 11 + [_p]),
     "nw_conv_zero_page": (_p, []),
     "nw_bn_nhwc_workspace_bytes": (_sz, [_i64, _i64]),
     "nw_bn_relu_nhwc_train_fwd_f32": (_int, [_p, _i64] + [_p] * 10 + [_sz, _i64, _i64, C.c_float, C.c_float, _int, _p]),
-    "nw_bn_relu_nhwc_train_bwd_f32": (_int, [_p, _i64] + [_p] * 9 + [_i64, _p, _p, _sz, _i64, _i64, _int, _p]),
+    "nw_bn_relu_nhwc_train_bwd_f32": (_int, [_p, _i64] + [_p] * 9 + [_i64, _i64, _p, _p, _sz, _i64, _i64, _int, _p]),
     "nw_debug_set": (_int, [C.c_char_p, _int]),
     "nw_debug_tile_timing": (_int, [_int]),
     "nw_debug_tile_timing_read": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -222,8 +222,8 @@ template <bool RELU>
 __global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                      const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                                                                     const float* __restrict__ k, const float* __restrict__ acc, int64_t ldacc,
-                                                                     float* __restrict__ dx, float* __restrict__ amax, int64_t R, int C) {
+                                                                     const float* __restrict__ k, const float* acc, int64_t ldacc,
+                                                                     float* dx, int64_t lddx, float* __restrict__ amax, int64_t R, int C) {
     extern __shared__ float prm[];   // [6][C]: mean, invstd, a, beta, k1, k2
     __shared__ float red[16];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_apply_kernel(const float*
             o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
         }
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
-        *reinterpret_cast<float4*>(dx + r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
     mx = block_max(mx, red);
     if (amax && threadIdx.x == 0)
@@ -326,10 +326,13 @@ extern "C" int nw_bn_relu_nhwc_train_fwd_f32(const float* x, int64_t ldx, const 
 
 extern "C" int nw_bn_relu_nhwc_train_bwd_f32(const float* x, int64_t ldx, const float* dy, const float* gamma, const float* beta,
                                              const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
-                                             float* dbeta, const float* acc, int64_t ldacc, float* amax_out, void* workspace,
-                                             size_t workspace_bytes, int64_t rows, int64_t c, int relu, void* stream) {
+                                             float* dbeta, const float* acc, int64_t ldacc, int64_t lddx, float* amax_out,
+                                             void* workspace, size_t workspace_bytes, int64_t rows, int64_t c, int relu,
+                                             void* stream) {
     using namespace nw;
-    if (rows < 0 || c <= 0 || c % 4 || ldx < c || ldx % 4 || (acc && (ldacc < c || ldacc % 4))) return NW_ERR_INVALID_ARG;
+    if (lddx == 0) lddx = c;
+    if (rows < 0 || c <= 0 || c % 4 || ldx < c || ldx % 4 || (acc && (ldacc < c || ldacc % 4)) || lddx < c || lddx % 4)
+        return NW_ERR_INVALID_ARG;
     if (rows == 0) return NW_OK;
     if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return NW_ERR_INVALID_ARG;
     if (bad_align(x, dy, dx, acc) || bad_align(gamma, beta, save_mean, save_invstd) || bad_align(amax_out, workspace))
@@ -351,7 +354,7 @@ extern "C" int nw_bn_relu_nhwc_train_bwd_f32(const float* x, int64_t ldx, const 
         hipLaunchKernelGGL(nw_bn_nhwc_bwd_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, \
                            1.f / (float)rows, dgamma, dbeta, k);                                                               \
         hipLaunchKernelGGL((nw_bn_nhwc_bwd_apply_kernel<R_>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, dy, gamma, beta,  \
-                           save_mean, save_invstd, k, acc, ldacc, dx, amax_out, rows, (int)c);                                 \
+                           save_mean, save_invstd, k, acc, ldacc, dx, lddx, amax_out, rows, (int)c);                                 \
     } while (0)
     if (relu) NW_BNB(true); else NW_BNB(false);
 #undef NW_BNB

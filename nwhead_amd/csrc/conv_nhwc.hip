@@ -45,6 +45,7 @@ struct ConvP {
     float* amax_out;         // nullable: CV_AMAX_SLOTS floats
     const float4* zeros;     // 32 bytes of zeros (what a loader reads for a pixel that does not exist)
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
+    int ldx, ldy;            // floats between consecutive pixels of x / y (>= Cin / Cout: a channel window of a wider tensor)
     int IP, IMG;             // virtual raster of PATCH mode: row stride W + pad, image stride (H + pad) IP
     int M, mtiles, ntiles;
 };
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     const int n = idx / p.IMG, r = idx - n * p.IMG, row = r / p.IP, col = r - row * p.IP;
                     const int yi = row - p.pad, xi = col - p.pad;
                     const bool ok = n < p.N && yi >= 0 && xi >= 0 && xi < p.W;
-                    aoff[q] = ok ? (unsigned)(((n * p.H + yi) * p.W + xi) * p.Cin + 8 * lj) : 0u;
+                    aoff[q] = ok ? (unsigned)(((n * p.H + yi) * p.W + xi) * p.ldx + 8 * lj) : 0u;
                     avalid |= ok ? (1u << q) : 0u;
                 }
             } else {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 for (int q = 0; q < NPASS; ++q) {
                     const int yi = gy[q] + dy, xi = gx[q] + dx;
                     const bool ok = live && gn[q] >= 0 && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
-                    const unsigned off = (unsigned)(((gn[q] + yi) * p.W + xi) * p.Cin + 32 * c + 8 * lj);
+                    const unsigned off = (unsigned)(((gn[q] + yi) * p.W + xi) * p.ldx + 32 * c + 8 * lj);
                     ldg2(L[q][0], L[q][1], pick(ok, p.x + off));
                 }
             }
@@ -464,9 +465,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     v.y = __builtin_fmaf(acc[a][b][1], ws4.y * inv_up, b4.y);
                     v.z = __builtin_fmaf(acc[a][b][2], ws4.z * inv_up, b4.z);
                     v.w = __builtin_fmaf(acc[a][b][3], ws4.w * inv_up, b4.w);
-                    const size_t o = (size_t)m * p.Cout + co;
+                    const size_t o = (size_t)m * p.ldy + co;
                     if (p.res) {
-                        const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+                        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.Cout + co);
                         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                     }
                     if (p.relu) {   // (x < 0 ? 0 : x keeps a NaN, like torch's relu)
@@ -620,10 +621,18 @@ extern "C" int nw_conv2d_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t
 extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const float* w_split, const float* w_scale,
                                     const float* bias, const float* residual, int relu, float* y, float* amax_out,
                                     int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
-                                    int64_t stride, int64_t pad, void* stream) {
+                                    int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, void* stream) {
     if (n < 0 || H < 0 || W < 0) return NW_ERR_INVALID_ARG;
     if (n == 0) return NW_OK;
     if (!nw_conv2d_nhwc_supported(n, H, W, Cin, Cout, KH, KW, stride, pad)) return NW_ERR_UNSUPPORTED;
+    if (ldx == 0) ldx = Cin;
+    if (ldy == 0) ldy = Cout;
+    if (ldx < Cin || ldy < Cout || ldx % 4 || ldy % 4) return NW_ERR_INVALID_ARG;
+    if (ldx != Cin && Cin % 32) return NW_ERR_UNSUPPORTED;   // (the few-channel stems read whole dense rows)
+    {
+        const int64_t Ho_ = (H + 2 * pad - KH) / stride + 1, Wo_ = (W + 2 * pad - KW) / stride + 1;
+        if (n * H * W * ldx >= (1LL << 31) || n * Ho_ * Wo_ * ldy >= (1LL << 31)) return NW_ERR_UNSUPPORTED;
+    }
     if (!x || !amax_in || !w_split || !w_scale || !y) return NW_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y) |
          reinterpret_cast<uintptr_t>(w_scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) |
@@ -637,6 +646,7 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
     if (!p.zeros) return NW_ERR_LAUNCH;
     p.N = (int)n; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout; p.KH = (int)KH; p.KW = (int)KW;
     p.stride = (int)stride; p.pad = (int)pad; p.relu = relu;
+    p.ldx = (int)ldx; p.ldy = (int)ldy;
     p.Ho = (int)((H + 2 * pad - KH) / stride + 1);
     p.Wo = (int)((W + 2 * pad - KW) / stride + 1);
     p.IP = (int)(W + pad);

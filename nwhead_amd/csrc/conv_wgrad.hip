@@ -32,6 +32,7 @@ struct WgradP {
     float* part;             // [ks][Cout][T][Cin]
     const float4* zeros;
     int N, H, W, Cin, Cout, T, KW, pad;
+    int ldx, ldg;            // floats between consecutive pixels of x / gy (>= Cin / Cout)
     int IP, IMG;             // virtual raster: row stride (W + 1 with taps, W without), image stride
     int nstage;              // 32-position stages in all
     int ks, spc;             // position chunks, stages per chunk
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
                 const int px = (row < 32 && sg >= s0 && sg < s1) ? pixel(pg[q]) : -1;
                 const int ch = co0 + 8 * g_c;
                 const bool ok = px >= 0 && ch < p.Cout;
-                const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.gy + (size_t)px * p.Cout + ch) : zpage);
+                const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.gy + (size_t)px * p.ldg + ch) : zpage);
                 L.g[q][0] = src[0];
                 L.g[q][1] = src[1];
                 advance(pg[q]);
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
                 const int px = row < 32 ? pixel(px_[q]) : -1;
                 const int ch = ci0 + 8 * x_c;
                 const bool ok = px >= 0 && ch < p.Cin;
-                const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.x + (size_t)px * p.Cin + ch) : zpage);
+                const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.x + (size_t)px * p.ldx + ch) : zpage);
                 L.x[q][0] = src[0];
                 L.x[q][1] = src[1];
                 advance(px_[q]);
@@ -421,10 +422,14 @@ extern "C" const void* nw_conv_zero_page(void);
 
 extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, const float* gy, const float* amax_g, float* dw,
                                           void* workspace, size_t workspace_bytes, int64_t n, int64_t H, int64_t W, int64_t Cin,
-                                          int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, void* stream) {
+                                          int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int64_t ldx,
+                                          int64_t ldg, void* stream) {
     using namespace nw;
     WgPlan pl;
     if (!wgrad_plan(n, H, W, Cin, Cout, KH, KW, stride, pad, &pl)) return NW_ERR_UNSUPPORTED;
+    if (ldx == 0) ldx = Cin;
+    if (ldg == 0) ldg = Cout;
+    if (ldx < Cin || ldg < Cout || ldx % 4 || ldg % 4) return NW_ERR_INVALID_ARG;
     if (!x || !amax_x || !gy || !amax_g || !dw) return NW_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dw) |
          reinterpret_cast<uintptr_t>(amax_x) | reinterpret_cast<uintptr_t>(amax_g) | reinterpret_cast<uintptr_t>(workspace)) & 15)
@@ -438,6 +443,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, c
     p.zeros = static_cast<const float4*>(nw_conv_zero_page());
     if (!p.zeros) return NW_ERR_LAUNCH;
     p.N = (int)n; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout; p.T = (int)(KH * KW); p.KW = (int)KW; p.pad = (int)pad;
+    p.ldx = (int)ldx; p.ldg = (int)ldg;
     p.IP = pl.IP; p.IMG = pl.IMG; p.nstage = pl.nstage; p.ks = pl.ks; p.spc = pl.spc; p.co_tiles = pl.co_tiles; p.ci_tiles = pl.ci_tiles;
     const unsigned grid = (unsigned)((int64_t)pl.ks * pl.co_tiles * pl.ci_tiles);
     if (pl.taps9) {

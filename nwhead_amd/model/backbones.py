@@ -146,6 +146,8 @@ FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.b
 # cores with split-fp16 operands (ops.conv2d_nhwc_train, csrc/conv_nhwc.hip + conv_wgrad.hip) and BatchNorm + ReLU through
 # csrc/bn_nhwc.hip; the DenseNets take this path.  NW_NHWC_TRAINING=0: the NCHW path (MIOpen convolutions).
 NHWC_TRAINING = _os.environ.get("NW_NHWC_TRAINING", "1") != "0"
+# a dense block of the channels-last training path as one autograd node over one slab (ops._DenseBlockNhwcFn)
+DENSE_SLAB = _os.environ.get("NW_DENSE_SLAB", "1") != "0"
 
 
 def _fused_training(bn, x):
@@ -241,8 +243,11 @@ class _DenseBlock(nn.Module):
         """Channels-last training forward of the block (DenseNet._forward_nhwc_train): the running concatenation passes
         through norm1's autograd node like in forward() below."""
         from .. import ops
+        layers = list(self.children())
+        if DENSE_SLAB and ops.dense_block_nhwc_supported(x, layers, bank):
+            return ops.dense_block_nhwc_train(x, layers, bank)      # one autograd node over one slab: no concatenations
         cur = x
-        for layer in self.children():
+        for layer in layers:
             a, cur = ops.bn_relu_train_nhwc(cur, layer.norm1, True, passthrough=True)
             o1 = bank.operands(layer.conv1.weight) if bank is not None else None
             o2 = bank.operands(layer.conv2.weight) if bank is not None else None

@@ -903,7 +903,7 @@ def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0
     with _OnDevice(x.device):
         _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(x), _ptr(amax), _ptr(weight.split), _ptr(weight.scale),
                                             None if bias is None else _ptr(_f32c(bias)), _ptr(residual), int(bool(relu)),
-                                            _ptr(y), _ptr(am_out), n, h, w, cin, cout, kh, kw, int(stride), int(pad),
+                                            _ptr(y), _ptr(am_out), n, h, w, cin, cout, kh, kw, int(stride), int(pad), 0, 0,
                                             _stream(x)), "nw_conv2d_nhwc_f16x2")
     if want_amax:
         y.nw_amax = am_out
@@ -986,7 +986,7 @@ class _BNReLUNhwcFn(torch.autograd.Function):
         ws = _workspace(ws_bytes, dev)
         with _OnDevice(dev):
             _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(xv), ctx.ldx, _ptr(gy), _ptr(wc), _ptr(bc), _ptr(mean), _ptr(invstd),
-                                                         _ptr(dx), _ptr(dg), _ptr(db), _ptr(acc), ldacc, _ptr(amax), _ptr(ws),
+                                                         _ptr(dx), _ptr(dg), _ptr(db), _ptr(acc), ldacc, 0, _ptr(amax), _ptr(ws),
                                                          ws_bytes, rows, c, int(ctx.relu), _stream(xv)),
                        "nw_bn_relu_nhwc_train_bwd_f32")
         dx.nw_amax = amax
@@ -1083,6 +1083,9 @@ class ConvWeightBank:
                                                                _ptr(self.split), _ptr(self.scale), _stream(self.split)),
                        "nw_split_conv_weights_f16x2")
         self._sig = sig
+
+    def has(self, w):
+        return id(w) in self._ops
 
     def operands(self, w):
         """(forward operand, data-gradient operand or None) of weight parameter w."""
@@ -1192,12 +1195,188 @@ def conv2d_nhwc_wgrad(x, gy, wshape, stride, pad, amax_x=None, amax_g=None):
         ws = _workspace(ws_bytes, x.device)
         with _OnDevice(x.device):
             _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(x), _ptr(amax_x), _ptr(gy), _ptr(amax_g), _ptr(dw), _ptr(ws), ws_bytes,
-                                                      n, h, w, cin, cout, kh, kw, stride, pad, _stream(x)),
+                                                      n, h, w, cin, cout, kh, kw, stride, pad, 0, 0, _stream(x)),
                        "nw_conv2d_nhwc_wgrad_f16x2")
         return dw.permute(0, 3, 1, 2)
     return torch.ops.aten.convolution_backward(gy.contiguous(), x.contiguous(), torch.empty(wshape, dtype=x.dtype, device=x.device),
                                                None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
                                                [False, True, False])[1]
+
+
+def _bn_tracking(bn):
+    """(running_mean, running_var, momentum, num_batches_tracked) as nw_bn_relu_nhwc_train_fwd_f32 takes them."""
+    if not (bn.track_running_stats and bn.running_mean is not None):
+        return None, None, 0.0, None
+    if bn.momentum is None:
+        bn.num_batches_tracked += 1
+        return bn.running_mean, bn.running_var, 1.0 / float(bn.num_batches_tracked), None
+    return bn.running_mean, bn.running_var, float(bn.momentum), bn.num_batches_tracked
+
+
+class _DenseBlockNhwcFn(torch.autograd.Function):
+    """A whole dense block (model/densenet.py:62-80: every layer reads the concatenation of the block's input and all
+    earlier layers' outputs) as ONE autograd node over ONE slab: the block's output tensor (rows = n h w, C0 + L growth
+    floats per row) is allocated once, the input is copied into its first C0 channels, and every layer's 3x3 convolution
+    writes its `growth` channels into place (row stride = the slab's width), so no concatenation is ever made; norm1 of a
+    layer reads a channel prefix of the slab.  The backward keeps ONE gradient slab: a layer's gradient is a channel window
+    of it, and norm1's backward kernel adds its dx into the prefix in place -- the O(L^2) gradient accumulations and slice
+    copies autograd derives for the concatenations do not exist.  Same kernels and arithmetic as the layer-by-layer path
+    (ops.bn_relu_train_nhwc, ops.conv2d_nhwc_train); parameter gradients in the order of `params`:
+    per layer norm1.weight, norm1.bias, conv1.weight, norm2.weight, norm2.bias, conv2.weight."""
+
+    @staticmethod
+    def forward(ctx, x, layers, bank, *params):
+        lib = _lib.load()
+        xv, ldx0 = _nhwc_rows(x.detach())
+        n, c0, h, w = xv.shape
+        rows, dev = n * h * w, xv.device
+        L = len(layers)
+        growth = layers[0].conv2.weight.shape[0]
+        mid = layers[0].conv1.weight.shape[0]
+        ctot = c0 + L * growth
+        slab = torch.empty((n, ctot, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        slab[:, :c0] = xv
+        st = _stream(xv)
+        saved, meta = [], []
+        f32 = dict(dtype=torch.float32, device=dev)
+        with _OnDevice(dev):
+            for k, layer in enumerate(layers):
+                c = c0 + k * growth
+                g1, b1, w1, g2, b2, w2 = (t.detach() for t in params[6 * k:6 * k + 6])
+                g1, b1, g2, b2 = _f32c(g1), _f32c(b1), _f32c(g2), _f32c(b2)
+                o1, o2 = bank.operands(layer.conv1.weight), bank.operands(layer.conv2.weight)
+                t1 = torch.empty((rows, c), **f32)
+                u = torch.empty((rows, mid), **f32)
+                t2 = torch.empty((rows, mid), **f32)
+                stats = torch.empty(2 * c + 2 * mid, **f32)            # mean1 | invstd1 | mean2 | invstd2
+                am = torch.empty(2 * AMAX_SLOTS, **f32)                # amax records of t1 | t2
+                m1, i1, m2, i2 = stats[:c], stats[c:2 * c], stats[2 * c:2 * c + mid], stats[2 * c + mid:]
+                ws_bytes = max(lib.nw_bn_nhwc_workspace_bytes(rows, c), lib.nw_bn_nhwc_workspace_bytes(rows, mid))
+                ws = _workspace(ws_bytes, dev)
+                rm, rv, mom, nbt = _bn_tracking(layer.norm1)
+                _lib.check(lib.nw_bn_relu_nhwc_train_fwd_f32(_ptr(slab), ctot, _ptr(g1), _ptr(b1), _ptr(rm), _ptr(rv), _ptr(t1),
+                                                             _ptr(m1), _ptr(i1), _ptr(nbt), _ptr(am), _ptr(ws), ws_bytes, rows, c,
+                                                             mom, float(layer.norm1.eps), 1, st), "nw_bn_relu_nhwc_train_fwd_f32")
+                _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(t1), _ptr(am), _ptr(o1[0].split), _ptr(o1[0].scale), None, None, 0,
+                                                    _ptr(u), None, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, st), "nw_conv2d_nhwc_f16x2")
+                rm, rv, mom, nbt = _bn_tracking(layer.norm2)
+                _lib.check(lib.nw_bn_relu_nhwc_train_fwd_f32(_ptr(u), mid, _ptr(g2), _ptr(b2), _ptr(rm), _ptr(rv), _ptr(t2),
+                                                             _ptr(m2), _ptr(i2), _ptr(nbt), am.data_ptr() + 4 * AMAX_SLOTS,
+                                                             _ptr(ws), ws_bytes, rows, mid, mom, float(layer.norm2.eps), 1, st),
+                           "nw_bn_relu_nhwc_train_fwd_f32")
+                kh = w2.shape[2]
+                _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, _ptr(o2[0].split), _ptr(o2[0].scale),
+                                                    None, None, 0, slab.data_ptr() + 4 * c, None, n, h, w, mid, growth, kh, kh, 1,
+                                                    kh // 2, 0, ctot, st), "nw_conv2d_nhwc_f16x2")
+                saved += [t1, u, t2, stats, am, g1, b1, g2, b2]
+                meta.append((c, kh, o1[1], o2[1], tuple(w1.shape), tuple(w2.shape)))
+        ctx.save_for_backward(slab, *saved)
+        ctx.meta, ctx.dims = meta, (n, c0, h, w, growth, mid, ctot)
+        return slab
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        slab, *saved = ctx.saved_tensors
+        n, c0, h, w, growth, mid, ctot = ctx.dims
+        rows, dev = n * h * w, slab.device
+        am_g = getattr(gout, "nw_amax", None)
+        G = gout.float().contiguous(memory_format=torch.channels_last)
+        if G.data_ptr() == gout.data_ptr():
+            G = G.clone(memory_format=torch.channels_last)             # the gradient slab is updated in place
+        if am_g is None:
+            am_g = absmax(G)
+        st = _stream(slab)
+        f32 = dict(dtype=torch.float32, device=dev)
+        grads = [None] * (6 * len(ctx.meta))
+        with _OnDevice(dev):
+            for k in range(len(ctx.meta) - 1, -1, -1):
+                c, kh, d1, d2, w1s, w2s = ctx.meta[k]
+                t1, u, t2, stats, am, g1, b1, g2, b2 = saved[9 * k:9 * k + 9]
+                m1, i1, m2, i2 = stats[:c], stats[c:2 * c], stats[2 * c:2 * c + mid], stats[2 * c + mid:]
+                gv = G.data_ptr() + 4 * c                              # this layer's window of the gradient slab
+                # conv2 (3x3): weight gradient, data gradient
+                dw2 = torch.empty((growth, kh, kh, mid), **f32)
+                wsb = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, mid, growth, kh, kh, 1, kh // 2)
+                ws = _workspace(wsb, dev)
+                _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, gv, _ptr(am_g), _ptr(dw2),
+                                                          _ptr(ws), wsb, n, h, w, mid, growth, kh, kh, 1, kh // 2, 0, ctot, st),
+                           "nw_conv2d_nhwc_wgrad_f16x2")
+                dt2 = torch.empty((rows, mid), **f32)
+                am_d = torch.empty(3 * AMAX_SLOTS, **f32)              # amax records of dt2 | du | dt1
+                _lib.check(lib.nw_conv2d_nhwc_f16x2(gv, _ptr(am_g), _ptr(d2.split), _ptr(d2.scale), None, None, 0, _ptr(dt2),
+                                                    _ptr(am_d), n, h, w, growth, mid, kh, kh, 1, kh - 1 - kh // 2, ctot, 0, st),
+                           "nw_conv2d_nhwc_f16x2")
+                # norm2 + relu
+                du = torch.empty((rows, mid), **f32)
+                dg2, db2 = torch.empty(mid, **f32), torch.empty(mid, **f32)
+                bnb = max(lib.nw_bn_nhwc_workspace_bytes(rows, c), lib.nw_bn_nhwc_workspace_bytes(rows, mid))
+                wsn = _workspace(bnb, dev)
+                _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(u), mid, _ptr(dt2), _ptr(g2), _ptr(b2), _ptr(m2), _ptr(i2),
+                                                             _ptr(du), _ptr(dg2), _ptr(db2), None, 0, 0,
+                                                             am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(wsn), bnb, rows, mid, 1, st),
+                           "nw_bn_relu_nhwc_train_bwd_f32")
+                # conv1 (1x1)
+                dw1 = torch.empty((mid, 1, 1, c), **f32)
+                wsb = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, c, mid, 1, 1, 1, 0)
+                ws = _workspace(wsb, dev)
+                _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
+                                                          _ptr(ws), wsb, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, st),
+                           "nw_conv2d_nhwc_wgrad_f16x2")
+                dt1 = torch.empty((rows, c), **f32)
+                _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,
+                                                    None, 0, _ptr(dt1), am_d.data_ptr() + 8 * AMAX_SLOTS, n, h, w, mid, c, 1, 1, 1, 0,
+                                                    0, 0, st), "nw_conv2d_nhwc_f16x2")
+                # norm1 + relu over the slab's prefix: dx is ADDED into the gradient slab's prefix, in place
+                dg1, db1 = torch.empty(c, **f32), torch.empty(c, **f32)
+                am_g = torch.empty(AMAX_SLOTS, **f32)
+                _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(slab), ctot, _ptr(dt1), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(i1),
+                                                             _ptr(G), _ptr(dg1), _ptr(db1), _ptr(G), ctot, ctot, _ptr(am_g),
+                                                             _ptr(wsn), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
+                grads[6 * k:6 * k + 6] = [dg1, db1, dw1.permute(0, 3, 1, 2), dg2, db2, dw2.permute(0, 3, 1, 2)]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = G[:, :c0].contiguous(memory_format=torch.channels_last)
+            dx.nw_amax = am_g
+        return (dx, None, None, *grads)
+
+
+def dense_block_nhwc_supported(x, layers, bank):
+    """Can ops.dense_block_nhwc_train run this block?  (channels-last fp32 on the device, a weight bank that holds every
+    layer's forward and data-gradient operands, affine BatchNorms, no dropout, shapes the convolution kernels serve)"""
+    if bank is None or not x.is_cuda or x.dim() != 4 or not layers:
+        return False
+    lib = _lib.load()
+    n, c0, h, w = x.shape
+    growth, mid = layers[0].conv2.weight.shape[0], layers[0].conv1.weight.shape[0]
+    if n * h * w <= 1 or c0 % 32 or growth % 32 or mid % 32 or c0 + len(layers) * growth > 1024:
+        return False
+    for k, layer in enumerate(layers):
+        c = c0 + k * growth
+        w1, w2 = layer.conv1.weight, layer.conv2.weight
+        kh = w2.shape[2]
+        if (layer.drop_rate > 0 or tuple(w1.shape) != (mid, c, 1, 1) or tuple(w2.shape) != (growth, mid, kh, kh) or kh % 2 == 0
+                or not (layer.norm1.affine and layer.norm2.affine) or layer.norm1.weight is None or layer.norm2.weight is None):
+            return False
+        for wt in (w1, w2):
+            ops_ = bank.operands(wt) if bank.has(wt) else None
+            if ops_ is None or ops_[0] is None or ops_[1] is None:
+                return False
+        if not (lib.nw_conv2d_nhwc_wgrad_supported(n, h, w, c, mid, 1, 1, 1, 0)
+                and lib.nw_conv2d_nhwc_wgrad_supported(n, h, w, mid, growth, kh, kh, 1, kh // 2)):
+            return False
+    return True
+
+
+def dense_block_nhwc_train(x, layers, bank):
+    """The dense block `layers` (modules with norm1, conv1, norm2, conv2) over a channels-last activation as one autograd node
+    over one slab (_DenseBlockNhwcFn); returns the block's output (n, C0 + L growth, h, w), channels_last."""
+    params = []
+    for layer in layers:
+        params += [layer.norm1.weight, layer.norm1.bias, layer.conv1.weight, layer.norm2.weight, layer.norm2.bias,
+                   layer.conv2.weight]
+    _need_hip(x, *params)
+    return _DenseBlockNhwcFn.apply(x, tuple(layers), bank, *params)
 
 
 def conv2d_nhwc_train(x, weight, stride=1, pad=0, amax=None, operands=None):
