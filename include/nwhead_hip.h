@@ -352,7 +352,14 @@ int nw_conv2d_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t Cin, int64
 int nw_conv2d_nhwc_f16x2(const float *x, const float *amax_in, const float *w_split, const float *w_scale,
                          const float *bias, const float *residual, int relu, float *y, float *amax_out,
                          int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
-                         int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, void *stream);
+                         int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, float *moments, void *stream);
+/* moments (nullable, Cin % 32 == 0): the convolution also leaves BatchNorm's batch statistics of y, so the BatchNorm that
+ * follows (model/densenet.py:33-60: conv1 -> norm2; the next layers' norm1 over conv2's channels) needs no pass over y:
+ * per group g of output pixels and channel co, moments[(k G + g) Cout + co] = k 0: pixels in the group, 1: their mean,
+ * 2: the sum of squared deviations from it; G = nw_conv2d_nhwc_moments_groups(same shape arguments) groups; the buffer
+ * holds (3 G + 48) Cout floats (the tail is scratch of nw_bn_nhwc_moments_from_partials_f32, which merges the groups). */
+int64_t nw_conv2d_nhwc_moments_groups(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                                      int64_t stride, int64_t pad);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ ReLU) in front of / behind the backbones' convolutions, forward and
@@ -427,6 +434,20 @@ int nw_bn_relu_nhwc_train_fwd_f32(const float *x, int64_t ldx, const float *gamm
                                   float *running_var, float *y, float *save_mean, float *save_invstd,
                                   int64_t *num_batches_tracked, float *amax_out, void *workspace, size_t workspace_bytes,
                                   int64_t rows, int64_t c, float momentum, float eps, int relu, void *stream);
+/* The forward in phases, for a caller that has the batch statistics from elsewhere (a dense block: a channel's statistics
+ * are the same for every later layer's norm1, and a convolution's epilogue leaves the moments of what it writes):
+ *   nw_bn_nhwc_moments_f32                mean, 1/sqrt(var + eps), biased var of the c channels of x (c,) each
+ *   nw_bn_nhwc_moments_from_partials_f32  the same from the groups a convolution left (nw_conv2d_nhwc_f16x2's `moments`)
+ *   nw_bn_relu_nhwc_apply_f32             y = act((x - mean) gamma invstd + beta) + the amax record of y; updates THIS
+ *                                         layer's running statistics (momentum; unbiased var) and step counter */
+int nw_bn_nhwc_moments_f32(const float *x, int64_t ldx, int64_t rows, int64_t c, float eps, float *mean, float *invstd,
+                           float *var, void *workspace, size_t workspace_bytes, void *stream);
+int nw_bn_nhwc_moments_from_partials_f32(float *partials, int64_t groups, int64_t c, float eps, float *mean,
+                                         float *invstd, float *var, void *stream);
+int nw_bn_relu_nhwc_apply_f32(const float *x, int64_t ldx, const float *mean, const float *invstd, const float *var,
+                              const float *gamma, const float *beta, float *running_mean, float *running_var,
+                              int64_t *num_batches_tracked, float momentum, float *y, float *amax_out, int64_t rows,
+                              int64_t c, int relu, void *stream);
 int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, const float *gamma, const float *beta,
                                   const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
                                   float *dbeta, const float *acc, int64_t ldacc, int64_t lddx, float *amax_out,

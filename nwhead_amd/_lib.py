@@ -56,7 +56,11 @@ SIGNATURES = {
     "nw_absmax_f32": (_int, [_p, _i64, _p, _p]),
     "nw_to_nhwc_pad_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "nw_conv2d_nhwc_supported": (_int, [_i64] * 9),
-    "nw_conv2d_nhwc_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _int, _p, _p] + [_i64] * 11 + [_p]),
+    "nw_conv2d_nhwc_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _int, _p, _p] + [_i64] * 11 + [_p, _p]),
+    "nw_conv2d_nhwc_moments_groups": (_i64, [_i64] * 9),
+    "nw_bn_nhwc_moments_f32": (_int, [_p, _i64, _i64, _i64, C.c_float, _p, _p, _p, _p, _sz, _p]),
+    "nw_bn_nhwc_moments_from_partials_f32": (_int, [_p, _i64, _i64, C.c_float, _p, _p, _p, _p]),
+    "nw_bn_relu_nhwc_apply_f32": (_int, [_p, _i64] + [_p] * 8 + [C.c_float, _p, _p, _i64, _i64, _int, _p]),
     "nw_split_conv_weights_f16x2": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "nw_conv2d_nhwc_wgrad_supported": (_int, [_i64] * 9),
     "nw_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i64] * 9),

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_stats_kernel(const float* __r
 __global__ __launch_bounds__(1024) void nw_bn_nhwc_finalize_kernel(const float* __restrict__ part, int G, int C,
                                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                     float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                                    int64_t* __restrict__ num_batches_tracked, float momentum, float eps) {
+                                                                    int64_t* __restrict__ num_batches_tracked, float momentum, float eps,
+                                                                    float* __restrict__ save_var) {
     __shared__ float sh[3][16][64];
     const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -108,8 +109,60 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_finalize_kernel(const float* 
     const float var = n > 0.f ? fmaxf(m2 / n, 0.f) : 0.f;
     save_mean[c] = mean;
     save_invstd[c] = 1.f / sqrtf(var + eps);
+    if (save_var) save_var[c] = var;
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
+}
+
+// The moments of MANY groups (what a convolution's epilogue leaves: thousands of 16..64-pixel groups) to mean, 1/sqrt(var +
+// eps) and the biased variance, in parallel over the groups: 16 channels x 64 group lanes per workgroup, two passes over the
+// partials -- the weighted mean, then sum(M2_g + n_g (mean_g - mean)^2) -- each summed per lane over groups j, j + 64, ... and
+// over the 64 lanes in a fixed order (deterministic; Chan's pairwise merge of nw_bn_nhwc_finalize_kernel is a serial chain
+// per lane: fine for <= 256 chunks, 130 dependent steps at 2058 groups).
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_merge_groups_kernel(const float* __restrict__ part, int G, int C, float eps,
+                                                                        float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                        float* __restrict__ save_var, float* __restrict__ slices) {
+    // blockIdx.y = slice of the groups (gridDim.y > 1: the slice's own count / mean / M2 go to `slices` in the layout
+    // nw_bn_nhwc_finalize_kernel merges, [k][slice][C]; one slice: the final values)
+    __shared__ float sh[2][64][17];
+    const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool live = c < C;
+    const int S = gridDim.y, per = (G + S - 1) / S, g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+    float sn = 0.f, sm = 0.f;
+    if (live)
+        for (int g = g0 + j; g < g1; g += 64) {
+            const float n = part[(int64_t)g * C + c];
+            sn += n;
+            sm = __builtin_fmaf(n, part[((int64_t)G + g) * C + c], sm);
+        }
+    sh[0][j][cl] = sn; sh[1][j][cl] = sm;
+    __syncthreads();
+    float tn = 0.f, tm = 0.f;
+    for (int k = 0; k < 64; ++k) { tn += sh[0][k][cl]; tm += sh[1][k][cl]; }
+    const float mean = tn > 0.f ? tm / tn : 0.f;
+    __syncthreads();
+    float q = 0.f;
+    if (live)
+        for (int g = g0 + j; g < g1; g += 64) {
+            const float n = part[(int64_t)g * C + c], d = part[((int64_t)G + g) * C + c] - mean;
+            q += __builtin_fmaf(n * d, d, part[((int64_t)2 * G + g) * C + c]);
+        }
+    sh[0][j][cl] = q;
+    __syncthreads();
+    if (j != 0 || !live) return;
+    float tq = 0.f;
+    for (int k = 0; k < 64; ++k) tq += sh[0][k][cl];
+    if (S > 1) {
+        slices[((int64_t)0 * S + blockIdx.y) * C + c] = tn;
+        slices[((int64_t)1 * S + blockIdx.y) * C + c] = mean;
+        slices[((int64_t)2 * S + blockIdx.y) * C + c] = fmaxf(tq, 0.f);
+        return;
+    }
+    const float var = tn > 0.f ? fmaxf(tq / tn, 0.f) : 0.f;
+    save_mean[c] = mean;
+    save_invstd[c] = 1.f / sqrtf(var + eps);
+    save_var[c] = var;
 }
 
 // y[r][c] = act((x[r][c] - mean[c]) a[c] + beta[c]), a = gamma invstd; amax record of y
@@ -117,13 +170,23 @@ template <bool RELU>
 __global__ __launch_bounds__(1024) void nw_bn_nhwc_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                                  const float* __restrict__ save_invstd, float* __restrict__ y,
-                                                                 float* __restrict__ amax, int64_t R, int C) {
+                                                                 float* __restrict__ amax, int64_t R, int C,
+                                                                 const float* __restrict__ batch_var, float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked,
+                                                                 float momentum, float unbias) {
     extern __shared__ float prm[];   // [3][C]: mean, a, beta
     __shared__ float red[16];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         prm[c] = save_mean[c];
         prm[C + c] = gamma[c] * save_invstd[c];
         prm[2 * C + c] = beta[c];
+    }
+    if (blockIdx.x == 0 && batch_var) {   // statistics that came from elsewhere (nw_bn_relu_nhwc_apply_f32): this layer's running ones
+        if (num_batches_tracked && threadIdx.x == 0) *num_batches_tracked += 1;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * save_mean[c];
+            if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * batch_var[c] * unbias;
+        }
     }
     __syncthreads();
     const int q4 = C >> 2;
@@ -311,15 +374,82 @@ extern "C" int nw_bn_relu_nhwc_train_fwd_f32(const float* x, int64_t ldx, const 
     const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
     hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, part, rows, (int)c, G, rpc);
     hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, running_mean,
-                       running_var, save_mean, save_invstd, num_batches_tracked, momentum, eps);
+                       running_var, save_mean, save_invstd, num_batches_tracked, momentum, eps, (float*)nullptr);
     const int ag = apply_grid(rows, c);
     const size_t lds = (size_t)3 * c * sizeof(float);
     if (relu)
         hipLaunchKernelGGL((nw_bn_nhwc_apply_kernel<true>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, gamma, beta, save_mean,
-                           save_invstd, y, amax_out, rows, (int)c);
+                           save_invstd, y, amax_out, rows, (int)c, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (int64_t*)nullptr, 0.f, 1.f);
     else
         hipLaunchKernelGGL((nw_bn_nhwc_apply_kernel<false>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, gamma, beta, save_mean,
-                           save_invstd, y, amax_out, rows, (int)c);
+                           save_invstd, y, amax_out, rows, (int)c, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (int64_t*)nullptr, 0.f, 1.f);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+// ---- the forward in phases, for callers that get the batch statistics elsewhere (a dense block: the statistics of a
+// channel do not change from layer to layer, and a convolution's epilogue leaves the moments of what it writes)
+extern "C" int nw_bn_nhwc_moments_f32(const float* x, int64_t ldx, int64_t rows, int64_t c, float eps, float* mean, float* invstd,
+                                      float* var, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace nw;
+    if (rows <= 0 || c <= 0 || c % 4 || ldx < c || ldx % 4) return NW_ERR_INVALID_ARG;
+    if (!x || !mean || !invstd || !var) return NW_ERR_INVALID_ARG;
+    if (bad_align(x, workspace) || bad_align(mean, invstd, var)) return NW_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < nw_bn_nhwc_workspace_bytes(rows, c)) return NW_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int G; int64_t rpc;
+    stats_grid(rows, c, &G, &rpc);
+    float* part = static_cast<float*>(workspace);
+    const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
+    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, part, rows, (int)c, G, rpc);
+    hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, (float*)nullptr,
+                       (float*)nullptr, mean, invstd, (int64_t*)nullptr, 0.f, eps, var);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_bn_nhwc_moments_from_partials_f32(float* partials, int64_t groups, int64_t c, float eps, float* mean,
+                                                    float* invstd, float* var, void* stream) {
+    using namespace nw;
+    if (groups <= 0 || groups >= (1LL << 30) || c <= 0) return NW_ERR_INVALID_ARG;
+    if (!partials || !mean || !invstd || !var) return NW_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // many groups (the 56x56 and 28x28 layers leave thousands): sliced over up to 16 workgroups per 16 channels, the slices'
+    // moments (behind the groups in the same buffer: 48 c more floats) merged by the chunk-merge kernel
+    int S = (int)(groups / 256);
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    float* slices = partials + (size_t)3 * groups * c;
+    hipLaunchKernelGGL(nw_bn_nhwc_merge_groups_kernel, dim3((unsigned)((c + 15) / 16), (unsigned)S), dim3(1024), 0, st, partials,
+                       (int)groups, (int)c, eps, mean, invstd, var, slices);
+    if (S > 1)
+        hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, slices, S, (int)c,
+                           (float*)nullptr, (float*)nullptr, mean, invstd, (int64_t*)nullptr, 0.f, eps, var);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_bn_relu_nhwc_apply_f32(const float* x, int64_t ldx, const float* mean, const float* invstd, const float* var,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                         int64_t* num_batches_tracked, float momentum, float* y, float* amax_out, int64_t rows,
+                                         int64_t c, int relu, void* stream) {
+    using namespace nw;
+    if (rows <= 0 || c <= 0 || c % 4 || ldx < c || ldx % 4) return NW_ERR_INVALID_ARG;
+    if (!x || !mean || !invstd || !var || !gamma || !beta || !y) return NW_ERR_INVALID_ARG;
+    if (bad_align(x, y, amax_out) || bad_align(gamma, beta, mean, invstd)) return NW_ERR_INVALID_ARG;
+    if (c > 1024) return NW_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ag = apply_grid(rows, c);
+    const size_t lds = (size_t)3 * c * sizeof(float);
+    const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+    if (relu)
+        hipLaunchKernelGGL((nw_bn_nhwc_apply_kernel<true>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, gamma, beta, mean, invstd, y,
+                           amax_out, rows, (int)c, var, running_mean, running_var, num_batches_tracked, momentum, unbias);
+    else
+        hipLaunchKernelGGL((nw_bn_nhwc_apply_kernel<false>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, gamma, beta, mean, invstd, y,
+                           amax_out, rows, (int)c, var, running_mean, running_var, num_batches_tracked, momentum, unbias);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

@@ -43,6 +43,8 @@ struct ConvP {
     const float* res;        // nullable (M, Cout)
     float* y;
     float* amax_out;         // nullable: CV_AMAX_SLOTS floats
+    float* moments;          // nullable: per (tile row, wave row) group and output channel the count, mean and M2 of y
+                             //   (part[(k G + group) Cout + co], G = mtiles WN): BatchNorm's statistics of y without a pass over it
     const float4* zeros;     // 32 bytes of zeros (what a loader reads for a pixel that does not exist)
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
     int ldx, ldy;            // floats between consecutive pixels of x / y (>= Cin / Cout: a channel window of a wider tensor)
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     using C = ConvCfg<NA, NB, WM, MODE>;
     constexpr bool PATCH = C::PATCH, ROWRUN = C::ROWRUN;
     constexpr int BN = C::BN, BM = C::BM, NIW = C::NIW, NPASS = C::NPASS, NACT = C::NACT, TI = C::TI, NSET = C::NSET;
-    constexpr int NWR = C::NWR, AH = C::AH, WST = C::WST, PB = C::PB, NPB = C::NPB, UNR = C::UNR;
+    constexpr int NWR = C::NWR, AH = C::AH, WST = C::WST, PB = C::PB, NPB = C::NPB, UNR = C::UNR, WN = C::WN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wring = smem;
     char* const pbuf = smem + NWR * WST;
@@ -476,6 +478,47 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     }
                     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                     *reinterpret_cast<float4*>(p.y + o) = v;
+                    acc[a][b] = f32x4{v.x, v.y, v.z, v.w};
+                }
+            }
+        }
+        if (p.moments) {
+            // Welford moments of this wave's pixel rows [m0 + wpx, + 16 NB) per output channel, two passes over the values
+            // still in registers (mean, then centred squares); the 16 lanes of a row hold 16 pixels of the same 4 channels:
+            // summed by four DPP rotations.  One group per (tile row, wave row); merged with Chan's formula by the finalize
+            // kernel of bn_nhwc.hip in a fixed order.
+            const int nw_ = min(max(p.M - (m0 + wpx), 0), 16 * NB);
+            const float cnt = (float)nw_, rc = nw_ > 0 ? 1.f / cnt : 0.f;
+            auto rowsum = [](float x) {
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));  // row_ror:4
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+                return x;
+            };
+            const int G = p.mtiles * WN, grp = mt * WN + wave / WM;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                float mean[4], m2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) s += (m0 + wpx + 16 * b + i < p.M) ? acc[a][b][e] : 0.f;
+                    mean[e] = rowsum(s) * rc;
+                    float q = 0.f;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const float d = (m0 + wpx + 16 * b + i < p.M) ? acc[a][b][e] - mean[e] : 0.f;
+                        q = __builtin_fmaf(d, d, q);
+                    }
+                    m2[e] = rowsum(q);
+                }
+                if (i == 0) {
+                    const int co = co0 + wco + 16 * a + 4 * g;
+                    *reinterpret_cast<float4*>(p.moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(cnt, cnt, cnt, cnt);
+                    *reinterpret_cast<float4*>(p.moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(mean[0], mean[1], mean[2], mean[3]);
+                    *reinterpret_cast<float4*>(p.moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(m2[0], m2[1], m2[2], m2[3]);
                 }
             }
         }
@@ -553,11 +596,15 @@ int num_cus() {
     return v;
 }
 
+// moments_groups (host, nullable): receives the number of groups the moments buffer holds (mtiles x wave rows);
+// dry: only report it (nw_conv2d_nhwc_moments_groups)
 template <int NA, int NB, int WM, int MODE>
-int launch_conv_cfg(ConvP p, hipStream_t st) {
+int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, bool dry = false) {
     using C = ConvCfg<NA, NB, WM, MODE>;
     p.mtiles = (p.M + C::BM - 1) / C::BM;
     p.ntiles = p.Cout / C::BN;
+    if (moments_groups) *moments_groups = (int64_t)p.mtiles * C::WN;
+    if (dry) return NW_OK;
     const int64_t total = (int64_t)p.mtiles * p.ntiles;
     int64_t grid = num_cus() < CV_AMAX_SLOTS ? num_cus() : CV_AMAX_SLOTS;
     const int cap = knob(KNOB_CONV_MAX_WGS);   // tests: many tiles per workgroup (diagnostic knob "conv_max_wgs")
@@ -618,11 +665,13 @@ extern "C" int nw_conv2d_nhwc_supported(int64_t n, int64_t H, int64_t W, int64_t
     return 1;
 }
 
-extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const float* w_split, const float* w_scale,
-                                    const float* bias, const float* residual, int relu, float* y, float* amax_out,
-                                    int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
-                                    int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, void* stream) {
+static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w_split, const float* w_scale,
+                           const float* bias, const float* residual, int relu, float* y, float* amax_out,
+                           int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                           int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, float* moments, int64_t* moments_groups,
+                           bool dry, void* stream) {
     if (n < 0 || H < 0 || W < 0) return NW_ERR_INVALID_ARG;
+    if (moments_groups) *moments_groups = 0;
     if (n == 0) return NW_OK;
     if (!nw_conv2d_nhwc_supported(n, H, W, Cin, Cout, KH, KW, stride, pad)) return NW_ERR_UNSUPPORTED;
     if (ldx == 0) ldx = Cin;
@@ -633,17 +682,18 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
         const int64_t Ho_ = (H + 2 * pad - KH) / stride + 1, Wo_ = (W + 2 * pad - KW) / stride + 1;
         if (n * H * W * ldx >= (1LL << 31) || n * Ho_ * Wo_ * ldy >= (1LL << 31)) return NW_ERR_UNSUPPORTED;
     }
-    if (!x || !amax_in || !w_split || !w_scale || !y) return NW_ERR_INVALID_ARG;
+    if (!dry && (!x || !amax_in || !w_split || !w_scale || !y)) return NW_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y) |
          reinterpret_cast<uintptr_t>(w_scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) |
-         reinterpret_cast<uintptr_t>(amax_in) | reinterpret_cast<uintptr_t>(amax_out)) & 15)
+         reinterpret_cast<uintptr_t>(amax_in) | reinterpret_cast<uintptr_t>(amax_out) | reinterpret_cast<uintptr_t>(moments)) & 15)
         return NW_ERR_INVALID_ARG;
+    if ((moments || dry) && Cin % 32) return NW_ERR_UNSUPPORTED;   // (the few-channel stems leave no moments)
     hipStream_t st = static_cast<hipStream_t>(stream);
     nw::ConvP p;
     p.x = x; p.amax_in = amax_in; p.ws = reinterpret_cast<const char*>(w_split); p.wscale = w_scale; p.bias = bias;
-    p.res = residual; p.y = y; p.amax_out = amax_out;
-    p.zeros = nw::zero_page();
-    if (!p.zeros) return NW_ERR_LAUNCH;
+    p.res = residual; p.y = y; p.amax_out = amax_out; p.moments = moments;
+    p.zeros = dry ? nullptr : nw::zero_page();
+    if (!dry && !p.zeros) return NW_ERR_LAUNCH;
     p.N = (int)n; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout; p.KH = (int)KH; p.KW = (int)KW;
     p.stride = (int)stride; p.pad = (int)pad; p.relu = relu;
     p.ldx = (int)ldx; p.ldy = (int)ldy;
@@ -675,8 +725,9 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
     auto tiles = [&](int bm, int bn) { return ((int64_t)p.M + bm - 1) / bm * (Cout / bn); };
 #define NW_CONV_TRY(NA_, NB_, WM_, BM_, BN_, LAST_)                                                            \
     if (Cout % BN_ == 0 && (LAST_ || tiles(BM_, BN_) >= want)) {                                               \
-        if (k33 && patch_fits(BM_) && !force_gather) return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_PATCH>(p, st); \
-        return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_GATHER>(p, st);                                       \
+        if (k33 && patch_fits(BM_) && !force_gather)                                                            \
+            return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_PATCH>(p, st, moments_groups, dry);                \
+        return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_GATHER>(p, st, moments_groups, dry);                   \
     }
     NW_CONV_TRY(4, 4, 2, 128, 128, false)
     NW_CONV_TRY(4, 2, 1, 128, 64, false)
@@ -686,4 +737,22 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
     NW_CONV_TRY(2, 1, 1, 64, 32, true)
 #undef NW_CONV_TRY
     return NW_ERR_UNSUPPORTED;
+}
+
+extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const float* w_split, const float* w_scale,
+                                    const float* bias, const float* residual, int relu, float* y, float* amax_out,
+                                    int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                                    int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, float* moments, void* stream) {
+    int64_t groups = 0;
+    return conv2d_nhwc_impl(x, amax_in, w_split, w_scale, bias, residual, relu, y, amax_out, n, H, W, Cin, Cout, KH, KW, stride,
+                            pad, ldx, ldy, moments, moments ? &groups : nullptr, false, stream);
+}
+
+extern "C" int64_t nw_conv2d_nhwc_moments_groups(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH,
+                                                 int64_t KW, int64_t stride, int64_t pad) {
+    int64_t groups = 0;
+    if (n <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;   // (validated like the call itself)
+    const int rc = conv2d_nhwc_impl(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, n, H, W, Cin, Cout,
+                                    KH, KW, stride, pad, 0, 0, nullptr, &groups, true, nullptr);
+    return rc == NW_OK ? groups : 0;
 }

@@ -904,7 +904,7 @@ def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0
         _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(x), _ptr(amax), _ptr(weight.split), _ptr(weight.scale),
                                             None if bias is None else _ptr(_f32c(bias)), _ptr(residual), int(bool(relu)),
                                             _ptr(y), _ptr(am_out), n, h, w, cin, cout, kh, kw, int(stride), int(pad), 0, 0,
-                                            _stream(x)), "nw_conv2d_nhwc_f16x2")
+                                            None, _stream(x)), "nw_conv2d_nhwc_f16x2")
     if want_amax:
         y.nw_amax = am_out
     return y
@@ -1239,37 +1239,54 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         st = _stream(xv)
         saved, meta = [], []
         f32 = dict(dtype=torch.float32, device=dev)
+        eps = float(layers[0].norm1.eps)
+        # Batch statistics per slab channel, computed ONCE: a channel's mean and variance are the same for every later layer's
+        # norm1, the block's input channels get one pass here, and each convolution leaves the moments of the channels it writes
+        # (nw_conv2d_nhwc_f16x2's `moments`), so no BatchNorm of the block reads its input for statistics.
+        bstat = torch.empty(3 * ctot, **f32)                               # mean | invstd | var of the slab's channels
+        bm, bi, bv = bstat[:ctot], bstat[ctot:2 * ctot], bstat[2 * ctot:]
         with _OnDevice(dev):
+            wsb = lib.nw_bn_nhwc_workspace_bytes(rows, c0)
+            ws = _workspace(wsb, dev)
+            _lib.check(lib.nw_bn_nhwc_moments_f32(_ptr(slab), ctot, rows, c0, eps, _ptr(bm), _ptr(bi), _ptr(bv), _ptr(ws), wsb, st),
+                       "nw_bn_nhwc_moments_f32")
             for k, layer in enumerate(layers):
                 c = c0 + k * growth
                 g1, b1, w1, g2, b2, w2 = (t.detach() for t in params[6 * k:6 * k + 6])
                 g1, b1, g2, b2 = _f32c(g1), _f32c(b1), _f32c(g2), _f32c(b2)
                 o1, o2 = bank.operands(layer.conv1.weight), bank.operands(layer.conv2.weight)
+                kh = w2.shape[2]
                 t1 = torch.empty((rows, c), **f32)
                 u = torch.empty((rows, mid), **f32)
                 t2 = torch.empty((rows, mid), **f32)
-                stats = torch.empty(2 * c + 2 * mid, **f32)            # mean1 | invstd1 | mean2 | invstd2
-                am = torch.empty(2 * AMAX_SLOTS, **f32)                # amax records of t1 | t2
-                m1, i1, m2, i2 = stats[:c], stats[c:2 * c], stats[2 * c:2 * c + mid], stats[2 * c + mid:]
-                ws_bytes = max(lib.nw_bn_nhwc_workspace_bytes(rows, c), lib.nw_bn_nhwc_workspace_bytes(rows, mid))
-                ws = _workspace(ws_bytes, dev)
+                stats = torch.empty(3 * mid, **f32)                        # norm2: mean | invstd | var
+                am = torch.empty(2 * AMAX_SLOTS, **f32)                    # amax records of t1 | t2
+                m2, i2, v2 = stats[:mid], stats[mid:2 * mid], stats[2 * mid:]
+                G1 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, c, mid, 1, 1, 1, 0)
+                G2 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, mid, growth, kh, kh, 1, kh // 2)
+                part = _workspace(4 * max((3 * G1 + 48) * mid, (3 * G2 + 48) * growth), dev)
                 rm, rv, mom, nbt = _bn_tracking(layer.norm1)
-                _lib.check(lib.nw_bn_relu_nhwc_train_fwd_f32(_ptr(slab), ctot, _ptr(g1), _ptr(b1), _ptr(rm), _ptr(rv), _ptr(t1),
-                                                             _ptr(m1), _ptr(i1), _ptr(nbt), _ptr(am), _ptr(ws), ws_bytes, rows, c,
-                                                             mom, float(layer.norm1.eps), 1, st), "nw_bn_relu_nhwc_train_fwd_f32")
+                _lib.check(lib.nw_bn_relu_nhwc_apply_f32(_ptr(slab), ctot, _ptr(bm), _ptr(bi), _ptr(bv), _ptr(g1), _ptr(b1), _ptr(rm),
+                                                         _ptr(rv), _ptr(nbt), mom, _ptr(t1), _ptr(am), rows, c, 1, st),
+                           "nw_bn_relu_nhwc_apply_f32")
                 _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(t1), _ptr(am), _ptr(o1[0].split), _ptr(o1[0].scale), None, None, 0,
-                                                    _ptr(u), None, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, st), "nw_conv2d_nhwc_f16x2")
+                                                    _ptr(u), None, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, _ptr(part), st),
+                           "nw_conv2d_nhwc_f16x2")
+                _lib.check(lib.nw_bn_nhwc_moments_from_partials_f32(_ptr(part), G1, mid, eps, _ptr(m2), _ptr(i2), _ptr(v2), st),
+                           "nw_bn_nhwc_moments_from_partials_f32")
                 rm, rv, mom, nbt = _bn_tracking(layer.norm2)
-                _lib.check(lib.nw_bn_relu_nhwc_train_fwd_f32(_ptr(u), mid, _ptr(g2), _ptr(b2), _ptr(rm), _ptr(rv), _ptr(t2),
-                                                             _ptr(m2), _ptr(i2), _ptr(nbt), am.data_ptr() + 4 * AMAX_SLOTS,
-                                                             _ptr(ws), ws_bytes, rows, mid, mom, float(layer.norm2.eps), 1, st),
-                           "nw_bn_relu_nhwc_train_fwd_f32")
-                kh = w2.shape[2]
+                _lib.check(lib.nw_bn_relu_nhwc_apply_f32(_ptr(u), mid, _ptr(m2), _ptr(i2), _ptr(v2), _ptr(g2), _ptr(b2), _ptr(rm),
+                                                         _ptr(rv), _ptr(nbt), mom, _ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, rows,
+                                                         mid, 1, st), "nw_bn_relu_nhwc_apply_f32")
                 _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, _ptr(o2[0].split), _ptr(o2[0].scale),
                                                     None, None, 0, slab.data_ptr() + 4 * c, None, n, h, w, mid, growth, kh, kh, 1,
-                                                    kh // 2, 0, ctot, st), "nw_conv2d_nhwc_f16x2")
+                                                    kh // 2, 0, ctot, _ptr(part), st), "nw_conv2d_nhwc_f16x2")
+                _lib.check(lib.nw_bn_nhwc_moments_from_partials_f32(_ptr(part), G2, growth, eps, bm.data_ptr() + 4 * c,
+                                                                    bi.data_ptr() + 4 * c, bv.data_ptr() + 4 * c, st),
+                           "nw_bn_nhwc_moments_from_partials_f32")
                 saved += [t1, u, t2, stats, am, g1, b1, g2, b2]
                 meta.append((c, kh, o1[1], o2[1], tuple(w1.shape), tuple(w2.shape)))
+        saved.append(bstat)
         ctx.save_for_backward(slab, *saved)
         ctx.meta, ctx.dims = meta, (n, c0, h, w, growth, mid, ctot)
         return slab
@@ -1278,6 +1295,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
     def backward(ctx, gout):
         lib = _lib.load()
         slab, *saved = ctx.saved_tensors
+        bstat = saved[-1]
         n, c0, h, w, growth, mid, ctot = ctx.dims
         rows, dev = n * h * w, slab.device
         am_g = getattr(gout, "nw_amax", None)
@@ -1293,7 +1311,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
             for k in range(len(ctx.meta) - 1, -1, -1):
                 c, kh, d1, d2, w1s, w2s = ctx.meta[k]
                 t1, u, t2, stats, am, g1, b1, g2, b2 = saved[9 * k:9 * k + 9]
-                m1, i1, m2, i2 = stats[:c], stats[c:2 * c], stats[2 * c:2 * c + mid], stats[2 * c + mid:]
+                m1, i1, m2, i2 = bstat[:c], bstat[ctot:ctot + c], stats[:mid], stats[mid:2 * mid]
                 gv = G.data_ptr() + 4 * c                              # this layer's window of the gradient slab
                 # conv2 (3x3): weight gradient, data gradient
                 dw2 = torch.empty((growth, kh, kh, mid), **f32)
@@ -1305,7 +1323,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                 dt2 = torch.empty((rows, mid), **f32)
                 am_d = torch.empty(3 * AMAX_SLOTS, **f32)              # amax records of dt2 | du | dt1
                 _lib.check(lib.nw_conv2d_nhwc_f16x2(gv, _ptr(am_g), _ptr(d2.split), _ptr(d2.scale), None, None, 0, _ptr(dt2),
-                                                    _ptr(am_d), n, h, w, growth, mid, kh, kh, 1, kh - 1 - kh // 2, ctot, 0, st),
+                                                    _ptr(am_d), n, h, w, growth, mid, kh, kh, 1, kh - 1 - kh // 2, ctot, 0, None, st),
                            "nw_conv2d_nhwc_f16x2")
                 # norm2 + relu
                 du = torch.empty((rows, mid), **f32)
@@ -1326,7 +1344,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                 dt1 = torch.empty((rows, c), **f32)
                 _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,
                                                     None, 0, _ptr(dt1), am_d.data_ptr() + 8 * AMAX_SLOTS, n, h, w, mid, c, 1, 1, 1, 0,
-                                                    0, 0, st), "nw_conv2d_nhwc_f16x2")
+                                                    0, 0, None, st), "nw_conv2d_nhwc_f16x2")
                 # norm1 + relu over the slab's prefix: dx is ADDED into the gradient slab's prefix, in place
                 dg1, db1 = torch.empty(c, **f32), torch.empty(c, **f32)
                 am_g = torch.empty(AMAX_SLOTS, **f32)
@@ -1356,7 +1374,8 @@ def dense_block_nhwc_supported(x, layers, bank):
         w1, w2 = layer.conv1.weight, layer.conv2.weight
         kh = w2.shape[2]
         if (layer.drop_rate > 0 or tuple(w1.shape) != (mid, c, 1, 1) or tuple(w2.shape) != (growth, mid, kh, kh) or kh % 2 == 0
-                or not (layer.norm1.affine and layer.norm2.affine) or layer.norm1.weight is None or layer.norm2.weight is None):
+                or not (layer.norm1.affine and layer.norm2.affine) or layer.norm1.weight is None or layer.norm2.weight is None
+                or layer.norm1.eps != layers[0].norm1.eps or layer.norm2.eps != layers[0].norm1.eps):
             return False
         for wt in (w1, w2):
             ops_ = bank.operands(wt) if bank.has(wt) else None
