@@ -676,7 +676,7 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
     if (!nw_conv2d_nhwc_supported(n, H, W, Cin, Cout, KH, KW, stride, pad)) return NW_ERR_UNSUPPORTED;
     if (ldx == 0) ldx = Cin;
     if (ldy == 0) ldy = Cout;
-    if (ldx < Cin || ldy < Cout || ldx % 4 || ldy % 4) return NW_ERR_INVALID_ARG;
+    if (ldx < Cin || ldy < Cout || (ldx != Cin && ldx % 4) || ldy % 4) return NW_ERR_INVALID_ARG;
     if (ldx != Cin && Cin % 32) return NW_ERR_UNSUPPORTED;   // (the few-channel stems read whole dense rows)
     {
         const int64_t Ho_ = (H + 2 * pad - KH) / stride + 1, Wo_ = (W + 2 * pad - KW) / stride + 1;

@@ -296,6 +296,138 @@ def test_densenet_training_step_nhwc_against_fp64(dev):
     assert c1 > 0.9999 and (1 - c1) < 3 * (1 - c0) + 1e-7, (c0, c1)
 
 
+@pytest.mark.parametrize("n,cin,h,w,cout,k,xw,yw", [(3, 64, 14, 14, 128, 1, 96, 0), (2, 128, 28, 28, 32, 3, 0, 96),
+                                                    (2, 32, 14, 14, 128, 3, 160, 0), (5, 128, 7, 7, 32, 3, 0, 864),
+                                                    (2, 128, 56, 56, 128, 1, 0, 0)])
+def test_conv_channel_windows_and_moments(dev, n, cin, h, w, cout, k, xw, yw):
+    """nw_conv2d_nhwc_f16x2 with ldx / ldy: the input is a channel window of a wider channels-last tensor, the output is
+    written into a window of another (the rest of which must stay untouched); `moments`: the groups it leaves merge
+    (nw_bn_nhwc_moments_from_partials_f32) to the batch mean / variance of y, against fp64."""
+    from nwhead_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin + cout + xw)
+    pad = k // 2
+    wide_x = _cl((torch.randn(n, cin + xw, h, w, generator=g) * 1.3 + 0.2).to(dev))
+    x = wide_x[:, 32:32 + cin] if xw else wide_x
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
+    sw = ops.SplitConvWeight(wt)
+    wide_y = _cl(torch.full((n, cout + yw, h, w), 7.5, device=dev))
+    c_off = 64 if yw else 0
+    am = ops.absmax(wide_x)
+    G = lib.nw_conv2d_nhwc_moments_groups(n, h, w, cin, cout, k, k, 1, pad)
+    assert G > 0
+    part = torch.empty((3 * G + 48) * cout, dtype=torch.float32, device=dev)
+    am_out = torch.empty(ops.AMAX_SLOTS, dtype=torch.float32, device=dev)
+    st = ops._stream(wide_x)
+    _lib.check(lib.nw_conv2d_nhwc_f16x2(x.data_ptr(), am.data_ptr(), sw.split.data_ptr(), sw.scale.data_ptr(), None, None, 0,
+                                        wide_y.data_ptr() + 4 * c_off, am_out.data_ptr(), n, h, w, cin, cout, k, k, 1, pad,
+                                        cin + xw, cout + yw, part.data_ptr(), st), "conv")
+    stats = torch.empty(3 * cout, dtype=torch.float32, device=dev)
+    _lib.check(lib.nw_bn_nhwc_moments_from_partials_f32(part.data_ptr(), G, cout, 1e-5, stats.data_ptr(),
+                                                        stats.data_ptr() + 4 * cout, stats.data_ptr() + 8 * cout, st), "merge")
+    ref = F.conv2d(x.double(), wt.double(), None, 1, pad)
+    y = wide_y[:, c_off:c_off + cout]
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < TOL
+    if yw:
+        assert float(wide_y[:, :c_off].min()) == 7.5 and float(wide_y[:, c_off + cout:].max()) == 7.5
+    assert abs(float(am_out.max()) - float(y.abs().max())) <= 1e-6 * float(y.abs().max())
+    mean, var = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False)
+    sd = var.sqrt()
+    assert ((stats[:cout].double() - mean).abs() / sd).max().item() < 1e-5
+    assert ((stats[2 * cout:].double() - var).abs() / var).max().item() < 1e-5
+    assert ((stats[cout:2 * cout].double() - (var + 1e-5).rsqrt()).abs() * sd).max().item() < 1e-5
+
+
+def test_bn_forward_in_phases_equals_the_fused_call(dev):
+    """nw_bn_nhwc_moments_f32 + nw_bn_relu_nhwc_apply_f32 against nw_bn_relu_nhwc_train_fwd_f32 on a channel prefix: same
+    outputs, saved statistics, running statistics and step counter."""
+    from nwhead_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w, wide = 3, 96, 9, 11, 160
+    full = _cl((torch.randn(n, wide, h, w, generator=g) * 1.7 - 0.4).to(dev))
+    x = full[:, :c]
+    rows = n * h * w
+    bn_a, bn_b = torch.nn.BatchNorm2d(c).to(dev).train(), torch.nn.BatchNorm2d(c).to(dev).train()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn_a.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    bn_b.load_state_dict(bn_a.state_dict())
+    y_a = ops.bn_relu_train_nhwc(x, bn_a, True)
+    st = ops._stream(full)
+    stats = torch.empty(3 * c, dtype=torch.float32, device=dev)
+    wsb = lib.nw_bn_nhwc_workspace_bytes(rows, c)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.nw_bn_nhwc_moments_f32(x.data_ptr(), wide, rows, c, float(bn_b.eps), stats.data_ptr(), stats.data_ptr() + 4 * c,
+                                          stats.data_ptr() + 8 * c, ws.data_ptr(), wsb, st), "moments")
+    y_b = torch.empty(rows, c, dtype=torch.float32, device=dev)
+    am = torch.empty(ops.AMAX_SLOTS, dtype=torch.float32, device=dev)
+    _lib.check(lib.nw_bn_relu_nhwc_apply_f32(x.data_ptr(), wide, stats.data_ptr(), stats.data_ptr() + 4 * c, stats.data_ptr() + 8 * c,
+                                             bn_b.weight.data_ptr(), bn_b.bias.data_ptr(), bn_b.running_mean.data_ptr(),
+                                             bn_b.running_var.data_ptr(), bn_b.num_batches_tracked.data_ptr(), float(bn_b.momentum),
+                                             y_b.data_ptr(), am.data_ptr(), rows, c, 1, st), "apply")
+    assert torch.equal(y_b.view(n, h, w, c).permute(0, 3, 1, 2), y_a.detach())
+    assert float(am.max()) == float(y_a.detach().abs().max())
+    assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-6, atol=1e-7)
+    assert int(bn_b.num_batches_tracked) == 1
+
+
+def test_dense_block_slab_node_against_layer_by_layer(dev):
+    """ops.dense_block_nhwc_train (one autograd node over one slab, statistics shared between the layers, moments from the
+    convolutions' epilogues, the gradient slab accumulated in place) against the layer-by-layer channels-last path and
+    fp64 torch: outputs, input gradient, every parameter gradient, running statistics."""
+    import copy
+    import nwhead_amd.model.backbones as BB
+    from nwhead_amd import ops
+    torch.manual_seed(3)
+    block = BB._DenseBlock(4, 64, 4, 32, 0.0).to(dev).train()
+    with torch.no_grad():
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+    x0 = _cl(torch.randn(5, 64, 14, 14, device=dev) * 1.5 + 0.3)
+    t = _cl(torch.randn(5, 64 + 4 * 32, 14, 14, device=dev))
+    convs = [(m.weight, True) for m in block.modules() if isinstance(m, torch.nn.Conv2d)]
+
+    def run(slab):
+        blk = copy.deepcopy(block)
+        bank = ops.ConvWeightBank([(m.weight, True) for m in blk.modules() if isinstance(m, torch.nn.Conv2d)])
+        bank.refresh()
+        old = BB.DENSE_SLAB
+        BB.DENSE_SLAB = slab
+        try:
+            x = x0.clone().requires_grad_(True)
+            if slab:
+                assert ops.dense_block_nhwc_supported(x, list(blk.children()), bank)
+            y = blk.forward_nhwc_train(x, bank)
+            (y * t).sum().backward()
+        finally:
+            BB.DENSE_SLAB = old
+        return y.detach().double(), x.grad.double(), {k: p.grad.double() for k, p in blk.named_parameters()}, \
+            {k: b.double() for k, b in blk.named_buffers() if "running" in k}
+
+    ya, gxa, gpa, rsa = run(False)
+    yb, gxb, gpb, rsb = run(True)
+    b64 = copy.deepcopy(block).double()
+    x64 = x0.double().contiguous().requires_grad_(True)
+    feats = [x64]
+    for layer in b64.children():
+        inp = torch.cat(feats, 1)
+        feats.append(layer.conv2(F.relu(layer.norm2(layer.conv1(F.relu(layer.norm1(inp)))))))
+    y64 = torch.cat(feats, 1)
+    (y64 * t.double()).sum().backward()
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    assert rel(yb, y64) < 2e-5 and rel(yb, y64) < 3 * rel(ya, y64) + 1e-6
+    assert rel(gxb, x64.grad) < 2e-4 and rel(gxb, x64.grad) < 3 * rel(gxa, x64.grad) + 1e-5
+    g64 = {k: p.grad for k, p in b64.named_parameters()}
+    for k in g64:
+        assert rel(gpb[k], g64[k]) < 3e-4 and rel(gpb[k], g64[k]) < 3 * rel(gpa[k], g64[k]) + 2e-5, k
+    for k in rsa:
+        assert rel(rsb[k], rsa[k]) < 1e-5, k
+
+
 @pytest.mark.parametrize("folding", [False, True])
 def test_k2_resnet18_plus_head_end_to_end(dev, folding):
     """BASELINE configs[1] end to end: load_model('resnet18') @224, 64 queries, a bank of N = 1000
