@@ -138,8 +138,18 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         // Every iteration issues the same instructions (past the end of the run: the weights' first rows into a ring
         // slot nobody reads any more, the page of zeros for the activations), so that the order of issue is periodic
         // and both hipcc's own waits for the register loads and the counted waits below are exact.
+        int w_skip = 0, a_skip = 0;                                // dummy issues in front of the first real ones (pipeline fill)
         auto issue_w = [&]() {
             const char* base = p.ws;
+            if (w_skip > 0) {                                      // fill: same instructions, stage 0's slot (its own DMA lands later)
+                --w_skip;
+                char* dst0 = wring;
+#pragma unroll
+                for (int m = 0; m < NIW; ++m)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[m]),
+                                                     (__attribute__((address_space(3))) void*)(dst0 + 1024 * (lw + 4 * m)), 16, 0, 0);
+                return;
+            }
             if (d_s < S) {
                 const int t_id = tbeg + d_tile * nslot;
                 const int nt = t_id % p.ntiles;
@@ -208,7 +218,8 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         float4 ld[NSET][NPASS][2];
         unsigned ldvalid[NSET];
         auto issue_a = [&](float4 (&L)[NPASS][2], unsigned& valid) {   // loads of the cursor's chunk
-            const bool live = a_g < QT;
+            const bool live = a_skip == 0 && a_g < QT;
+            if (a_skip > 0) --a_skip;
             if (live && a_q == 0) setup_tile();
             valid = 0xffffffffu;
             if (PATCH) {
@@ -306,32 +317,39 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         //      complete at barrier s - 1) and the loads of the chunk NSET further on are issued into the registers it
         //      leaves;  B  the weights of stage s + AH are issued;  C  stage s + 2's weights have landed: all but the
         //      DMAs (and loads) issued after them, a constant in the periodic order.
-#pragma unroll
-        for (int u = 0; u < NSET; ++u) issue_a(ld[u], ldvalid[u]);     // chunks 0 .. NSET - 1
-#pragma unroll
-        for (int k = 0; k < AH - 2; ++k) issue_w();                    // stages 0 .. AH - 3
-        up = __builtin_ldexpf(1.f, split_exponent(amax_read(p.amax_in, lane)));
+        // Pipeline fill: the loop starts V iterations early and runs the SAME periodic order of issues -- dummies (the
+        // weights' first rows into stage 0's slot, the page of zeros) where the stage or chunk an iteration would issue
+        // does not exist yet -- with the same counted waits, which cannot bind before the ring is full; nothing is
+        // written and no barrier is passed before iteration -2.  (The first version issued a prefix by hand and waited
+        // vmcnt(0) through the first AH iterations: one full memory latency per stage, ~10 us at the start of every launch
+        // -- most of the run time of the 14x14 and 7x7 layers.)
+        constexpr int V = PATCH ? 9 : (NSET > AH - 2 ? NSET : AH - 2);
+        constexpr int S_BEGIN = -2 - UNR * ((V + UNR - 1) / UNR);
+        w_skip = -AH - S_BEGIN > 0 ? -AH - S_BEGIN : 0;
+        a_skip = (!PATCH && (-2 - NSET) - S_BEGIN > 0) ? (-2 - NSET) - S_BEGIN : 0;
+        const float4 am4 = reinterpret_cast<const float4*>(p.amax_in)[lane];   // the tensor's amax record (used at iteration -2)
         int w_g = 0;                                                   // next chunk to write
-        for (int s = -2; s < S; s += UNR) {
+        for (int s = S_BEGIN; s < S; s += UNR) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int si = s + u;
                 if (si >= S) break;
+                if (si == -2) up = __builtin_ldexpf(1.f, split_exponent(wave_max(fmaxf(fmaxf(am4.x, am4.y), fmaxf(am4.z, am4.w)))));
                 if (!PATCH || u == 0) {
                     constexpr int SET_MASK = NSET - 1;
                     float4 (&L)[NPASS][2] = ld[PATCH ? 0 : (u & SET_MASK)];
-                    unsigned& V = ldvalid[PATCH ? 0 : (u & SET_MASK)];
+                    unsigned& V_ = ldvalid[PATCH ? 0 : (u & SET_MASK)];
                     // the chunk's loads have landed: all but what was issued after them
-                    if (si < (PATCH ? 9 : NSET) + AH) wait_vmcnt<0>();
-                    else if constexpr (PATCH) wait_vmcnt<9 * NIW>();
+                    if constexpr (PATCH) wait_vmcnt<9 * NIW>();
                     else wait_vmcnt<NSET * NIW + (NSET - 1) * NACT>();
-                    if (w_g < QT) write_a(L, V, w_g);
-                    ++w_g;
-                    issue_a(L, V);
+                    if (si >= -2) {
+                        if (w_g < QT) write_a(L, V_, w_g);
+                        ++w_g;
+                    }
+                    issue_a(L, V_);
                 }
                 issue_w();
-                if (si < AH) wait_vmcnt<0>();
-                else if constexpr (PATCH) {
+                if constexpr (PATCH) {
                     if (u <= AH - 3) wait_vmcnt<(AH - 2) * NIW + NACT>();   // this period's chunk loads are younger too
                     else wait_vmcnt<(AH - 2) * NIW>();
                 } else {
