@@ -418,7 +418,7 @@ extern "C" int nw_bn_nhwc_moments_from_partials_f32(float* partials, int64_t gro
     hipStream_t st = static_cast<hipStream_t>(stream);
     // many groups (the 56x56 and 28x28 layers leave thousands): sliced over up to 16 workgroups per 16 channels, the slices'
     // moments (behind the groups in the same buffer: 48 c more floats) merged by the chunk-merge kernel
-    int S = (int)(groups / 256);
+    int S = (int)(groups / 768);
     if (S > 16) S = 16;
     if (S < 1) S = 1;
     float* slices = partials + (size_t)3 * groups * c;

@@ -94,6 +94,11 @@ extern "C" int nw_scores_f32(const float* q, const float* s, float* scores, int6
 
 // Scratch: the fused path keeps per-tile softmax statistics and label-run sums (fused.hip); the
 // two-kernel path (per-query supports, N <= 25, weights requested) one (B,N) score matrix.
+static size_t agg_slice_bytes(int64_t B, int64_t N, int64_t C) {
+    const int S = nw::aggregate_slices(B, N);
+    return S > 1 ? align256((size_t)S * (size_t)B * (size_t)(2 + (C > 0 ? C : 0)) * sizeof(float)) : 0;
+}
+
 extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C) {
     (void)d; (void)C;
     if (B <= 0 || N <= 0) return 0;
@@ -102,7 +107,8 @@ extern "C" size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_
     // + room for the split-fp16 form of the queries (rows, scales, norms) behind the fused area
     const size_t qsplit = align256((size_t)B * (size_t)d * sizeof(float)) + 2 * align256((size_t)B * sizeof(float));
     // + B floats for the log-sum-exp when weights / influences are derived from the fused kernel's scores
-    return (plain > fused ? plain : fused) + qsplit + align256((size_t)B * sizeof(float));
+    // + the slice partials of the two-kernel path's aggregation (few queries, long rows: nw::aggregate_slices)
+    return (plain > fused ? plain : fused) + qsplit + align256((size_t)B * sizeof(float)) + agg_slice_bytes(B, N, C);
 }
 
 extern "C" int nw_row_norm2_f32(const float* x, float* n2, int64_t rows, int64_t d, void* stream) {
@@ -136,7 +142,7 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, con
         if (weights_out) {
             float* lse = lse_out;
             if (!lse) lse = reinterpret_cast<float*>(static_cast<char*>(workspace) + nw_fwd_workspace_bytes(B, N, d, C) -
-                                                     align256((size_t)B * sizeof(float)));
+                                                     align256((size_t)B * sizeof(float)) - agg_slice_bytes(B, N, C));
             const int rc = nw_fwd_f32(q, s, sy, s_norm2, s_split, s_scale, out, sc_buf, lse, nullptr, workspace,
                                       workspace_bytes, B, N, d, C, kind, logit_scale_dev, 0, 0, opts, stream);
             if (rc != NW_OK) return rc;
@@ -158,8 +164,15 @@ extern "C" int nw_fwd_f32(const float* q, const float* s, const int64_t* sy, con
     }
     int rc = nw::launch_scores(q, s, scores, B, N, d, kind, logit_scale_dev, sup_batched, st);
     if (rc != NW_OK) return rc;
+    float* slice_ws = nullptr;
+    size_t slice_floats = 0;
+    const size_t sb = agg_slice_bytes(B, N, C);
+    if (sb && workspace && workspace_bytes >= nw_fwd_workspace_bytes(B, N, d, C)) {   // (the last area of the workspace)
+        slice_ws = reinterpret_cast<float*>(static_cast<char*>(workspace) + nw_fwd_workspace_bytes(B, N, d, C) - sb);
+        slice_floats = sb / sizeof(float);
+    }
     return nw::launch_aggregate(scores, sy, labels_batched, out, lse_out, weights_out, nullptr,
-                                nullptr, nullptr, B, N, C, st);
+                                nullptr, nullptr, B, N, C, st, slice_ws, slice_floats);
 }
 
 extern "C" int nw_fwd_partial_f32(const float* q, const float* s, const int64_t* sy,
@@ -231,7 +244,8 @@ extern "C" int nw_fwd_influence_f32(const float* q, const float* s, const int64_
     if (!qy || !infl_out || !out) return NW_ERR_INVALID_ARG;
     const size_t need = nw_fwd_workspace_bytes(B, N, d, C);   // its last B floats: the log-sum-exp slot
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
-    float* lse = lse_out ? lse_out : reinterpret_cast<float*>(static_cast<char*>(workspace) + need - align256((size_t)B * sizeof(float)));
+    float* lse = lse_out ? lse_out : reinterpret_cast<float*>(static_cast<char*>(workspace) + need - align256((size_t)B * sizeof(float)) -
+                                                              agg_slice_bytes(B, N, C));
     // scores into infl_out (fused tile kernel when eligible, else the score kernel of the two-kernel path)
     const int rc = nw_fwd_f32(q, s, sy, s_norm2, s_split, s_scale, out, infl_out, lse, nullptr, workspace,
                               workspace_bytes, B, N, d, C, kind, logit_scale_dev, 0, 0, opts, stream);

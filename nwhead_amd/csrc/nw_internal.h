@@ -21,9 +21,12 @@ int launch_scores(const float* q, const float* s, float* scores, int64_t B, int6
 // softmax over supports + per-class aggregation of one (B,N) score matrix
 //   final:   out (B,C), optional lse (B,), optional weights (B,N)
 //   partial: m (B,), den (B,), num (B,C)
+// slice_ws (nullable, slice_ws_floats): scratch of aggregate_slices(B, N) * B * (2 + C) floats -- with it, few queries over
+// long rows are aggregated by several workgroups per query (partials + merge)
+int aggregate_slices(int64_t B, int64_t N);
 int launch_aggregate(const float* scores, const int64_t* sy, int labels_batched, float* out,
                      float* lse, float* weights, float* m, float* den, float* num, int64_t B,
-                     int64_t N, int64_t C, hipStream_t st);
+                     int64_t N, int64_t C, hipStream_t st, float* slice_ws = nullptr, size_t slice_ws_floats = 0);
 
 int launch_merge(const float* m, const float* den, const float* num, float* out, int64_t G,
                  int64_t B, int64_t C, int64_t sm, int64_t sd, int64_t sn, const int64_t* class_lo,

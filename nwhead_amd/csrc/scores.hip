@@ -136,6 +136,75 @@ __global__ __launch_bounds__(256) void nw_scores_direct_rows_kernel(
         direct_pair<KIND>(q + b * d, s + (sup_batched ? (b * N + j) * d : j * d), scores, logit_scale, b * N + j, d, lane);
 }
 
+// Per-query supports (sx of shape (B, N, d): every query has its own support rows, nw/nw.py:266-289 with a 3-D sx) at large
+// N: nothing is shared between queries, so the work is one pass over B N d floats -- HBM-bound.  Sixteen lanes per support
+// row (float4 loads: a wave reads four rows' 256-byte segments per instruction, sixteen rows = sixteen loads in flight per
+// lane group of a wave), the direct-difference form of direct_pair (same arithmetic per pair, different summation order),
+// the 16-lane sums by four DPP rotations.  One wave per pair (nw_scores_direct_kernel) ran 16 x 5000 x 512 at 0.37 TB/s.
+template <int KIND>
+__global__ __launch_bounds__(256) void nw_scores_batched_stream_kernel(
+    const float* __restrict__ q, const float* __restrict__ s, float* __restrict__ scores,
+    const float* __restrict__ logit_scale, int64_t N, int64_t d) {
+    constexpr int ROWS_WAVE = 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int64_t b = blockIdx.y;
+    const float* __restrict__ x = q + b * d;
+    const float* __restrict__ sb = s + b * N * d;
+    float* __restrict__ orow = scores + b * N;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * ROWS_WAVE;
+    auto rowsum = [](float v) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+        return v;
+    };
+    const float scale = (KIND == NW_SCORE_CLIP) ? expf(*logit_scale) : 1.f;
+#pragma unroll 1
+    for (int it = 0; it < ROWS_WAVE / 4; ++it) {
+        const int64_t j = row0 + 4 * it + g;
+        if (row0 + 4 * it >= N) break;                       // wave-uniform
+        const float* __restrict__ y = sb + (j < N ? j : N - 1) * d;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        if (KIND == NW_SCORE_EUCLIDEAN) {
+            float e0 = 0.f, e1 = 0.f;
+#pragma unroll 8
+            for (int64_t k = 4 * i; k < d; k += 64) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + k), yv = *reinterpret_cast<const float4*>(y + k);
+                const float t0 = xv.x - yv.x, t1 = xv.y - yv.y, t2 = xv.z - yv.z, t3 = xv.w - yv.w;
+                e0 = __builtin_fmaf(t0, t0, e0); e1 = __builtin_fmaf(t1, t1, e1);
+                e0 = __builtin_fmaf(t2, t2, e0); e1 = __builtin_fmaf(t3, t3, e1);
+            }
+            const float out = -sqrtf(rowsum(e0 + e1));
+            if (i == 0 && j < N) orow[j] = out;
+            continue;
+        }
+#pragma unroll 8
+        for (int64_t k = 4 * i; k < d; k += 64) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + k), yv = *reinterpret_cast<const float4*>(y + k);
+            a0 += xv.x * yv.x + xv.y * yv.y + xv.z * yv.z + xv.w * yv.w;
+            a1 += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+            a2 += yv.x * yv.x + yv.y * yv.y + yv.z * yv.z + yv.w * yv.w;
+        }
+        a0 = rowsum(a0); a1 = rowsum(a1); a2 = rowsum(a2);
+        float out;
+        if (KIND == NW_SCORE_HYPERSPHERE) {   // direct form on the normalised rows (the row is re-read from the caches)
+            const float inq = 1.f / fmaxf(sqrtf(a1), NW_NORM_EPS), ins = 1.f / fmaxf(sqrtf(a2), NW_NORM_EPS);
+            float acc = 0.f;
+            for (int64_t k = 4 * i; k < d; k += 64) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + k), yv = *reinterpret_cast<const float4*>(y + k);
+                const float t0 = xv.x * inq - yv.x * ins, t1 = xv.y * inq - yv.y * ins, t2 = xv.z * inq - yv.z * ins,
+                            t3 = xv.w * inq - yv.w * ins;
+                acc += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+            }
+            out = -sqrtf(rowsum(acc));
+        } else {
+            out = score_from_dot<KIND>(a0, a1, a2, scale);
+        }
+        if (i == 0 && j < N) orow[j] = out;
+    }
+}
+
 template <int RS, int KIND>
 int launch_mfma_rs(const float* q, const float* s, float* scores, const float* ls, int B, int N,
                    int d, hipStream_t st) {
@@ -167,6 +236,14 @@ int launch_kind(const float* q, const float* s, float* scores, int64_t B, int64_
         }
     }
     const int64_t pairs = B * N;
+    if (sup_batched && N > 25 && d % 4 == 0 && aligned && B <= 65535) {   // per-query supports at large N: one streaming pass
+        const int64_t gx = (N + 63) / 64;
+        if (gx > 0x7fffffffLL) return NW_ERR_INVALID_ARG;
+        hipLaunchKernelGGL((nw_scores_batched_stream_kernel<KIND>), dim3((unsigned)gx, (unsigned)B), dim3(256), 0, st, q, s, scores,
+                           ls, N, d);
+        NW_CHECK_LAUNCH();
+        return NW_OK;
+    }
     if (B >= 4096 && N > 1) {   // enough queries to fill the chip with a wave each
         const int64_t grid = (B + 3) / 4;
         if (grid > 0x7fffffffLL) return NW_ERR_INVALID_ARG;

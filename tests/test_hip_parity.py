@@ -107,6 +107,28 @@ def test_g3_backward(dev, ops, tag, kind):
         np.testing.assert_allclose(ls.grad.cpu().numpy(), g[f"{tag}_{kind}_gls"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("kind", ["euclidean", "cosine", "hypersphere_euclidean", "dotproduct", "clip"])
+@pytest.mark.parametrize("B,N,d,C", [(16, 5000, 512, 100), (3, 9001, 132, 7), (40, 300, 64, 1000)])
+def test_per_query_supports_at_large_n(dev, ops, kind, B, N, d, C):
+    """sx of shape (B, N, d) with labels (B, N) beyond the small-N regime: the streaming score kernel (16 lanes per support
+    row) and the aggregation sliced over several workgroups per query, against fp64 (16 x 5000 x 512)."""
+    from oracle import nw_oracle as O
+    g = torch.Generator().manual_seed(B + N)
+    q = torch.randn(B, d, generator=g)
+    s = torch.randn(B, N, d, generator=g) * 0.7 + 0.1
+    sy = torch.randint(0, C, (B, N), generator=g)
+    ls = torch.tensor(2.3) if kind == "clip" else None
+    out = ops.nw_head(q.to(dev), s.to(dev), sy.to(dev), C, kind, None if ls is None else ls.to(dev))
+    out2 = ops.nw_head(q.to(dev), s.to(dev), sy.to(dev), C, kind, None if ls is None else ls.to(dev))
+    assert torch.equal(out, out2)
+    nb = min(B, 3)
+    ref = torch.stack([O.nw_head_f64(q[b:b + 1], s[b], sy[b], C, kind, 2.3)[0] for b in range(nb)])
+    np.testing.assert_allclose(out[:nb].cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=3e-5)
+    sc = ops.nw_scores(q.to(dev), s.to(dev), kind, None if ls is None else ls.to(dev))
+    ref_sc = torch.stack([O.scores_f64(q[b:b + 1], s[b], kind, 2.3)[0] for b in range(nb)])
+    assert (sc[:nb].cpu().double() - ref_sc).abs().max().item() < 2e-5 * max(1.0, ref_sc.abs().max().item())
+
+
 @pytest.mark.parametrize("tag", ["n20", "n64"])
 def test_g3_backward_batched_support(dev, ops, tag):
     g = load_golden("g3_backward.npz")
