@@ -595,8 +595,9 @@ def main():
                               "number: matrix-pipe utilisation counting issued products); alg_frac_fp16_peak = "
                               "achieved / 2500 (algorithmic flops against the guide's peak, no factor 3); "
                               "achieved_vs_fp32_mfma_peak = achieved / 157.3 (the guide's fp32 MFMA peak, > 1 because "
-                              "the work is not on the fp32 pipe).  On random operands the chip holds ~1.5-1.75 GHz "
-                              "on this loop, not the 2.4 GHz the spec peak assumes (DESIGN.md, power-limited pace)"
+                              "the work is not on the fp32 pipe).  clock_GHz / mfma_busy_frac (from the committed PMC passes of this "
+                              "command) say at what clock and matrix-pipe occupancy it was reached: the kernel runs at "
+                              "~2.1-2.2 GHz with the pipe busy about half of the time (DESIGN.md 4.3)"
                               if fast else "fp32 dense MFMA peak (guide)"),
                 "frac_fp16_pipe": (3 * ach / PEAK_F16_MFMA_TFLOPS) if fast else None,
                 "alg_frac_fp16_peak": ach / PEAK_F16_MFMA_TFLOPS,

@@ -290,6 +290,12 @@ int nw_bias_act_nhwc_f32(const float *x, const float *bias, const float *residua
  *              small planes); may be NULL when that is 0
  *   bias       optional (cout,) (the BatchNorm that FOLLOWS the convolution, folded); post_relu: max(., 0)
  *   out        (n, cout, hw), batch stride out_batch_stride floats */
+size_t nw_conv1x1_workspace_bytes(int64_t n, int64_t cin, int64_t cout, int64_t hw);
+int nw_conv1x1_f32(const float *x, int64_t x_batch_stride, const float *pre_scale, const float *pre_shift,
+                   int pre_relu, const float *w_t, const float *bias, int post_relu, float *out,
+                   int64_t out_batch_stride, void *workspace, size_t workspace_bytes,
+                   int64_t n, int64_t cin, int64_t cout, int64_t hw, void *stream);
+
 /* 3x3 convolution, stride 1, padding 1, as an implicit GEMM on the fp32 matrix cores with bias / residual / ReLU fused
  * in; the output may be a channel window of a wider tensor (out_batch_stride), e.g. a DenseNet block's slab.  Replaces
  * the 3x3 convolutions of the folded inference backbones (model/densenet.py:41-45 conv2, model/densenet3.py:10-22,
@@ -311,12 +317,6 @@ int nw_conv3x3_f32(const float *x, int64_t x_batch_stride, const float *w_t, con
  * backbones keep MIOpen below 192. */
 int64_t nw_conv3x3_workgroups(int64_t n, int64_t cin, int64_t cout, int64_t H, int64_t W);
 
-
-size_t nw_conv1x1_workspace_bytes(int64_t n, int64_t cin, int64_t cout, int64_t hw);
-int nw_conv1x1_f32(const float *x, int64_t x_batch_stride, const float *pre_scale, const float *pre_shift,
-                   int pre_relu, const float *w_t, const float *bias, int post_relu, float *out,
-                   int64_t out_batch_stride, void *workspace, size_t workspace_bytes,
-                   int64_t n, int64_t cin, int64_t cout, int64_t hw, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution of the backbones on the fp16 matrix cores at fp32-grade accuracy (csrc/conv_nhwc.hip): an implicit
