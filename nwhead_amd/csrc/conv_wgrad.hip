@@ -392,9 +392,11 @@ bool wgrad_plan(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int6
     // ~one workgroup per CU, and no more chunks than the output tile is worth: the partial tiles cross memory twice
     // (written, read by the reduction), 2 ks Cout T Cin floats against (Cout + Cin) 32 nstage read by the product
     int64_t ks = (256 + tiles - 1) / tiles;
-    // at least 8 (3x3: 16, a chunk starts with four steps of rows around its first stage) stages per chunk: small planes are
+    // at least 4 (3x3: 8, a chunk starts with four steps of rows around its first stage) stages per chunk: small planes are
     // latency-bound and want many workgroups
-    const int64_t maxks = (pl->nstage + (pl->taps9 ? 15 : 7)) / (pl->taps9 ? 16 : 8);
+    int64_t minst = pl->taps9 ? 8 : 4;   // (16 / 8 until round 3: K4 19.05 -> 18.83 ms with twice the workgroups on the small planes)
+    if (knob(KNOB_WGRAD_MIN_STAGES) > 0) minst = pl->taps9 ? knob(KNOB_WGRAD_MIN_STAGES) : (knob(KNOB_WGRAD_MIN_STAGES) + 1) / 2;
+    const int64_t maxks = (pl->nstage + minst - 1) / minst;
     if (ks > maxks) ks = maxks;
     if (ks < 1) ks = 1;
     pl->spc = (int)((pl->nstage + ks - 1) / ks);

@@ -165,6 +165,48 @@ int main() {
     EXPECT(nw_conv3x3_f32(F, 25088, F, nullptr, nullptr, 0, 0, F, 1568, nullptr, 0, 64, 512, 32, 7, 7, nullptr), NW_ERR_WORKSPACE);
     EXPECT(nw_conv3x3_workgroups(64, 512, 32, 7, 7) >= 192, 1);
     EXPECT(nw_conv3x3_workgroups(1, 8, 32, 7, 7), 1);
+    // channels-last convolutions on the fp16 matrix cores, their weight gradient, BatchNorm in phases
+    EXPECT(nw_conv2d_nhwc_supported(2, 14, 14, 128, 32, 3, 3, 1, 1), 1);
+    EXPECT(nw_conv2d_nhwc_supported(2, 14, 14, 128, 24, 3, 3, 1, 1), 0);                       // Cout % 32
+    EXPECT(nw_conv2d_nhwc_supported(2, 14, 14, 48, 32, 3, 3, 1, 1), 0);                        // Cin % 32 with KW * Cin > 32
+    EXPECT(nw_conv2d_nhwc_f16x2(F, F, F, F, nullptr, nullptr, 0, F, nullptr, -1, 14, 14, 128, 32, 3, 3, 1, 1, 0, 0, nullptr, nullptr),
+           NW_ERR_INVALID_ARG);
+    EXPECT(nw_conv2d_nhwc_f16x2(F, F, F, F, nullptr, nullptr, 0, F, nullptr, 0, 14, 14, 128, 32, 3, 3, 1, 1, 0, 0, nullptr, nullptr), NW_OK);
+    EXPECT(nw_conv2d_nhwc_f16x2(F, F, F, F, nullptr, nullptr, 0, F, nullptr, 2, 14, 14, 128, 24, 3, 3, 1, 1, 0, 0, nullptr, nullptr),
+           NW_ERR_UNSUPPORTED);
+    EXPECT(nw_conv2d_nhwc_f16x2(nullptr, F, F, F, nullptr, nullptr, 0, F, nullptr, 2, 14, 14, 128, 32, 3, 3, 1, 1, 0, 0, nullptr, nullptr),
+           NW_ERR_INVALID_ARG);
+    EXPECT(nw_conv2d_nhwc_f16x2(F, F, F, F, nullptr, nullptr, 0, F, nullptr, 2, 14, 14, 128, 32, 3, 3, 1, 1, 64, 0, nullptr, nullptr),
+           NW_ERR_INVALID_ARG);                                                                 // ldx < Cin
+    EXPECT(nw_conv2d_nhwc_f16x2(F, F, F, F, nullptr, nullptr, 0, F, nullptr, 2, 14, 14, 128, 32, 3, 3, 1, 1, 0, 34, nullptr, nullptr),
+           NW_ERR_INVALID_ARG);                                                                 // ldy % 4
+    EXPECT(nw_conv2d_nhwc_f16x2(F, F, F, F, nullptr, nullptr, 0, F, nullptr, 2, 14, 14, 4, 32, 7, 7, 2, 3, 8, 0, nullptr, nullptr),
+           NW_ERR_UNSUPPORTED);                                                                 // a window of a few-channel input
+    EXPECT(nw_conv2d_nhwc_f16x2(F, F, F, F, nullptr, nullptr, 0, F, nullptr, 2, 14, 14, 4, 32, 7, 7, 2, 3, 0, 0, F, nullptr),
+           NW_ERR_UNSUPPORTED);                                                                 // moments of a few-channel input
+    EXPECT(nw_conv2d_nhwc_moments_groups(42, 14, 14, 512, 128, 1, 1, 1, 0) > 0, 1);
+    EXPECT(nw_conv2d_nhwc_moments_groups(42, 14, 14, 512, 100, 1, 1, 1, 0), 0);
+    EXPECT(nw_conv2d_nhwc_moments_groups(0, 14, 14, 512, 128, 1, 1, 1, 0), 0);
+    EXPECT(nw_conv2d_nhwc_wgrad_supported(2, 14, 14, 128, 32, 3, 3, 1, 1), 1);
+    EXPECT(nw_conv2d_nhwc_wgrad_supported(2, 14, 14, 128, 32, 3, 3, 2, 1), 0);                 // strided
+    EXPECT(nw_conv2d_nhwc_wgrad_supported(2, 64, 64, 128, 32, 3, 3, 1, 1), 0);                 // W > 62 with taps
+    EXPECT(nw_conv2d_nhwc_wgrad_workspace_bytes(2, 14, 14, 128, 32, 3, 3, 1, 1) > 0, 1);
+    EXPECT(nw_conv2d_nhwc_wgrad_f16x2(F, F, F, F, F, ws, 8, 2, 14, 14, 128, 32, 3, 3, 1, 1, 0, 0, nullptr), NW_ERR_WORKSPACE);
+    EXPECT(nw_conv2d_nhwc_wgrad_f16x2(F, F, F, F, F, ws, sizeof ws, 2, 14, 14, 128, 32, 3, 3, 1, 1, 64, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_conv2d_nhwc_wgrad_f16x2(F, F, F, F, F, ws, sizeof ws, 2, 14, 14, 128, 32, 3, 3, 2, 1, 0, 0, nullptr), NW_ERR_UNSUPPORTED);
+    EXPECT(nw_bn_nhwc_workspace_bytes(0, 64), 0);
+    EXPECT(nw_bn_nhwc_workspace_bytes(8232, 128) > 0, 1);
+    EXPECT(nw_bn_nhwc_moments_f32(F, 64, 100, 64, 1e-5f, F, F, F, ws, 8, nullptr), NW_ERR_WORKSPACE);
+    EXPECT(nw_bn_nhwc_moments_f32(F, 32, 100, 64, 1e-5f, F, F, F, ws, sizeof ws, nullptr), NW_ERR_INVALID_ARG);   // ldx < c
+    EXPECT(nw_bn_nhwc_moments_f32(F, 64, 100, 64, 1e-5f, nullptr, F, F, ws, sizeof ws, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bn_nhwc_moments_from_partials_f32(F, 0, 64, 1e-5f, F, F, F, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bn_nhwc_moments_from_partials_f32(nullptr, 4, 64, 1e-5f, F, F, F, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_bn_relu_nhwc_apply_f32(F, 64, F, F, F, F, F, nullptr, nullptr, nullptr, 0.1f, F, nullptr, 100, 66, 1, nullptr),
+           NW_ERR_INVALID_ARG);                                                                 // c % 4
+    EXPECT(nw_bn_relu_nhwc_apply_f32(F, 2048, F, F, F, F, F, nullptr, nullptr, nullptr, 0.1f, F, nullptr, 100, 2048, 1, nullptr),
+           NW_ERR_UNSUPPORTED);                                                                 // c > 1024
+    EXPECT(nw_bn_relu_nhwc_train_bwd_f32(F, 64, F, F, F, F, F, F, F, F, nullptr, 0, 32, nullptr, ws, sizeof ws, 100, 64, 1, nullptr),
+           NW_ERR_INVALID_ARG);                                                                 // lddx < c
     std::printf(failures ? "abi_args: %d FAILED\n" : "abi_args: all argument checks refused as documented\n", failures);
     return failures ? 1 : 0;
 }

@@ -10,7 +10,7 @@ bash $R/tools/prof_bench.sh bench_r03 > $OUT/prof_bench_r03.log 2>&1 || true
 echo bench done
 bash $R/tools/prof.sh T_r03 256 10000 512 200 fwd > $OUT/prof_T_r03.log 2>&1 || true
 echo T done
-bash $R/tools/prof_fold.sh K2_r03 resnet18 > $OUT/prof_K2_r03.log 2>&1 || true
+bash $R/tools/prof_k2.sh K2_r03 > $OUT/prof_K2_r03.log 2>&1 || true
 echo K2 done
 bash $R/tools/prof_train.sh K4_r03 1 > $OUT/prof_K4_r03.log 2>&1 || true
 echo K4 done
