@@ -356,8 +356,8 @@ int nw_conv2d_nhwc_f16x2(const float *x, const float *amax_in, const float *w_sp
 /* moments (nullable, Cin % 32 == 0): the convolution also leaves BatchNorm's batch statistics of y, so the BatchNorm that
  * follows (model/densenet.py:33-60: conv1 -> norm2; the next layers' norm1 over conv2's channels) needs no pass over y:
  * per group g of output pixels and channel co, moments[(k G + g) Cout + co] = k 0: pixels in the group, 1: their mean,
- * 2: the sum of squared deviations from it; G = nw_conv2d_nhwc_moments_groups(same shape arguments) groups; the buffer
- * holds (3 G + 48) Cout floats (the tail is scratch of nw_bn_nhwc_moments_from_partials_f32, which merges the groups). */
+ * 2: the sum of squared deviations from it; G = nw_conv2d_nhwc_moments_groups(same shape arguments) groups (3 G Cout
+ * floats), merged by nw_bn_nhwc_moments_from_partials_f32. */
 int64_t nw_conv2d_nhwc_moments_groups(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                                       int64_t stride, int64_t pad);
 

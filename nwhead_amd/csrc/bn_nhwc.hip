@@ -114,55 +114,60 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_finalize_kernel(const float* 
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
 }
 
-// The moments of MANY groups (what a convolution's epilogue leaves: thousands of 16..64-pixel groups) to mean, 1/sqrt(var +
-// eps) and the biased variance, in parallel over the groups: 16 channels x 64 group lanes per workgroup, two passes over the
-// partials -- the weighted mean, then sum(M2_g + n_g (mean_g - mean)^2) -- each summed per lane over groups j, j + 64, ... and
-// over the 64 lanes in a fixed order (deterministic; Chan's pairwise merge of nw_bn_nhwc_finalize_kernel is a serial chain
-// per lane: fine for <= 256 chunks, 130 dependent steps at 2058 groups).
+// The moments of MANY groups (what a convolution's epilogue leaves: up to thousands of 16..64-pixel groups) to mean,
+// 1/sqrt(var + eps) and the biased variance, in parallel over the groups: FOUR channels (one float4) x 256 group lanes per
+// workgroup, two passes over the partials -- the weighted mean, then sum(M2_g + n_g (mean_g - mean)^2) -- each summed per
+// lane over groups j, j + 256, ... and over the lanes in a fixed order (deterministic).  (Chan's pairwise merge of
+// nw_bn_nhwc_finalize_kernel is a serial chain per lane: fine for <= 256 chunks, 130 dependent steps at 2058 groups; a
+// first version with 16 channels x 64 lanes per workgroup ran on C / 16 = 2..8 CUs: 26 us on the 56 x 56 layers.)
 __global__ __launch_bounds__(1024) void nw_bn_nhwc_merge_groups_kernel(const float* __restrict__ part, int G, int C, float eps,
                                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                                        float* __restrict__ save_var, float* __restrict__ slices) {
-    // blockIdx.y = slice of the groups (gridDim.y > 1: the slice's own count / mean / M2 go to `slices` in the layout
-    // nw_bn_nhwc_finalize_kernel merges, [k][slice][C]; one slice: the final values)
-    __shared__ float sh[2][64][17];
-    const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    const bool live = c < C;
-    const int S = gridDim.y, per = (G + S - 1) / S, g0 = blockIdx.y * per, g1 = min(G, g0 + per);
-    float sn = 0.f, sm = 0.f;
-    if (live)
-        for (int g = g0 + j; g < g1; g += 64) {
-            const float n = part[(int64_t)g * C + c];
-            sn += n;
-            sm = __builtin_fmaf(n, part[((int64_t)G + g) * C + c], sm);
+                                                                        float* __restrict__ save_var) {
+    __shared__ float4 sh[1024];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * 4;                               // this workgroup's four channels (C % 4 == 0)
+    auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    auto block_sum4 = [&](float4 v) {                            // fixed-order tree over the 1024 threads; result in all
+        __syncthreads();
+        sh[t] = v;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {
+            if (t < w) sh[t] = add4(sh[t], sh[t + w]);
+            __syncthreads();
         }
-    sh[0][j][cl] = sn; sh[1][j][cl] = sm;
-    __syncthreads();
-    float tn = 0.f, tm = 0.f;
-    for (int k = 0; k < 64; ++k) { tn += sh[0][k][cl]; tm += sh[1][k][cl]; }
-    const float mean = tn > 0.f ? tm / tn : 0.f;
-    __syncthreads();
-    float q = 0.f;
-    if (live)
-        for (int g = g0 + j; g < g1; g += 64) {
-            const float n = part[(int64_t)g * C + c], d = part[((int64_t)G + g) * C + c] - mean;
-            q += __builtin_fmaf(n * d, d, part[((int64_t)2 * G + g) * C + c]);
-        }
-    sh[0][j][cl] = q;
-    __syncthreads();
-    if (j != 0 || !live) return;
-    float tq = 0.f;
-    for (int k = 0; k < 64; ++k) tq += sh[0][k][cl];
-    if (S > 1) {
-        slices[((int64_t)0 * S + blockIdx.y) * C + c] = tn;
-        slices[((int64_t)1 * S + blockIdx.y) * C + c] = mean;
-        slices[((int64_t)2 * S + blockIdx.y) * C + c] = fmaxf(tq, 0.f);
-        return;
+        return sh[0];
+    };
+    float4 sn = make_float4(0.f, 0.f, 0.f, 0.f), sm = sn;
+    for (int g = t; g < G; g += 1024) {
+        const float4 n = *reinterpret_cast<const float4*>(part + (int64_t)g * C + c0);
+        const float4 m = *reinterpret_cast<const float4*>(part + ((int64_t)G + g) * C + c0);
+        sn = add4(sn, n);
+        sm.x = __builtin_fmaf(n.x, m.x, sm.x); sm.y = __builtin_fmaf(n.y, m.y, sm.y);
+        sm.z = __builtin_fmaf(n.z, m.z, sm.z); sm.w = __builtin_fmaf(n.w, m.w, sm.w);
     }
-    const float var = tn > 0.f ? fmaxf(tq / tn, 0.f) : 0.f;
-    save_mean[c] = mean;
-    save_invstd[c] = 1.f / sqrtf(var + eps);
-    save_var[c] = var;
+    const float4 tn = block_sum4(sn);
+    const float4 tm = block_sum4(sm);
+    const float4 mean = make_float4(tn.x > 0.f ? tm.x / tn.x : 0.f, tn.y > 0.f ? tm.y / tn.y : 0.f, tn.z > 0.f ? tm.z / tn.z : 0.f,
+                                    tn.w > 0.f ? tm.w / tn.w : 0.f);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = t; g < G; g += 1024) {
+        const float4 n = *reinterpret_cast<const float4*>(part + (int64_t)g * C + c0);
+        const float4 m = *reinterpret_cast<const float4*>(part + ((int64_t)G + g) * C + c0);
+        const float4 m2 = *reinterpret_cast<const float4*>(part + ((int64_t)2 * G + g) * C + c0);
+        const float dx = m.x - mean.x, dy = m.y - mean.y, dz = m.z - mean.z, dw = m.w - mean.w;
+        q.x += __builtin_fmaf(n.x * dx, dx, m2.x); q.y += __builtin_fmaf(n.y * dy, dy, m2.y);
+        q.z += __builtin_fmaf(n.z * dz, dz, m2.z); q.w += __builtin_fmaf(n.w * dw, dw, m2.w);
+    }
+    const float4 tq = block_sum4(q);
+    if (t != 0) return;
+    const float mn[4] = {mean.x, mean.y, mean.z, mean.w}, nn[4] = {tn.x, tn.y, tn.z, tn.w}, qq[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float var = nn[k] > 0.f ? fmaxf(qq[k] / nn[k], 0.f) : 0.f;
+        save_mean[c0 + k] = mn[k];
+        save_invstd[c0 + k] = 1.f / sqrtf(var + eps);
+        save_var[c0 + k] = var;
+    }
 }
 
 // y[r][c] = act((x[r][c] - mean[c]) a[c] + beta[c]), a = gamma invstd; amax record of y
@@ -416,17 +421,9 @@ extern "C" int nw_bn_nhwc_moments_from_partials_f32(float* partials, int64_t gro
     if (groups <= 0 || groups >= (1LL << 30) || c <= 0) return NW_ERR_INVALID_ARG;
     if (!partials || !mean || !invstd || !var) return NW_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // many groups (the 56x56 and 28x28 layers leave thousands): sliced over up to 16 workgroups per 16 channels, the slices'
-    // moments (behind the groups in the same buffer: 48 c more floats) merged by the chunk-merge kernel
-    int S = (int)(groups / 768);
-    if (S > 16) S = 16;
-    if (S < 1) S = 1;
-    float* slices = partials + (size_t)3 * groups * c;
-    hipLaunchKernelGGL(nw_bn_nhwc_merge_groups_kernel, dim3((unsigned)((c + 15) / 16), (unsigned)S), dim3(1024), 0, st, partials,
-                       (int)groups, (int)c, eps, mean, invstd, var, slices);
-    if (S > 1)
-        hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, slices, S, (int)c,
-                           (float*)nullptr, (float*)nullptr, mean, invstd, (int64_t*)nullptr, 0.f, eps, var);
+    if (c % 4 || (reinterpret_cast<uintptr_t>(partials) & 15)) return NW_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(nw_bn_nhwc_merge_groups_kernel, dim3((unsigned)(c / 4)), dim3(1024), 0, st, partials, (int)groups, (int)c, eps,
+                       mean, invstd, var);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

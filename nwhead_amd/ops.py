@@ -1264,7 +1264,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                 m2, i2, v2 = stats[:mid], stats[mid:2 * mid], stats[2 * mid:]
                 G1 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, c, mid, 1, 1, 1, 0)
                 G2 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, mid, growth, kh, kh, 1, kh // 2)
-                part = _workspace(4 * max((3 * G1 + 48) * mid, (3 * G2 + 48) * growth), dev)
+                part = _workspace(4 * 3 * max(G1 * mid, G2 * growth), dev)
                 rm, rv, mom, nbt = _bn_tracking(layer.norm1)
                 _lib.check(lib.nw_bn_relu_nhwc_apply_f32(_ptr(slab), ctot, _ptr(bm), _ptr(bi), _ptr(bv), _ptr(g1), _ptr(b1), _ptr(rm),
                                                          _ptr(rv), _ptr(nbt), mom, _ptr(t1), _ptr(am), rows, c, 1, st),
