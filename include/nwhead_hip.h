@@ -360,6 +360,21 @@ int nw_conv2d_nhwc_f16x2(const float *x, const float *amax_in, const float *w_sp
  * floats), merged by nw_bn_nhwc_moments_from_partials_f32. */
 int64_t nw_conv2d_nhwc_moments_groups(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                                       int64_t stride, int64_t pad);
+/* The data gradient of a convolution whose input was relu(batch_norm(x)) (model/densenet.py:33-60: norm - relu - conv):
+ * y = dL/d relu(bn(x)) is computed as nw_conv2d_nhwc_f16x2 does (no bias / residual / ReLU), and the epilogue also leaves
+ * BatchNorm's backward statistics: per pixel group and channel, partials[(k G + group) Cout + co] = k 0: sum g, 1: sum g xhat,
+ * with g = y where the forward's bn(x) = (x - mean) gamma invstd + beta was positive, xhat = (x - mean) invstd; G =
+ * nw_conv2d_nhwc_moments_groups(same shape arguments).  x: (pixels, >= Cout) fp32 with row stride ldx, the tensor the
+ * BatchNorm read (channel c of x is channel c of y).  nw_bn_relu_nhwc_train_bwd_from_partials_f32 takes it from there. */
+typedef struct nw_conv_bnstat {
+    const float *x; int64_t ldx;
+    const float *mean, *invstd, *gamma, *beta;   /* (Cout,) each */
+    float *partials;                             /* 2 G Cout floats */
+} nw_conv_bnstat;
+int nw_conv2d_nhwc_bnstat_f16x2(const float *x, const float *amax_in, const float *w_split, const float *w_scale, float *y,
+                                float *amax_out, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH,
+                                int64_t KW, int64_t stride, int64_t pad, int64_t ldx, int64_t ldy,
+                                const nw_conv_bnstat *bnstat, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ ReLU) in front of / behind the backbones' convolutions, forward and
@@ -448,6 +463,14 @@ int nw_bn_relu_nhwc_apply_f32(const float *x, int64_t ldx, const float *mean, co
                               const float *gamma, const float *beta, float *running_mean, float *running_var,
                               int64_t *num_batches_tracked, float momentum, float *y, float *amax_out, int64_t rows,
                               int64_t c, int relu, void *stream);
+/* The backward from the statistics a data-gradient convolution left (nw_conv2d_nhwc_bnstat_f16x2): the groups are summed
+ * (-> dgamma, dbeta), then dx as in nw_bn_relu_nhwc_train_bwd_f32 (relu != 0).  workspace: 2 c floats. */
+int nw_bn_relu_nhwc_train_bwd_from_partials_f32(const float *x, int64_t ldx, const float *dy, const float *gamma,
+                                                const float *beta, const float *save_mean, const float *save_invstd,
+                                                const float *partials, int64_t groups, float *dx, float *dgamma,
+                                                float *dbeta, const float *acc, int64_t ldacc, int64_t lddx,
+                                                float *amax_out, void *workspace, size_t workspace_bytes, int64_t rows,
+                                                int64_t c, void *stream);
 int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, const float *gamma, const float *beta,
                                   const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
                                   float *dbeta, const float *acc, int64_t ldacc, int64_t lddx, float *amax_out,

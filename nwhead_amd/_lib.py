@@ -58,6 +58,9 @@ SIGNATURES = {
     "nw_conv2d_nhwc_supported": (_int, [_i64] * 9),
     "nw_conv2d_nhwc_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _int, _p, _p] + [_i64] * 11 + [_p, _p]),
     "nw_conv2d_nhwc_moments_groups": (_i64, [_i64] * 9),
+    "nw_conv2d_nhwc_bnstat_f16x2": (_int, [_p, _p, _p, _p, _p, _p] + [_i64] * 11 + [_p, _p]),
+    "nw_bn_relu_nhwc_train_bwd_from_partials_f32": (_int, [_p, _i64] + [_p] * 6 + [_i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _sz, _i64,
+                                                           _i64, _p]),
     "nw_bn_nhwc_moments_f32": (_int, [_p, _i64, _i64, _i64, C.c_float, _p, _p, _p, _p, _sz, _p]),
     "nw_bn_nhwc_moments_from_partials_f32": (_int, [_p, _i64, _i64, C.c_float, _p, _p, _p, _p]),
     "nw_bn_relu_nhwc_apply_f32": (_int, [_p, _i64] + [_p] * 8 + [C.c_float, _p, _p, _i64, _i64, _int, _p]),
@@ -104,6 +107,12 @@ def load():
     _lib = lib
     sync_knobs()
     return lib
+
+
+class ConvBnStat(C.Structure):
+    """nw_conv_bnstat (include/nwhead_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("partials", C.c_void_p)]
 
 
 class FwdOpts(C.Structure):

@@ -285,6 +285,39 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_finalize_kernel(const flo
     k[C + c] = s2 * inv_m;
 }
 
+// The backward sums of MANY groups (what a data-gradient convolution's epilogue leaves): dgamma, dbeta and the two means,
+// four channels x 1024 group lanes per workgroup, summed in a fixed order.
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_sum_groups_kernel(const float* __restrict__ part, int G, int C, float inv_m,
+                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                          float* __restrict__ k) {
+    __shared__ float4 sh[1024];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * 4;
+    auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    auto block_sum4 = [&](float4 v) {
+        __syncthreads();
+        sh[t] = v;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {
+            if (t < w) sh[t] = add4(sh[t], sh[t + w]);
+            __syncthreads();
+        }
+        return sh[0];
+    };
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (int g = t; g < G; g += 1024) {
+        s1 = add4(s1, *reinterpret_cast<const float4*>(part + (int64_t)g * C + c0));
+        s2 = add4(s2, *reinterpret_cast<const float4*>(part + ((int64_t)G + g) * C + c0));
+    }
+    const float4 t1 = block_sum4(s1);
+    const float4 t2 = block_sum4(s2);
+    if (t != 0) return;
+    *reinterpret_cast<float4*>(dbeta + c0) = t1;
+    *reinterpret_cast<float4*>(dgamma + c0) = t2;
+    *reinterpret_cast<float4*>(k + c0) = make_float4(t1.x * inv_m, t1.y * inv_m, t1.z * inv_m, t1.w * inv_m);
+    *reinterpret_cast<float4*>(k + C + c0) = make_float4(t2.x * inv_m, t2.y * inv_m, t2.z * inv_m, t2.w * inv_m);
+}
+
 // dx[r][c] = a (g - k1 - xhat k2) [+ acc[r][c]]; amax record of dx
 template <bool RELU>
 __global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
@@ -485,6 +518,35 @@ extern "C" int nw_bn_relu_nhwc_train_bwd_f32(const float* x, int64_t ldx, const 
     } while (0)
     if (relu) NW_BNB(true); else NW_BNB(false);
 #undef NW_BNB
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_bn_relu_nhwc_train_bwd_from_partials_f32(const float* x, int64_t ldx, const float* dy, const float* gamma,
+                                                           const float* beta, const float* save_mean, const float* save_invstd,
+                                                           const float* partials, int64_t groups, float* dx, float* dgamma,
+                                                           float* dbeta, const float* acc, int64_t ldacc, int64_t lddx,
+                                                           float* amax_out, void* workspace, size_t workspace_bytes, int64_t rows,
+                                                           int64_t c, void* stream) {
+    using namespace nw;
+    if (lddx == 0) lddx = c;
+    if (rows <= 0 || c <= 0 || c % 4 || ldx < c || ldx % 4 || (acc && (ldacc < c || ldacc % 4)) || lddx < c || lddx % 4 ||
+        groups <= 0 || groups >= (1LL << 30))
+        return NW_ERR_INVALID_ARG;
+    if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !partials || !dx || !dgamma || !dbeta) return NW_ERR_INVALID_ARG;
+    if (bad_align(x, dy, dx, acc) || bad_align(gamma, beta, save_mean, save_invstd) || bad_align(amax_out, workspace, partials) ||
+        bad_align(dgamma, dbeta))
+        return NW_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < (size_t)2 * c * sizeof(float)) return NW_ERR_WORKSPACE;
+    if (c > 1024) return NW_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* k = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(nw_bn_nhwc_bwd_sum_groups_kernel, dim3((unsigned)(c / 4)), dim3(1024), 0, st, partials, (int)groups, (int)c,
+                       1.f / (float)rows, dgamma, dbeta, k);
+    const int ag = apply_grid(rows, c);
+    const size_t lds = (size_t)6 * c * sizeof(float);
+    hipLaunchKernelGGL((nw_bn_nhwc_bwd_apply_kernel<true>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, dy, gamma, beta, save_mean,
+                       save_invstd, k, acc, ldacc, dx, lddx, amax_out, rows, (int)c);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

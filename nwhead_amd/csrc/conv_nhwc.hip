@@ -46,6 +46,11 @@ struct ConvP {
     float* moments;          // nullable: per (tile row, wave row) group and output channel the count, mean and M2 of y
                              //   (part[(k G + group) Cout + co], G = mtiles WN): BatchNorm's statistics of y without a pass over it
     const float4* zeros;     // 32 bytes of zeros (what a loader reads for a pixel that does not exist)
+    // nullable (bnb_part): y is the gradient of relu(batch_norm(bnb_x)) -- the epilogue also leaves, per pixel group and
+    // channel, sum g and sum g xhat with g = y [bn(x) > 0]: BatchNorm's backward statistics without a pass over (x, y)
+    const float* bnb_x; const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta;
+    float* bnb_part;
+    int bnb_ldx;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
     int ldx, ldy;            // floats between consecutive pixels of x / y (>= Cin / Cout: a channel window of a wider tensor)
     int IP, IMG;             // virtual raster of PATCH mode: row stride W + pad, image stride (H + pad) IP
@@ -540,6 +545,55 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 }
             }
         }
+        if (p.bnb_part) {
+            // y = dL/d relu(bn(x)): sum g and sum g xhat over this wave's pixel rows, g = y where the forward's own
+            // bn(x) = (x - mean) (gamma invstd) + beta was positive (the same expression nw_bn_nhwc_bwd_stats_kernel uses)
+            auto rowsum = [](float x) {
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4e, 0xf, 0xf, false));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xb1, 0xf, 0xf, false));
+                return x;
+            };
+            const int G = p.mtiles * WN, grp = mt * WN + wave / WM;
+            // every x value first (rows past the end clamped: their g is zeroed below), so that the loads fly together
+            float4 x4[NA][NB];
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int m = min(m0 + wpx + 16 * b + i, p.M - 1);
+                    x4[a][b] = *reinterpret_cast<const float4*>(p.bnb_x + (size_t)m * p.bnb_ldx + (co0 + wco + 16 * a + 4 * g));
+                }
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int co = co0 + wco + 16 * a + 4 * g;
+                const float4 m4 = *reinterpret_cast<const float4*>(p.bnb_mean + co), i4 = *reinterpret_cast<const float4*>(p.bnb_invstd + co),
+                             g4 = *reinterpret_cast<const float4*>(p.bnb_gamma + co), b4 = *reinterpret_cast<const float4*>(p.bnb_beta + co);
+                const float mean[4] = {m4.x, m4.y, m4.z, m4.w}, inv[4] = {i4.x, i4.y, i4.z, i4.w};
+                const float sa[4] = {g4.x * i4.x, g4.y * i4.y, g4.z * i4.z, g4.w * i4.w}, sb[4] = {b4.x, b4.y, b4.z, b4.w};
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const bool ok = m0 + wpx + 16 * b + i < p.M;
+                    const float xv[4] = {x4[a][b].x, x4[a][b].y, x4[a][b].z, x4[a][b].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xm = xv[e] - mean[e];
+                        const float pre = __builtin_fmaf(xm, sa[e], sb[e]);
+                        const float gd = (ok && pre > 0.f) ? acc[a][b][e] : 0.f;
+                        s1[e] += gd;
+                        s2[e] = __builtin_fmaf(gd, xm * inv[e], s2[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[e] = rowsum(s1[e]); s2[e] = rowsum(s2[e]); }
+                if (i == 0) {
+                    *reinterpret_cast<float4*>(p.bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                    *reinterpret_cast<float4*>(p.bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                }
+            }
+        }
     }
     // this workgroup's maximum -> its slot of the output's amax record (no atomics, nothing to clear beforehand)
     amax = wave_max(amax);
@@ -687,7 +741,7 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
                            const float* bias, const float* residual, int relu, float* y, float* amax_out,
                            int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                            int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, float* moments, int64_t* moments_groups,
-                           bool dry, void* stream) {
+                           bool dry, void* stream, const nw_conv_bnstat* bnstat = nullptr) {
     if (n < 0 || H < 0 || W < 0) return NW_ERR_INVALID_ARG;
     if (moments_groups) *moments_groups = 0;
     if (n == 0) return NW_OK;
@@ -710,6 +764,18 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
     nw::ConvP p;
     p.x = x; p.amax_in = amax_in; p.ws = reinterpret_cast<const char*>(w_split); p.wscale = w_scale; p.bias = bias;
     p.res = residual; p.y = y; p.amax_out = amax_out; p.moments = moments;
+    p.bnb_x = p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_part = nullptr; p.bnb_ldx = 0;
+    if (bnstat) {
+        if (Cin % 32) return NW_ERR_UNSUPPORTED;
+        if (!bnstat->x || !bnstat->mean || !bnstat->invstd || !bnstat->gamma || !bnstat->beta || !bnstat->partials ||
+            bnstat->ldx < Cout || bnstat->ldx % 4 || n * ((H + 2 * pad - KH) / stride + 1) * ((W + 2 * pad - KW) / stride + 1) * bnstat->ldx >= (1LL << 31))
+            return NW_ERR_INVALID_ARG;
+        if ((reinterpret_cast<uintptr_t>(bnstat->x) | reinterpret_cast<uintptr_t>(bnstat->mean) | reinterpret_cast<uintptr_t>(bnstat->invstd) |
+             reinterpret_cast<uintptr_t>(bnstat->gamma) | reinterpret_cast<uintptr_t>(bnstat->beta) | reinterpret_cast<uintptr_t>(bnstat->partials)) & 15)
+            return NW_ERR_INVALID_ARG;
+        p.bnb_x = bnstat->x; p.bnb_mean = bnstat->mean; p.bnb_invstd = bnstat->invstd; p.bnb_gamma = bnstat->gamma;
+        p.bnb_beta = bnstat->beta; p.bnb_part = bnstat->partials; p.bnb_ldx = (int)bnstat->ldx;
+    }
     p.zeros = dry ? nullptr : nw::zero_page();
     if (!dry && !p.zeros) return NW_ERR_LAUNCH;
     p.N = (int)n; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout; p.KH = (int)KH; p.KW = (int)KW;
@@ -764,6 +830,16 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
     int64_t groups = 0;
     return conv2d_nhwc_impl(x, amax_in, w_split, w_scale, bias, residual, relu, y, amax_out, n, H, W, Cin, Cout, KH, KW, stride,
                             pad, ldx, ldy, moments, moments ? &groups : nullptr, false, stream);
+}
+
+extern "C" int nw_conv2d_nhwc_bnstat_f16x2(const float* x, const float* amax_in, const float* w_split, const float* w_scale, float* y,
+                                           float* amax_out, int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH,
+                                           int64_t KW, int64_t stride, int64_t pad, int64_t ldx, int64_t ldy,
+                                           const nw_conv_bnstat* bnstat, void* stream) {
+    if (!bnstat) return NW_ERR_INVALID_ARG;
+    int64_t groups = 0;
+    return conv2d_nhwc_impl(x, amax_in, w_split, w_scale, nullptr, nullptr, 0, y, amax_out, n, H, W, Cin, Cout, KH, KW, stride, pad,
+                            ldx, ldy, nullptr, &groups, false, stream, bnstat);
 }
 
 extern "C" int64_t nw_conv2d_nhwc_moments_groups(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH,

@@ -4,6 +4,7 @@ autograd bookkeeping); every arithmetic step runs in libnwhead_hip.so.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -1213,6 +1214,12 @@ def _bn_tracking(bn):
     return bn.running_mean, bn.running_var, float(bn.momentum), bn.num_batches_tracked
 
 
+# BatchNorm's backward sums from the data-gradient convolutions' epilogues (nw_conv2d_nhwc_bnstat_f16x2) instead of a statistics
+# pass: one launch and one read of (x, dy) less per BatchNorm, paid for by the x loads of the epilogue.  Measured on K4, three
+# alternations on one box: 18.93-18.97 ms with, 18.79-18.83 without -- left OFF
+DENSE_BWD_STATS_IN_DGRAD = os.environ.get("NW_DENSE_BWD_STATS", "0") == "1"
+
+
 class _DenseBlockNhwcFn(torch.autograd.Function):
     """A whole dense block (model/densenet.py:62-80: every layer reads the concatenation of the block's input and all
     earlier layers' outputs) as ONE autograd node over ONE slab: the block's output tensor (rows = n h w, C0 + L growth
@@ -1320,37 +1327,77 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                 _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, gv, _ptr(am_g), _ptr(dw2),
                                                           _ptr(ws), wsb, n, h, w, mid, growth, kh, kh, 1, kh // 2, 0, ctot, st),
                            "nw_conv2d_nhwc_wgrad_f16x2")
-                dt2 = torch.empty((rows, mid), **f32)
-                am_d = torch.empty(3 * AMAX_SLOTS, **f32)              # amax records of dt2 | du | dt1
-                _lib.check(lib.nw_conv2d_nhwc_f16x2(gv, _ptr(am_g), _ptr(d2.split), _ptr(d2.scale), None, None, 0, _ptr(dt2),
-                                                    _ptr(am_d), n, h, w, growth, mid, kh, kh, 1, kh - 1 - kh // 2, ctot, 0, None, st),
-                           "nw_conv2d_nhwc_f16x2")
-                # norm2 + relu
-                du = torch.empty((rows, mid), **f32)
-                dg2, db2 = torch.empty(mid, **f32), torch.empty(mid, **f32)
-                bnb = max(lib.nw_bn_nhwc_workspace_bytes(rows, c), lib.nw_bn_nhwc_workspace_bytes(rows, mid))
-                wsn = _workspace(bnb, dev)
-                _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(u), mid, _ptr(dt2), _ptr(g2), _ptr(b2), _ptr(m2), _ptr(i2),
-                                                             _ptr(du), _ptr(dg2), _ptr(db2), None, 0, 0,
-                                                             am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(wsn), bnb, rows, mid, 1, st),
-                           "nw_bn_relu_nhwc_train_bwd_f32")
-                # conv1 (1x1)
-                dw1 = torch.empty((mid, 1, 1, c), **f32)
-                wsb = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, c, mid, 1, 1, 1, 0)
-                ws = _workspace(wsb, dev)
-                _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
-                                                          _ptr(ws), wsb, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, st),
-                           "nw_conv2d_nhwc_wgrad_f16x2")
-                dt1 = torch.empty((rows, c), **f32)
-                _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,
-                                                    None, 0, _ptr(dt1), am_d.data_ptr() + 8 * AMAX_SLOTS, n, h, w, mid, c, 1, 1, 1, 0,
-                                                    0, 0, None, st), "nw_conv2d_nhwc_f16x2")
-                # norm1 + relu over the slab's prefix: dx is ADDED into the gradient slab's prefix, in place
-                dg1, db1 = torch.empty(c, **f32), torch.empty(c, **f32)
-                am_g = torch.empty(AMAX_SLOTS, **f32)
-                _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(slab), ctot, _ptr(dt1), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(i1),
-                                                             _ptr(G), _ptr(dg1), _ptr(db1), _ptr(G), ctot, ctot, _ptr(am_g),
-                                                             _ptr(wsn), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
+                if DENSE_BWD_STATS_IN_DGRAD:
+                    dt2 = torch.empty((rows, mid), **f32)
+                    am_d = torch.empty(3 * AMAX_SLOTS, **f32)              # amax records of dt2 | du | dt1
+                    # the data gradients also leave BatchNorm's backward sums of what they write (sum g, sum g xhat per pixel
+                    # group), so the BatchNorm backward is the sum of the groups + ONE pass (dx), not two
+                    Gd2 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, growth, mid, kh, kh, 1, kh - 1 - kh // 2)
+                    Gd1 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, mid, c, 1, 1, 1, 0)
+                    bpart = torch.empty(2 * max(Gd2 * mid, Gd1 * c), **f32)
+                    bs2 = _lib.ConvBnStat(_ptr(u), mid, _ptr(m2), _ptr(i2), _ptr(g2), _ptr(b2), _ptr(bpart))
+                    _lib.check(lib.nw_conv2d_nhwc_bnstat_f16x2(gv, _ptr(am_g), _ptr(d2.split), _ptr(d2.scale), _ptr(dt2), _ptr(am_d),
+                                                               n, h, w, growth, mid, kh, kh, 1, kh - 1 - kh // 2, ctot, 0,
+                                                               ctypes.byref(bs2), st), "nw_conv2d_nhwc_bnstat_f16x2")
+                    # norm2 + relu
+                    du = torch.empty((rows, mid), **f32)
+                    dg2, db2 = torch.empty(mid, **f32), torch.empty(mid, **f32)
+                    kws = torch.empty(2 * max(c, mid), **f32)
+                    _lib.check(lib.nw_bn_relu_nhwc_train_bwd_from_partials_f32(
+                        _ptr(u), mid, _ptr(dt2), _ptr(g2), _ptr(b2), _ptr(m2), _ptr(i2), _ptr(bpart), Gd2, _ptr(du), _ptr(dg2), _ptr(db2),
+                        None, 0, 0, am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(kws), 4 * kws.numel(), rows, mid, st),
+                        "nw_bn_relu_nhwc_train_bwd_from_partials_f32")
+                    # conv1 (1x1)
+                    dw1 = torch.empty((mid, 1, 1, c), **f32)
+                    wsb = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, c, mid, 1, 1, 1, 0)
+                    ws = _workspace(wsb, dev)
+                    _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
+                                                              _ptr(ws), wsb, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, st),
+                               "nw_conv2d_nhwc_wgrad_f16x2")
+                    dt1 = torch.empty((rows, c), **f32)
+                    bs1 = _lib.ConvBnStat(_ptr(slab), ctot, _ptr(m1), _ptr(i1), _ptr(g1), _ptr(b1), _ptr(bpart))
+                    _lib.check(lib.nw_conv2d_nhwc_bnstat_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale),
+                                                               _ptr(dt1), am_d.data_ptr() + 8 * AMAX_SLOTS, n, h, w, mid, c, 1, 1, 1, 0, 0, 0,
+                                                               ctypes.byref(bs1), st), "nw_conv2d_nhwc_bnstat_f16x2")
+                    # norm1 + relu over the slab's prefix: dx is ADDED into the gradient slab's prefix, in place
+                    dg1, db1 = torch.empty(c, **f32), torch.empty(c, **f32)
+                    am_g = torch.empty(AMAX_SLOTS, **f32)
+                    _lib.check(lib.nw_bn_relu_nhwc_train_bwd_from_partials_f32(
+                        _ptr(slab), ctot, _ptr(dt1), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(i1), _ptr(bpart), Gd1, _ptr(G), _ptr(dg1), _ptr(db1),
+                        _ptr(G), ctot, ctot, _ptr(am_g), _ptr(kws), 4 * kws.numel(), rows, c, st),
+                        "nw_bn_relu_nhwc_train_bwd_from_partials_f32")
+                else:
+                    dt2 = torch.empty((rows, mid), **f32)
+                    am_d = torch.empty(3 * AMAX_SLOTS, **f32)              # amax records of dt2 | du | dt1
+                    _lib.check(lib.nw_conv2d_nhwc_f16x2(gv, _ptr(am_g), _ptr(d2.split), _ptr(d2.scale), None, None, 0, _ptr(dt2),
+                                                        _ptr(am_d), n, h, w, growth, mid, kh, kh, 1, kh - 1 - kh // 2, ctot, 0, None, st),
+                               "nw_conv2d_nhwc_f16x2")
+                    # norm2 + relu
+                    du = torch.empty((rows, mid), **f32)
+                    dg2, db2 = torch.empty(mid, **f32), torch.empty(mid, **f32)
+                    bnb = max(lib.nw_bn_nhwc_workspace_bytes(rows, c), lib.nw_bn_nhwc_workspace_bytes(rows, mid))
+                    wsn = _workspace(bnb, dev)
+                    _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(u), mid, _ptr(dt2), _ptr(g2), _ptr(b2), _ptr(m2), _ptr(i2),
+                                                                 _ptr(du), _ptr(dg2), _ptr(db2), None, 0, 0,
+                                                                 am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(wsn), bnb, rows, mid, 1, st),
+                               "nw_bn_relu_nhwc_train_bwd_f32")
+                    # conv1 (1x1)
+                    dw1 = torch.empty((mid, 1, 1, c), **f32)
+                    wsb = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, c, mid, 1, 1, 1, 0)
+                    ws = _workspace(wsb, dev)
+                    _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
+                                                              _ptr(ws), wsb, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, st),
+                               "nw_conv2d_nhwc_wgrad_f16x2")
+                    dt1 = torch.empty((rows, c), **f32)
+                    _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,
+                                                        None, 0, _ptr(dt1), am_d.data_ptr() + 8 * AMAX_SLOTS, n, h, w, mid, c, 1, 1, 1, 0,
+                                                        0, 0, None, st), "nw_conv2d_nhwc_f16x2")
+                    # norm1 + relu over the slab's prefix: dx is ADDED into the gradient slab's prefix, in place
+                    dg1, db1 = torch.empty(c, **f32), torch.empty(c, **f32)
+                    am_g = torch.empty(AMAX_SLOTS, **f32)
+                    _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(slab), ctot, _ptr(dt1), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(i1),
+                                                                 _ptr(G), _ptr(dg1), _ptr(db1), _ptr(G), ctot, ctot, _ptr(am_g),
+                                                                 _ptr(wsn), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
                 grads[6 * k:6 * k + 6] = [dg1, db1, dw1.permute(0, 3, 1, 2), dg2, db2, dw2.permute(0, 3, 1, 2)]
         dx = None
         if ctx.needs_input_grad[0]:

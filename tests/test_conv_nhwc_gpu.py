@@ -373,7 +373,8 @@ def test_bn_forward_in_phases_equals_the_fused_call(dev):
     assert int(bn_b.num_batches_tracked) == 1
 
 
-def test_dense_block_slab_node_against_layer_by_layer(dev):
+@pytest.mark.parametrize("bwd_stats_in_dgrad", [False, True])
+def test_dense_block_slab_node_against_layer_by_layer(dev, bwd_stats_in_dgrad):
     """ops.dense_block_nhwc_train (one autograd node over one slab, statistics shared between the layers, moments from the
     convolutions' epilogues, the gradient slab accumulated in place) against the layer-by-layer channels-last path and
     fp64 torch: outputs, input gradient, every parameter gradient, running statistics."""
@@ -395,8 +396,9 @@ def test_dense_block_slab_node_against_layer_by_layer(dev):
         blk = copy.deepcopy(block)
         bank = ops.ConvWeightBank([(m.weight, True) for m in blk.modules() if isinstance(m, torch.nn.Conv2d)])
         bank.refresh()
-        old = BB.DENSE_SLAB
+        old, old_f = BB.DENSE_SLAB, ops.DENSE_BWD_STATS_IN_DGRAD
         BB.DENSE_SLAB = slab
+        ops.DENSE_BWD_STATS_IN_DGRAD = bwd_stats_in_dgrad      # (BatchNorm's backward sums from the data gradients' epilogues)
         try:
             x = x0.clone().requires_grad_(True)
             if slab:
@@ -404,7 +406,7 @@ def test_dense_block_slab_node_against_layer_by_layer(dev):
             y = blk.forward_nhwc_train(x, bank)
             (y * t).sum().backward()
         finally:
-            BB.DENSE_SLAB = old
+            BB.DENSE_SLAB, ops.DENSE_BWD_STATS_IN_DGRAD = old, old_f
         return y.detach().double(), x.grad.double(), {k: p.grad.double() for k, p in blk.named_parameters()}, \
             {k: b.double() for k, b in blk.named_buffers() if "running" in k}
 
