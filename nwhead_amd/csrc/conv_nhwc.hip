@@ -807,8 +807,10 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
     // latency-bound: 42 x 196 pixels are 33 tiles of 256 pixels, or 129 of 64)
     const int64_t want = (int64_t)nw::num_cus() * 3 / 4;
     auto tiles = [&](int bm, int bn) { return ((int64_t)p.M + bm - 1) / bm * (Cout / bn); };
+    const int skip = nw::knob(nw::KNOB_CONV_SKIP_CFGS) > 0 ? nw::knob(nw::KNOB_CONV_SKIP_CFGS) : 0;   // timing experiments: pass over the first n fitting shapes
+    int seen = 0;
 #define NW_CONV_TRY(NA_, NB_, WM_, BM_, BN_, LAST_)                                                            \
-    if (Cout % BN_ == 0 && (LAST_ || tiles(BM_, BN_) >= want)) {                                               \
+    if (Cout % BN_ == 0 && (LAST_ || (tiles(BM_, BN_) >= want && seen++ >= skip))) {                           \
         if (k33 && patch_fits(BM_) && !force_gather)                                                            \
             return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_PATCH>(p, st, moments_groups, dry);                \
         return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_GATHER>(p, st, moments_groups, dry);                   \
