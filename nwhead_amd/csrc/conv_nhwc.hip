@@ -91,10 +91,34 @@ __device__ __forceinline__ float amax_read(const float* rec, int lane) {
     const float4 v = reinterpret_cast<const float4*>(rec)[lane];
     return wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
 }
+// 16-byte slot of piece s (0-3: the h halves of channels 8 s .. 8 s + 7, 4-7: the l halves) inside the 128-byte LDS row of
+// activation entry e.  ds_read_b128 serves a wave in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... --
+// i.e. all 16 entries e0 + i once, with piece g for eight of them and g ^ 1 for the other eight; bit 0 of the slot follows the
+// piece (so the two halves of a group never meet) and the upper bits rotate with e / 2 (four same-parity entries of either
+// half: four distinct values) -- conflict-free for EVERY e0.  The XOR swizzle s ^ (e / 2 & 7) of the head's tiles is
+// conflict-free only for e0 % 4 == 0; a 3x3 tap shifts e0 by dy IP + dx: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE went from
+// 2.79 M / 7.35 M to 1.26 M / 5.82 M cycles on the 128 -> 32 3x3 layer at 56 x 56 (the rest: the loaders' stores) -- at the
+// same 67 us: the LDS is not what bounds that kernel ("what bounds the narrow tiles").
+__device__ __forceinline__ int pslot(int e, int s) { return (s & 1) | ((((s >> 1) ^ (e >> 1)) & 3) << 1); }
 // workgroup b of g writes its maximum to slot b and zeros to the slots b + g, b + 2 g, ... it stands in for
 __device__ __forceinline__ void amax_write(float* rec, float m, int b, int g) {
     for (int k = b; k < CV_AMAX_SLOTS; k += g) rec[k] = k == b ? m : 0.f;
 }
+
+#ifdef NW_CONV_DIAG   // diagnostic build only (tools/bench_conv.hip): s_memtime totals of workgroup phases, [wg][16]
+__device__ unsigned long long nw_conv_diag[16 * 1024];
+#define NW_CSTAMP(k)                                                                          \
+    do {                                                                                      \
+        unsigned long long now_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        cd_[k] += now_ - cl_;                                                                 \
+        cl_ = now_;                                                                           \
+    } while (0)
+#else
+#define NW_CSTAMP(k)
+#endif
 
 template <int NA, int NB, int WM, int MODE>
 __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
@@ -140,6 +164,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             woff[m] = (unsigned)((size_t)R * wrow) + (unsigned)(((lane & 7) ^ ((R >> 1) & 7)) << 4);
         }
         int d_tile = 0, d_k = 0, d_s = 0;                          // next stage to issue: tile index, stage in tile, global
+        const char* w_tile = p.ws;
+        size_t w_off = 0;
+        int w_t = 0;
         // Every iteration issues the same instructions (past the end of the run: the weights' first rows into a ring
         // slot nobody reads any more, the page of zeros for the activations), so that the order of issue is periodic
         // and both hipcc's own waits for the register loads and the counted waits below are exact.
@@ -149,25 +176,41 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             if (w_skip > 0) {                                      // fill: same instructions, stage 0's slot (its own DMA lands later)
                 --w_skip;
                 char* dst0 = wring;
+#ifndef NW_CABL_NODMA
 #pragma unroll
                 for (int m = 0; m < NIW; ++m)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[m]),
                                                      (__attribute__((address_space(3))) void*)(dst0 + 1024 * (lw + 4 * m)), 16, 0, 0);
+#endif
                 return;
             }
             if (d_s < S) {
-                const int t_id = tbeg + d_tile * nslot;
-                const int nt = t_id % p.ntiles;
-                int c, t;
-                if (PATCH) { c = d_k / 9; t = d_k - 9 * c; } else { t = d_k / nc; c = d_k - t * nc; }
-                base = p.ws + (size_t)(nt * BN) * wrow + (ROWRUN ? (size_t)t * 128 : ((size_t)t * p.Cin + 32 * c) * 4);
+                if (d_k == 0) {                                    // a new tile: its weight rows (one division per tile, not per stage)
+                    const int t_id = tbeg + d_tile * nslot;
+                    w_tile = p.ws + (size_t)((t_id % p.ntiles) * BN) * wrow;
+                    w_off = 0;
+                    w_t = 0;
+                }
+                base = w_tile + w_off;
             }
             char* dst = wring + (d_s % NWR) * WST;
+#ifndef NW_CABL_NODMA
 #pragma unroll
             for (int m = 0; m < NIW; ++m)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[m]),
                                                  (__attribute__((address_space(3))) void*)(dst + 1024 * (lw + 4 * m)), 16, 0, 0);
+#else
+            (void)dst;
+#endif
             ++d_s;
+            // the stage's byte offset inside a weight row, kept incrementally: (t Cin + 32 c) 4 with (c, t) = (k / 9, k % 9) in
+            // PATCH order, and simply 128 k otherwise (t nc + c = k)
+            if (PATCH) {
+                w_off += (size_t)p.Cin * 4;
+                if (++w_t == 9) { w_t = 0; w_off -= (size_t)9 * p.Cin * 4 - 128; }
+            } else {
+                w_off += 128;
+            }
             if (++d_k == ST) { d_k = 0; ++d_tile; }
         };
         // ---- activations: chunk cursor
@@ -214,6 +257,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         // select into a branch around two loads and then waits for everything in flight at the join)
         const uintptr_t zpage = reinterpret_cast<uintptr_t>(p.zeros);
         auto pick = [&](bool ok, const void* ptr) {
+#ifdef NW_CABL_NOLOAD
+            ok = false;
+#endif
             return reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(ptr) : zpage);
         };
         // (the activation loads are plain loads: hipcc's own waits order them against the conversions that read their
@@ -279,11 +325,13 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         };
         // the tensor's scale: one power of two from the bound its producer left (read behind the first loads)
         float up = 1.f;
-        auto write_a = [&](const float4 (&L)[NPASS][2], unsigned valid, int g) {   // a loaded chunk -> split -> buffer g % NPB
+        auto write_pass = [&](const float4& L0, const float4& L1, unsigned valid, int g, int q) {   // pass q of a loaded chunk -> split -> buffer g % NPB
             char* pb = pbuf + (g % NPB) * PB;
-#pragma unroll
-            for (int q = 0; q < NPASS; ++q) {
-                const float xs[8] = {L[q][0].x, L[q][0].y, L[q][0].z, L[q][0].w, L[q][1].x, L[q][1].y, L[q][1].z, L[q][1].w};
+#ifdef NW_CABL_NOCVT
+            if (L0.x != 12345.678f) return;
+#endif
+            {
+                const float xs[8] = {L0.x, L0.y, L0.z, L0.w, L1.x, L1.y, L1.z, L1.w};
                 float xv[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) xv[k] = (MODE == CV_ROWRUN && !((valid >> (8 * q + k)) & 1)) ? 0.f : xs[k];
@@ -306,16 +354,20 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                         "s_nop 0"
                         : "=&v"(hh[2 * u]), "=&v"(hh[2 * u + 1]), "=&v"(ll[2 * u]), "=&v"(ll[2 * u + 1])
                         : "v"(xv[4 * u]), "v"(xv[4 * u + 1]), "v"(xv[4 * u + 2]), "v"(xv[4 * u + 3]), "v"(up));
-                const int e = le + 64 * q, sw = (e >> 1) & 7;
+                const int e = le + 64 * q;
                 // the LDS stores by hand too: a wave with LDS-DMAs in flight gets an s_waitcnt vmcnt(0) from hipcc in front
                 // of every LDS access it can see (it cannot tell the DMA's target from this buffer)
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 hv = {hh[0], hh[1], hh[2], hh[3]}, lv = {ll[0], ll[1], ll[2], ll[3]};
                 typedef __attribute__((address_space(3))) char lds_char;
-                const unsigned ah_ = (unsigned)(uintptr_t)(lds_char*)(pb + e * 128 + ((lj ^ sw) << 4));
-                const unsigned al_ = (unsigned)(uintptr_t)(lds_char*)(pb + e * 128 + (((4 + lj) ^ sw) << 4));
+                const unsigned ah_ = (unsigned)(uintptr_t)(lds_char*)(pb + e * 128 + (pslot(e, lj) << 4));
+                const unsigned al_ = (unsigned)(uintptr_t)(lds_char*)(pb + e * 128 + (pslot(e, 4 + lj) << 4));
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %2, %3" ::"v"(ah_), "v"(hv), "v"(al_), "v"(lv) : "memory");
             }
+        };
+        auto write_a = [&](const float4 (&L)[NPASS][2], unsigned valid, int g) {   // a loaded chunk -> split -> buffer g % NPB
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) write_pass(L[q][0], L[q][1], valid, g, q);
         };
         // Iteration s (from -2; a barrier closes it from -1 on, the first one releases the consumers):
         //   A  the chunk whose first stage is s + 2 goes to LDS (its buffer was last read for a stage whose reads are
@@ -334,6 +386,10 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         a_skip = (!PATCH && (-2 - NSET) - S_BEGIN > 0) ? (-2 - NSET) - S_BEGIN : 0;
         const float4 am4 = reinterpret_cast<const float4*>(p.amax_in)[lane];   // the tensor's amax record (used at iteration -2)
         int w_g = 0;                                                   // next chunk to write
+#ifdef NW_CONV_DIAG
+        unsigned long long cd_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cl_ = __builtin_amdgcn_s_memtime();
+        const unsigned long long cf_ = cl_;
+#endif
         for (int s = S_BEGIN; s < S; s += UNR) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -345,15 +401,20 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     float4 (&L)[NPASS][2] = ld[PATCH ? 0 : (u & SET_MASK)];
                     unsigned& V_ = ldvalid[PATCH ? 0 : (u & SET_MASK)];
                     // the chunk's loads have landed: all but what was issued after them
+                    NW_CSTAMP(0);                                                  // bookkeeping
                     if constexpr (PATCH) wait_vmcnt<9 * NIW>();
                     else wait_vmcnt<NSET * NIW + (NSET - 1) * NACT>();
+                    NW_CSTAMP(1);                                                  // wait: the chunk's loads
                     if (si >= -2) {
                         if (w_g < QT) write_a(L, V_, w_g);
                         ++w_g;
                     }
+                    NW_CSTAMP(2);                                                  // convert + LDS stores
                     issue_a(L, V_);
+                    NW_CSTAMP(3);                                                  // issue of the next chunk's loads
                 }
                 issue_w();
+                NW_CSTAMP(0);
                 if constexpr (PATCH) {
                     if (u <= AH - 3) wait_vmcnt<(AH - 2) * NIW + NACT>();   // this period's chunk loads are younger too
                     else wait_vmcnt<(AH - 2) * NIW>();
@@ -361,9 +422,17 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     wait_vmcnt<(AH - 2) * (NACT + NIW)>();
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                NW_CSTAMP(4);                                                      // wait: stage s + 2's weights
                 if (si >= -1) __builtin_amdgcn_s_barrier();
+                NW_CSTAMP(5);                                                      // barrier
             }
         }
+#ifdef NW_CONV_DIAG
+        if (tid == 256 && blockIdx.x < 1024) {
+            for (int k = 0; k < 6; ++k) nw_conv_diag[16 * blockIdx.x + k] = cd_[k];
+            nw_conv_diag[16 * blockIdx.x + 6] = cl_ - cf_;
+        }
+#endif
         wait_vmcnt<0>();                                               // (the dummy tail of the issue order)
         __builtin_amdgcn_s_barrier();                                  // the consumers have parked their maxima
         return;
@@ -379,11 +448,24 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         float4 ah[NA], al[NA], bh[NB], bl[NB];
     };
     auto mm = [](const float4& a, const float4& b, f32x4 c) {
+#ifdef NW_CABL_NOMFMA   // ablation builds (tools/bench_conv.hip): what the other role costs alone
+        c[0] += a.x * b.x;
+        return c;
+#else
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+#endif
     };
     float amax = 0.f;
     int sg = 0, qg = 0;                                            // global stage / chunk counters
+#ifdef NW_CONV_DIAG
+    unsigned long long cd_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cl_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long cf_ = cl_;
+#define NW_CBAR() do { NW_CSTAMP(1); tile_barrier(); NW_CSTAMP(2); } while (0)
+#else
+#define NW_CBAR() tile_barrier()
+#endif
     __builtin_amdgcn_s_barrier();                                  // the prologue's stages have landed
+    NW_CSTAMP(0);                                                  // wait for the pipeline fill
     for (int tl = 0; tl < ntile; ++tl) {
         const int t_id = tbeg + tl * nslot;
         const int mt = t_id / p.ntiles, nt = t_id - mt * p.ntiles;
@@ -417,6 +499,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 shift = dy * p.IP + dx;
             }
             const char* pb = pbuf + ((qg + q) % NPB) * PB;
+#ifdef NW_CABL_NOFRAG   // ablation: fragments read once (first stage of the kernel), the rest of the stages reuse the registers
+            if (sg + k > 0) return;
+#endif
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 f.ah[a] = *reinterpret_cast<const float4*>(wb + aoff_h + a * 2048);
@@ -424,9 +509,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int e = eb[b] + shift, sw = (e >> 1) & 7;
-                f.bh[b] = *reinterpret_cast<const float4*>(pb + e * 128 + ((g ^ sw) << 4));
-                f.bl[b] = *reinterpret_cast<const float4*>(pb + e * 128 + (((4 + g) ^ sw) << 4));
+                const int e = eb[b] + shift;
+                f.bh[b] = *reinterpret_cast<const float4*>(pb + e * 128 + (pslot(e, g) << 4));
+                f.bl[b] = *reinterpret_cast<const float4*>(pb + e * 128 + (pslot(e, 4 + g) << 4));
             }
         };
         auto mfma_stage = [&](const Frag& f) {                     // small terms first, the dominant h*h product last
@@ -455,21 +540,22 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         };
         Frag f0, f1;
         load_frags(f0, 0);
+        NW_CSTAMP(3);                                              // tile set-up (+ the first fragments' issue)
         int k = 0;
         for (; k + 2 < ST; k += 2) {
             load_frags(f1, k + 1);
             mfma_stage(f0);
             interleave();
-            tile_barrier();
+            NW_CBAR();
             load_frags(f0, k + 2);
             mfma_stage(f1);
             interleave();
-            tile_barrier();
+            NW_CBAR();
         }
         for (; k < ST; ++k) {
             if (k + 1 < ST) load_frags(f1, k + 1);
             mfma_stage(f0);
-            tile_barrier();
+            NW_CBAR();
             f0 = f1;
         }
         sg += ST;
@@ -500,6 +586,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                         v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                     }
                     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+#ifdef NW_CABL_NOEPI
+                    if (v.x == 12345.678f)
+#endif
                     *reinterpret_cast<float4*>(p.y + o) = v;
                     acc[a][b] = f32x4{v.x, v.y, v.z, v.w};
                 }
@@ -594,7 +683,14 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 }
             }
         }
+        NW_CSTAMP(4);                                              // epilogue of the tile
     }
+#ifdef NW_CONV_DIAG
+    if (tid == 0 && blockIdx.x < 1024) {
+        for (int k = 0; k < 5; ++k) nw_conv_diag[16 * blockIdx.x + 8 + k] = cd_[k];
+        nw_conv_diag[16 * blockIdx.x + 14] = cl_ - cf_;
+    }
+#endif
     // this workgroup's maximum -> its slot of the output's amax record (no atomics, nothing to clear beforehand)
     amax = wave_max(amax);
     float* red = reinterpret_cast<float*>(smem);
