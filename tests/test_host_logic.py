@@ -159,3 +159,23 @@ def test_bank_loader_workers_keep_the_row_order():
         banks.append((torch.cat(f), torch.cat(y)))
     assert torch.equal(banks[0][1], banks[1][1]) and torch.equal(banks[0][0], banks[1][0])
     assert banks[0][1].tolist() == sorted(banks[0][1].tolist())
+
+
+def test_dense_block_slab_node_is_a_device_path_only():
+    """ops.dense_block_nhwc_supported: CPU tensors, a missing weight bank or dropout never select the slab node (the module
+    then runs the reference's layer-by-layer sequence); nothing here touches the HIP library."""
+    import nwhead_amd.model.backbones as BB
+    from nwhead_amd import ops
+    block = BB._DenseBlock(2, 64, 4, 32, 0.0)
+    x = torch.randn(2, 64, 8, 8).contiguous(memory_format=torch.channels_last)
+    assert not ops.dense_block_nhwc_supported(x, list(block.children()), None)
+
+    class _Bank:                                              # would serve every weight: still refused for a CPU tensor
+        def has(self, w):
+            return True
+
+        def operands(self, w):
+            return (object(), object())
+    assert not ops.dense_block_nhwc_supported(x, list(block.children()), _Bank())
+    y = block(x)                                              # the CPU forward is the reference's sequence
+    assert y.shape == (2, 64 + 2 * 32, 8, 8)
