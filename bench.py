@@ -597,7 +597,7 @@ def main():
                               "achieved_vs_fp32_mfma_peak = achieved / 157.3 (the guide's fp32 MFMA peak, > 1 because "
                               "the work is not on the fp32 pipe).  clock_GHz / mfma_busy_frac (from the committed PMC passes of this "
                               "command) say at what clock and matrix-pipe occupancy it was reached: the kernel runs at "
-                              "~2.1-2.2 GHz with the pipe busy about half of the time (DESIGN.md 4.3)"
+                              "1.9-2.2 GHz (box to box) with the pipe busy about half of the time (DESIGN.md 4.3)"
                               if fast else "fp32 dense MFMA peak (guide)"),
                 "frac_fp16_pipe": (3 * ach / PEAK_F16_MFMA_TFLOPS) if fast else None,
                 "alg_frac_fp16_peak": ach / PEAK_F16_MFMA_TFLOPS,
