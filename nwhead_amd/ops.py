@@ -8,6 +8,7 @@ import ctypes
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import SCORE_KINDS, NWHipError
@@ -967,6 +968,7 @@ class _BNReLUNhwcFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy, gpass=None):
         lib = _lib.load()
         xv, wc, bc, mean, invstd = ctx.saved_tensors
@@ -1140,6 +1142,7 @@ class _ConvNhwcFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         xv, weight, amax_x = ctx.saved_tensors
         stride, pad = ctx.stride, ctx.pad
@@ -1299,6 +1302,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         return slab
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         lib = _lib.load()
         slab, *saved = ctx.saved_tensors
