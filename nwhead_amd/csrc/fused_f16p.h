@@ -255,7 +255,11 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
     static_assert(!(TWO && QB > 1), "two 128-query workgroups do not fit the LDS of a CU");
     static_assert(BQP % (8 * NLOAD) == 0, "query and support pieces must not share a loader round");
     constexpr int NB = TWO ? 3 : 4;  // ring depth
+#ifdef NW_ABL_AHEAD   // timing experiment (tools/bench_fused.hip): fewer stages in flight
+    constexpr int AHEAD = NW_ABL_AHEAD;
+#else
     constexpr int AHEAD = NB - 1;    // stages in flight per loader wave
+#endif
     static_assert(RS > 5, "the persistent kernel is built for the tall tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hdr0 = reinterpret_cast<float*>(smem);  // NHB header buffers of HDR_F floats, by tile index mod NHB
@@ -377,6 +381,9 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
             return true;
         };
         auto wait_landed = [&](bool issued) {  // everything but the youngest stage of this wave has landed
+#ifdef NW_ABL_AHEAD   // (with fewer stages in flight the youngest must have landed too: the consumers read one stage ahead)
+            if (AHEAD < NB - 1) { wait_vmcnt<0>(); return; }
+#endif
             if (!issued) wait_vmcnt<0>();
             else if (long_wave) { if (young_hdr) wait_vmcnt<NI + P::HPW>(); else wait_vmcnt<NI>(); }
             else { if (young_hdr) wait_vmcnt<NI_LO + P::HPW>(); else wait_vmcnt<NI_LO>(); }
