@@ -438,7 +438,8 @@ const void *nw_conv_zero_page(void);
 /* ---------------------------------------------------------------------------------------------
  * The same pair over channels-last activations (csrc/bn_nhwc.hip), for the training path whose convolutions run in
  * nw_conv2d_nhwc_f16x2: x is (rows = n h w, c) with row stride ldx >= c floats (a channel prefix of a wider NHWC
- * tensor qualifies), c % 4 == 0, y / dy / dx dense (rows, c).  Moments per row chunk merged in a fixed order (Chan),
+ * tensor qualifies), c % 4 == 0 and c <= 2560 (NW_ERR_UNSUPPORTED beyond: the per-channel factors live in LDS), y / dy / dx
+ * dense (rows, c).  Moments per row chunk merged in a fixed order (Chan),
  * deterministic; amax_out (nullable): the amax record (NW_AMAX_SLOTS floats) of y / dx for the convolution that reads
  * it next.  acc (nullable, backward): a second gradient of x with row stride ldacc, added into dx; lddx: row stride of
  * dx (0: dense); dx may be acc itself (the gradient slab of a dense block accumulates in place).

@@ -21,6 +21,8 @@ namespace nw {
 namespace {
 
 constexpr int BN_SLOTS = 256;        // = NW_AMAX_SLOTS
+constexpr int BN_MAX_C = 2560;       // channels: the backward apply keeps six per-channel factors in LDS (60 KB; DenseNet-161 / -201
+                                     // reach 2208 / 1920 channels in front of their last BatchNorm)
 constexpr int BN_TC = 64;            // channels per stats workgroup: 16 float4 lanes x 64 row lanes
 constexpr int BN_RL = 64;            // row lanes of a stats workgroup (1024 threads)
 constexpr int BN_GC = 16384;         // chunks x channels of the partial moments (196 KB: what every apply workgroup re-reads)
@@ -404,7 +406,7 @@ extern "C" int nw_bn_relu_nhwc_train_fwd_f32(const float* x, int64_t ldx, const 
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd) return NW_ERR_INVALID_ARG;
     if (bad_align(x, y, amax_out, workspace) || bad_align(gamma, beta, save_mean, save_invstd)) return NW_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < nw_bn_nhwc_workspace_bytes(rows, c)) return NW_ERR_WORKSPACE;
-    if (c > 1024) return NW_ERR_UNSUPPORTED;   // the per-channel factors and the merge scratch live in LDS
+    if (c > BN_MAX_C) return NW_ERR_UNSUPPORTED;   // the per-channel factors live in LDS
     hipStream_t st = static_cast<hipStream_t>(stream);
     int G; int64_t rpc;
     stats_grid(rows, c, &G, &rpc);
@@ -469,7 +471,7 @@ extern "C" int nw_bn_relu_nhwc_apply_f32(const float* x, int64_t ldx, const floa
     if (rows <= 0 || c <= 0 || c % 4 || ldx < c || ldx % 4) return NW_ERR_INVALID_ARG;
     if (!x || !mean || !invstd || !var || !gamma || !beta || !y) return NW_ERR_INVALID_ARG;
     if (bad_align(x, y, amax_out) || bad_align(gamma, beta, mean, invstd)) return NW_ERR_INVALID_ARG;
-    if (c > 1024) return NW_ERR_UNSUPPORTED;
+    if (c > BN_MAX_C) return NW_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ag = apply_grid(rows, c);
     const size_t lds = (size_t)3 * c * sizeof(float);
@@ -498,7 +500,7 @@ extern "C" int nw_bn_relu_nhwc_train_bwd_f32(const float* x, int64_t ldx, const 
     if (bad_align(x, dy, dx, acc) || bad_align(gamma, beta, save_mean, save_invstd) || bad_align(amax_out, workspace))
         return NW_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < nw_bn_nhwc_workspace_bytes(rows, c)) return NW_ERR_WORKSPACE;
-    if (c > 1024) return NW_ERR_UNSUPPORTED;
+    if (c > BN_MAX_C) return NW_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int G; int64_t rpc;
     stats_grid(rows, c, &G, &rpc);
@@ -538,7 +540,7 @@ extern "C" int nw_bn_relu_nhwc_train_bwd_from_partials_f32(const float* x, int64
         bad_align(dgamma, dbeta))
         return NW_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < (size_t)2 * c * sizeof(float)) return NW_ERR_WORKSPACE;
-    if (c > 1024) return NW_ERR_UNSUPPORTED;
+    if (c > BN_MAX_C) return NW_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* k = static_cast<float*>(workspace);
     hipLaunchKernelGGL(nw_bn_nhwc_bwd_sum_groups_kernel, dim3((unsigned)(c / 4)), dim3(1024), 0, st, partials, (int)groups, (int)c,

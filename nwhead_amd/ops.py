@@ -996,6 +996,9 @@ class _BNReLUNhwcFn(torch.autograd.Function):
         return dx, dg, db, None, None, None
 
 
+BN_NHWC_MAX_C = 2560      # channels nw_bn_relu_nhwc_train_* serve (bn_nhwc.hip: BN_MAX_C)
+
+
 def bn_relu_train_nhwc(x, bn, relu=True, passthrough=False):
     """relu(bn(x)) for a BatchNorm2d in training mode over a channels-last fp32 activation on the MI355X; the result is
     channels_last and carries `.nw_amax` for the convolution that follows.  passthrough: see bn_relu_train."""
@@ -1006,6 +1009,13 @@ def bn_relu_train_nhwc(x, bn, relu=True, passthrough=False):
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
     if x.shape[1] % 4:
         raise ValueError("bn_relu_train_nhwc needs a channel count that is a multiple of 4")
+    if x.shape[1] > BN_NHWC_MAX_C:           # wider than the kernels' per-channel tables: torch's BatchNorm on the same layout
+        y = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True,
+                                           0.0 if bn.momentum is None else bn.momentum, bn.eps)
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        y = torch.relu(y) if relu else y
+        return (y, x) if passthrough else y
     return _BNReLUNhwcFn.apply(x, bn.weight, bn.bias, bn, bool(relu), bool(passthrough))
 
 
@@ -1418,7 +1428,7 @@ def dense_block_nhwc_supported(x, layers, bank):
     lib = _lib.load()
     n, c0, h, w = x.shape
     growth, mid = layers[0].conv2.weight.shape[0], layers[0].conv1.weight.shape[0]
-    if n * h * w <= 1 or c0 % 32 or growth % 32 or mid % 32 or c0 + len(layers) * growth > 1024:
+    if n * h * w <= 1 or c0 % 32 or growth % 32 or mid % 32 or c0 + len(layers) * growth > BN_NHWC_MAX_C:
         return False
     for k, layer in enumerate(layers):
         c = c0 + k * growth

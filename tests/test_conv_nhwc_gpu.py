@@ -196,7 +196,8 @@ def test_weight_bank_operands_equal_the_per_weight_split(dev):
 
 
 @pytest.mark.parametrize("n,c,h,w,prefix,relu", [(4, 64, 12, 12, 0, True), (3, 160, 7, 7, 32, True), (2, 32, 30, 17, 0, False),
-                                                (6, 256, 14, 14, 0, True), (2, 1024, 7, 7, 0, True)])
+                                                (6, 256, 14, 14, 0, True), (2, 1024, 7, 7, 0, True),
+                                                (3, 1664, 7, 7, 0, True), (2, 2592, 4, 4, 0, True)])   # DenseNet-169's last norm; beyond the kernels' 2560: torch
 def test_bn_relu_nhwc_train_against_fp64(dev, n, c, h, w, prefix, relu):
     """nw_bn_relu_nhwc_train_fwd/bwd: outputs, running statistics, dx, dgamma, dbeta against fp64 torch, also on a channel
     prefix of a wider channels-last tensor (row stride > c) and with a pass-through gradient."""
@@ -220,7 +221,8 @@ def test_bn_relu_nhwc_train_against_fp64(dev, n, c, h, w, prefix, relu):
     (y64 * t.double()).sum().backward()
     sc = lambda a: max(float(a.detach().abs().max()), 1e-12)
     assert (y.double() - y64).abs().max().item() < 2e-6 * sc(y64)
-    assert float(y.nw_amax.max()) == float(y.detach().abs().max())
+    if c <= ops.BN_NHWC_MAX_C:
+        assert float(y.nw_amax.max()) == float(y.detach().abs().max())
     assert (x.grad.double() - x64.grad).abs().max().item() < 1e-5 * sc(x64.grad)
     assert (bn.weight.grad.double() - ref.weight.grad).abs().max().item() < 1e-5 * sc(ref.weight.grad)
     assert (bn.bias.grad.double() - ref.bias.grad).abs().max().item() < 1e-5 * sc(ref.bias.grad)
