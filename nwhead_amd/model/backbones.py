@@ -333,9 +333,29 @@ class DenseNet(nn.Module):
 
     def forward(self, x):
         if (NHWC_TRAINING and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-                and x.dim() == 4 and x.shape[1] == 3):
+                and x.dim() == 4 and x.shape[1] == 3 and self._nhwc_servable()):
             return self._forward_nhwc_train(x)
         return torch.flatten(F.adaptive_avg_pool2d(F.relu(self.features(x)), (1, 1)), 1)
+
+    def _nhwc_servable(self):
+        """Do the channels-last kernels serve every layer?  (convolutions: input and output channels in multiples of 32 --
+        DenseNet-161's growth of 48 is not -- apart from the RGB stem; BatchNorms: channels in multiples of 4.)  Otherwise the
+        NCHW path (MIOpen convolutions + the NCHW BatchNorm kernels) runs, as for every other module layout."""
+        ok = getattr(self, "_nw_nhwc_ok", None)
+        if ok is None:
+            f = self.features
+            ok = True
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    cout, cin = m.weight.shape[:2]
+                    if m is f.conv0:
+                        ok &= cin == 3 and cout % 32 == 0 and m.bias is None
+                    else:
+                        ok &= cin % 32 == 0 and cout % 32 == 0 and m.bias is None and m.stride == (1, 1) and m.groups == 1
+                elif isinstance(m, nn.BatchNorm2d):
+                    ok &= m.num_features % 4 == 0 and m.affine
+            self._nw_nhwc_ok = ok = bool(ok)
+        return ok
 
     def _forward_nhwc_train(self, x):
         """The training forward in channels-last layout on the MI355X (same values as the reference's module sequence,

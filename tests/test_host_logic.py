@@ -179,3 +179,12 @@ def test_dense_block_slab_node_is_a_device_path_only():
     assert not ops.dense_block_nhwc_supported(x, list(block.children()), _Bank())
     y = block(x)                                              # the CPU forward is the reference's sequence
     assert y.shape == (2, 64 + 2 * 32, 8, 8)
+
+
+def test_nhwc_training_path_is_chosen_by_architecture():
+    """DenseNet._nhwc_servable: the channels-last training kernels need channel counts in multiples of 32 -- DenseNet-161
+    (growth 48) stays on the NCHW path (its training step used to die with NW_ERR_UNSUPPORTED), -121 / -169 / -201 do not."""
+    from nwhead_amd.model import load_model
+    assert load_model("densenet121")._nhwc_servable()
+    assert load_model("densenet169")._nhwc_servable()
+    assert not load_model("densenet161")._nhwc_servable()

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nwhead_amd.model.backbones as BB
 from nwhead_amd.model import load_model
 dev = torch.device("cuda:0")
-for arch, n, side in (("densenet169", 6, 96), ("densenet201", 4, 96), ("densenet121", 3, 64), ("resnet18", 8, 96), ("resnet34", 4, 96),
+ARCHS = [a for a in sys.argv[1:]]
+for arch, n, side in [(a, 4, 96) for a in ARCHS] or (("densenet169", 6, 96), ("densenet201", 4, 96), ("densenet121", 3, 64), ("resnet18", 8, 96), ("resnet34", 4, 96),
                       ("CIFAR_DenseNet121", 8, 32), ("CIFAR_ResNet18", 8, 32)):
     torch.manual_seed(0)
     try:
