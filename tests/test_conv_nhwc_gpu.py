@@ -432,6 +432,45 @@ def test_dense_block_slab_node_against_layer_by_layer(dev, bwd_stats_in_dgrad):
         assert rel(rsb[k], rsa[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("n,c0,h,w,L", [(3, 96, 9, 11, 3), (1, 32, 5, 7, 2), (2, 160, 30, 17, 2), (7, 64, 3, 3, 5)])
+def test_dense_block_slab_node_on_ragged_shapes(dev, n, c0, h, w, L):
+    """The slab node on shapes whose pixel counts are no multiple of any tile (ragged last tiles and groups, one image,
+    tiny maps): input gradient and parameter gradients against the layer-by-layer channels-last path."""
+    import copy
+    import nwhead_amd.model.backbones as BB
+    from nwhead_amd import ops
+    torch.manual_seed(n + c0 + h)
+    block = BB._DenseBlock(L, c0, 4, 32, 0.0).to(dev).train()
+    with torch.no_grad():
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+    x0 = _cl(torch.randn(n, c0, h, w, device=dev) + 0.2)
+    t = _cl(torch.randn(n, c0 + L * 32, h, w, device=dev))
+    outs = []
+    for slab in (False, True):
+        blk = copy.deepcopy(block)
+        bank = ops.ConvWeightBank([(m.weight, True) for m in blk.modules() if isinstance(m, torch.nn.Conv2d)])
+        bank.refresh()
+        old = BB.DENSE_SLAB
+        BB.DENSE_SLAB = slab
+        try:
+            x = x0.clone().requires_grad_(True)
+            if slab and not ops.dense_block_nhwc_supported(x, list(blk.children()), bank):
+                pytest.skip("shape not served by the slab node")
+            y = blk.forward_nhwc_train(x, bank)
+            (y * t).sum().backward()
+        finally:
+            BB.DENSE_SLAB = old
+        outs.append((y.detach().double(), x.grad.double(), torch.cat([p.grad.double().flatten() for p in blk.parameters()])))
+    (ya, gxa, gpa), (yb, gxb, gpb) = outs
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    assert rel(yb, ya) < 2e-5
+    assert rel(gxb, gxa) < 5e-4
+    assert float((gpb * gpa).sum() / (gpb.norm() * gpa.norm())) > 0.99999
+
+
 @pytest.mark.parametrize("folding", [False, True])
 def test_k2_resnet18_plus_head_end_to_end(dev, folding):
     """BASELINE configs[1] end to end: load_model('resnet18') @224, 64 queries, a bank of N = 1000
