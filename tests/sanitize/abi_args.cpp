@@ -203,8 +203,8 @@ int main() {
     EXPECT(nw_bn_nhwc_moments_from_partials_f32(nullptr, 4, 64, 1e-5f, F, F, F, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_bn_relu_nhwc_apply_f32(F, 64, F, F, F, F, F, nullptr, nullptr, nullptr, 0.1f, F, nullptr, 100, 66, 1, nullptr),
            NW_ERR_INVALID_ARG);                                                                 // c % 4
-    EXPECT(nw_bn_relu_nhwc_apply_f32(F, 2048, F, F, F, F, F, nullptr, nullptr, nullptr, 0.1f, F, nullptr, 100, 2048, 1, nullptr),
-           NW_ERR_UNSUPPORTED);                                                                 // c > 1024
+    EXPECT(nw_bn_relu_nhwc_apply_f32(F, 2564, F, F, F, F, F, nullptr, nullptr, nullptr, 0.1f, F, nullptr, 100, 2564, 1, nullptr),
+           NW_ERR_UNSUPPORTED);                                                                 // c > 2560
     EXPECT(nw_bn_relu_nhwc_train_bwd_f32(F, 64, F, F, F, F, F, F, F, F, nullptr, 0, 32, nullptr, ws, sizeof ws, 100, 64, 1, nullptr),
            NW_ERR_INVALID_ARG);                                                                 // lddx < c
     std::printf(failures ? "abi_args: %d FAILED\n" : "abi_args: all argument checks refused as documented\n", failures);
