@@ -432,6 +432,19 @@ int nw_conv2d_nhwc_wgrad_f16x2(const float *x, const float *amax_x, const float 
                                void *workspace, size_t workspace_bytes, int64_t n, int64_t H, int64_t W, int64_t Cin,
                                int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int64_t ldx, int64_t ldg,
                                void *stream);
+/* Several independent weight gradients in as few launches as possible (all 3x3 problems in one kernel, all 1x1 problems in
+ * another, 32 per launch): the layers of a dense block on 14x14 / 7x7 maps give a dozen workgroups each, and their weight
+ * gradients are not on the backward's critical path -- collected per block and run together they fill the chip.  Each job
+ * as in nw_conv2d_nhwc_wgrad_f16x2; workspace: nw_conv2d_nhwc_wgrad_batch_workspace_bytes(jobs, njobs) (every job its own
+ * part).  Nothing is launched if any job is refused. */
+typedef struct nw_wgrad_job {
+    const float *x, *amax_x, *gy, *amax_g;
+    float *dw;
+    int64_t n, H, W, Cin, Cout, KH, KW, stride, pad, ldx, ldg;
+} nw_wgrad_job;
+size_t nw_conv2d_nhwc_wgrad_batch_workspace_bytes(const nw_wgrad_job *jobs, int64_t njobs);
+int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job *jobs, int64_t njobs, void *workspace, size_t workspace_bytes,
+                                     void *stream);
 /* device address of 32 bytes of zeros the convolution kernels read in place of pixels that do not exist (internal) */
 const void *nw_conv_zero_page(void);
 

@@ -69,6 +69,8 @@ SIGNATURES = {
     "nw_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i64] * 9),
     "nw_conv2d_nhwc_wgrad_f16x2": (_int, [_p, _p, _p, _p, _p, _p, _sz] + [_i64] * 11 + [_p]),
     "nw_conv_zero_page": (_p, []),
+    "nw_conv2d_nhwc_wgrad_batch_workspace_bytes": (_sz, [_p, _i64]),
+    "nw_conv2d_nhwc_wgrad_batch_f16x2": (_int, [_p, _i64, _p, _sz, _p]),
     "nw_bn_nhwc_workspace_bytes": (_sz, [_i64, _i64]),
     "nw_bn_relu_nhwc_train_fwd_f32": (_int, [_p, _i64] + [_p] * 10 + [_sz, _i64, _i64, C.c_float, C.c_float, _int, _p]),
     "nw_bn_relu_nhwc_train_bwd_f32": (_int, [_p, _i64] + [_p] * 9 + [_i64, _i64, _p, _p, _sz, _i64, _i64, _int, _p]),
@@ -107,6 +109,12 @@ def load():
     _lib = lib
     sync_knobs()
     return lib
+
+
+class WgradJob(C.Structure):
+    """nw_wgrad_job (include/nwhead_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("amax_x", C.c_void_p), ("gy", C.c_void_p), ("amax_g", C.c_void_p), ("dw", C.c_void_p)] + \
+               [(k, C.c_int64) for k in ("n", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "ldx", "ldg")]
 
 
 class ConvBnStat(C.Structure):

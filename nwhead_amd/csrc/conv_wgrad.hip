@@ -60,7 +60,7 @@ struct WgCfg {
 };
 
 template <bool TAPS9>
-__global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
+__device__ __forceinline__ void wgrad_body(const WgradP& p, int bx) {
     using C = WgCfg<TAPS9>;
     constexpr int COT = C::COT, CIT = C::CIT, GRS = C::GRS, XRS = C::XRS, NBG = C::NBG, RING = C::RING, NSET = C::NSET;
     constexpr int XAHEAD = C::XAHEAD, XBEHIND = C::XBEHIND, GP = C::GP, XP = C::XP;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroup -> (position chunk, output-channel tile, input-channel tile)
-    int b = blockIdx.x;
+    int b = bx;
     const int cit = b % p.ci_tiles; b /= p.ci_tiles;
     const int cot = b % p.co_tiles; b /= p.co_tiles;
     const int kc = b;
@@ -118,7 +118,11 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
                 const int row = g_r + GROWS * q;
                 const int px = (row < 32 && sg >= s0 && sg < s1) ? pixel(pg[q]) : -1;
                 const int ch = co0 + 8 * g_c;
+#ifdef NW_WABL_NOLOAD   // ablation builds (tools/bench_wgrad.hip)
+                const bool ok = false; (void)px; (void)ch;
+#else
                 const bool ok = px >= 0 && ch < p.Cout;
+#endif
                 const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.gy + (size_t)px * p.ldg + ch) : zpage);
                 L.g[q][0] = src[0];
                 L.g[q][1] = src[1];
@@ -129,7 +133,11 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
                 const int row = x_r + XROWS * q;
                 const int px = row < 32 ? pixel(px_[q]) : -1;
                 const int ch = ci0 + 8 * x_c;
+#ifdef NW_WABL_NOLOAD
+                const bool ok = false; (void)px; (void)ch;
+#else
                 const bool ok = px >= 0 && ch < p.Cin;
+#endif
                 const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.x + (size_t)px * p.ldx + ch) : zpage);
                 L.x[q][0] = src[0];
                 L.x[q][1] = src[1];
@@ -164,6 +172,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
             *reinterpret_cast<uint4*>(rowp + ((((u + 2) ^ f)) << 5) + ((cgrp & 1) << 4)) = lv;
         };
         auto write = [&](const Set& L, int sg, int sx) {
+#ifdef NW_WABL_NOCVT
+            if (L.g[0][0].x != 12345.678f) return;
+#endif
 #pragma unroll
             for (int q = 0; q < GP; ++q) {
                 const int row = g_r + GROWS * q;
@@ -228,7 +239,11 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
         const halfx4w bq = tr4(base + rb * rs + ((unit ^ unit_swz(rb)) << 5) + 8 * tp);
         return half8{a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
     };
+#ifdef NW_WABL_NOMFMA
+    auto mm = [](const half8& a, const half8& bq, f32x4 c) { c[0] += (float)a[0] * (float)bq[0]; return c; };
+#else
     auto mm = [](const half8& a, const half8& bq, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, c, 0, 0, 0); };
+#endif
     auto unit_of = [](int col0, bool low) { return 4 * (col0 >> 5) + ((col0 >> 4) & 1) + (low ? 2 : 0); };
 
     constexpr int NACC = TAPS9 ? 18 : 16;
@@ -266,6 +281,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
         xb[f] = swz_c(shift + lr + 4, u);
     }
     auto rd8 = [&](const char* pa, const char* pb) {
+#ifdef NW_WABL_NOFRAG
+        return half8{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
+#endif
         const halfx4w a = tr4(pa), bq = tr4(pb);
         return half8{a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
     };
@@ -344,13 +362,37 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) {
     }
 }
 
+template <bool TAPS9>
+__global__ __launch_bounds__(512, 1) void nw_conv_wgrad_kernel(const WgradP p) { wgrad_body<TAPS9>(p, blockIdx.x); }
+
+// Several independent weight gradients in ONE launch (the kernel arguments hold up to 32 problems and the first workgroup of
+// each): the 14x14 and 7x7 layers of a dense block give 12-38 workgroups each -- launched one after the other they leave
+// most of the chip idle for ~20 us apiece; their gradients are not on the backward's critical path, so a block's layers are
+// collected and run together.
+constexpr int WG_BATCH = 32;
+struct WgradBatch {
+    int n;
+    int first[WG_BATCH + 1];
+    WgradP p[WG_BATCH];
+};
+template <bool TAPS9>
+__global__ __launch_bounds__(512, 1) void nw_conv_wgrad_batch_kernel(const WgradBatch bt) {
+    int prob = 0;
+    for (int k = 1; k < bt.n; ++k)
+        if ((int)blockIdx.x >= bt.first[k]) prob = k;      // (wave-uniform: scalar compares)
+    wgrad_body<TAPS9>(bt.p[prob], (int)blockIdx.x - bt.first[prob]);
+}
+
+struct RedJob { const float* part; float* dw; long long total4; int ks; int first; };
+struct RedBatch { int n; RedJob j[WG_BATCH]; };
+
 // dw[idx] = sum_k part[k][idx] in chunk order: 64 float4 columns x 16 chunk lanes per workgroup -- lane j adds the chunks
 // j, j + 16, ... (coalesced across the columns), the 16 partial sums are added in lane order through LDS (deterministic)
-__global__ __launch_bounds__(1024) void nw_conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                     int64_t total4, int ks) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int64_t total4, int ks,
+                                                  int bx) {
     __shared__ float4 sh[16][64];
     const int col = threadIdx.x & 63, j = threadIdx.x >> 6;
-    const int64_t idx = (int64_t)blockIdx.x * 64 + col;
+    const int64_t idx = (int64_t)bx * 64 + col;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < total4)
         for (int k = j; k < ks; k += 16) {
@@ -366,6 +408,16 @@ __global__ __launch_bounds__(1024) void nw_conv_wgrad_reduce_kernel(const float*
         }
         reinterpret_cast<float4*>(dw)[idx] = a;
     }
+}
+__global__ __launch_bounds__(1024) void nw_conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                     int64_t total4, int ks) {
+    wgrad_reduce_body(part, dw, total4, ks, blockIdx.x);
+}
+__global__ __launch_bounds__(1024) void nw_conv_wgrad_reduce_batch_kernel(const RedBatch rb) {
+    int job = 0;
+    for (int k = 1; k < rb.n; ++k)
+        if ((int)blockIdx.x >= rb.j[k].first) job = k;
+    wgrad_reduce_body(rb.j[job].part, rb.j[job].dw, rb.j[job].total4, rb.j[job].ks, (int)blockIdx.x - rb.j[job].first);
 }
 
 struct WgPlan {
@@ -463,6 +515,94 @@ extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, c
         const int64_t total4 = Cout * KH * KW * Cin / 4;
         hipLaunchKernelGGL(nw_conv_wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(1024), 0, st,
                            static_cast<const float*>(workspace), dw, total4, pl.ks);
+    }
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+// ---- a batch of weight gradients (nw_wgrad_job, include/nwhead_hip.h)
+static size_t wgrad_job_ws(const nw_wgrad_job& j) {
+    const size_t b = nw_conv2d_nhwc_wgrad_workspace_bytes(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad);
+    return (b + 255) & ~(size_t)255;
+}
+
+extern "C" size_t nw_conv2d_nhwc_wgrad_batch_workspace_bytes(const nw_wgrad_job* jobs, int64_t njobs) {
+    size_t total = 0;
+    for (int64_t k = 0; jobs && k < njobs; ++k) total += wgrad_job_ws(jobs[k]);
+    return total;
+}
+
+extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_t njobs, void* workspace, size_t workspace_bytes,
+                                                void* stream) {
+    using namespace nw;
+    if (njobs < 0 || (njobs > 0 && !jobs)) return NW_ERR_INVALID_ARG;
+    if (njobs == 0) return NW_OK;
+    if (workspace_bytes < nw_conv2d_nhwc_wgrad_batch_workspace_bytes(jobs, njobs) || (workspace_bytes && !workspace) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return NW_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float4* zeros = static_cast<const float4*>(nw_conv_zero_page());
+    if (!zeros) return NW_ERR_LAUNCH;
+    static const bool attr9 = hipFuncSetAttribute(reinterpret_cast<const void*>(nw_conv_wgrad_batch_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgCfg<true>::LDS) == hipSuccess;
+    static const bool attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(nw_conv_wgrad_batch_kernel<false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgCfg<false>::LDS) == hipSuccess;
+    if (!attr9 || !attr1) return NW_ERR_LAUNCH;
+    // validate everything first: nothing is launched for a batch with a bad job
+    for (int64_t k = 0; k < njobs; ++k) {
+        const nw_wgrad_job& j = jobs[k];
+        WgPlan pl;
+        if (!wgrad_plan(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad, &pl)) return NW_ERR_UNSUPPORTED;
+        const int64_t ldx = j.ldx ? j.ldx : j.Cin, ldg = j.ldg ? j.ldg : j.Cout;
+        if (!j.x || !j.amax_x || !j.gy || !j.amax_g || !j.dw || ldx < j.Cin || ldg < j.Cout || ldx % 4 || ldg % 4) return NW_ERR_INVALID_ARG;
+        if ((reinterpret_cast<uintptr_t>(j.x) | reinterpret_cast<uintptr_t>(j.gy) | reinterpret_cast<uintptr_t>(j.dw) |
+             reinterpret_cast<uintptr_t>(j.amax_x) | reinterpret_cast<uintptr_t>(j.amax_g)) & 15)
+            return NW_ERR_INVALID_ARG;
+    }
+    char* wsp = static_cast<char*>(workspace);
+    for (int pass = 0; pass < 2; ++pass) {                   // 3x3 problems, then 1x1 problems: two kernels
+        const bool want9 = pass == 0;
+        WgradBatch bt;
+        RedBatch rb;
+        bt.n = 0; bt.first[0] = 0; rb.n = 0;
+        int red_wgs = 0;
+        auto flush = [&]() {
+            if (bt.n) {
+                if (want9) hipLaunchKernelGGL(nw_conv_wgrad_batch_kernel<true>, dim3((unsigned)bt.first[bt.n]), dim3(512), WgCfg<true>::LDS, st, bt);
+                else hipLaunchKernelGGL(nw_conv_wgrad_batch_kernel<false>, dim3((unsigned)bt.first[bt.n]), dim3(512), WgCfg<false>::LDS, st, bt);
+            }
+            if (rb.n) hipLaunchKernelGGL(nw_conv_wgrad_reduce_batch_kernel, dim3((unsigned)red_wgs), dim3(1024), 0, st, rb);
+            bt.n = 0; bt.first[0] = 0; rb.n = 0; red_wgs = 0;
+        };
+        size_t off = 0;
+        for (int64_t k = 0; k < njobs; ++k) {
+            const nw_wgrad_job& j = jobs[k];
+            const size_t wsz = wgrad_job_ws(j);
+            char* jws = wsp + off;
+            off += wsz;
+            WgPlan pl;
+            wgrad_plan(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad, &pl);
+            if (pl.taps9 != want9) continue;
+            WgradP& q = bt.p[bt.n];
+            q.x = j.x; q.amax_x = j.amax_x; q.gy = j.gy; q.amax_g = j.amax_g;
+            q.part = pl.ks == 1 ? j.dw : reinterpret_cast<float*>(jws);
+            q.zeros = zeros;
+            q.N = (int)j.n; q.H = (int)j.H; q.W = (int)j.W; q.Cin = (int)j.Cin; q.Cout = (int)j.Cout; q.T = (int)(j.KH * j.KW);
+            q.KW = (int)j.KW; q.pad = (int)j.pad;
+            q.ldx = (int)(j.ldx ? j.ldx : j.Cin); q.ldg = (int)(j.ldg ? j.ldg : j.Cout);
+            q.IP = pl.IP; q.IMG = pl.IMG; q.nstage = pl.nstage; q.ks = pl.ks; q.spc = pl.spc; q.co_tiles = pl.co_tiles; q.ci_tiles = pl.ci_tiles;
+            bt.first[bt.n + 1] = bt.first[bt.n] + pl.ks * pl.co_tiles * pl.ci_tiles;
+            ++bt.n;
+            if (pl.ks > 1) {
+                RedJob& r = rb.j[rb.n];
+                r.part = reinterpret_cast<const float*>(jws); r.dw = j.dw; r.total4 = j.Cout * j.KH * j.KW * j.Cin / 4; r.ks = pl.ks;
+                r.first = red_wgs;
+                red_wgs += (int)((r.total4 + 63) / 64);
+                ++rb.n;
+            }
+            if (bt.n == WG_BATCH) flush();
+        }
+        flush();
     }
     NW_CHECK_LAUNCH();
     return NW_OK;

@@ -1328,6 +1328,9 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         st = _stream(slab)
         f32 = dict(dtype=torch.float32, device=dev)
         grads = [None] * (6 * len(ctx.meta))
+        # the weight gradients are not on the critical path: collected here and run together behind the loop
+        # (nw_conv2d_nhwc_wgrad_batch_f16x2: a dozen workgroups per 14x14 / 7x7 layer fill the chip only together)
+        wjobs, wkeep = [], []
         with _OnDevice(dev):
             for k in range(len(ctx.meta) - 1, -1, -1):
                 c, kh, d1, d2, w1s, w2s = ctx.meta[k]
@@ -1336,11 +1339,9 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                 gv = G.data_ptr() + 4 * c                              # this layer's window of the gradient slab
                 # conv2 (3x3): weight gradient, data gradient
                 dw2 = torch.empty((growth, kh, kh, mid), **f32)
-                wsb = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, mid, growth, kh, kh, 1, kh // 2)
-                ws = _workspace(wsb, dev)
-                _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, gv, _ptr(am_g), _ptr(dw2),
-                                                          _ptr(ws), wsb, n, h, w, mid, growth, kh, kh, 1, kh // 2, 0, ctot, st),
-                           "nw_conv2d_nhwc_wgrad_f16x2")
+                wjobs.append(_lib.WgradJob(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, gv, _ptr(am_g), _ptr(dw2),
+                                           n, h, w, mid, growth, kh, kh, 1, kh // 2, 0, ctot))
+                wkeep.append(am_g)
                 if DENSE_BWD_STATS_IN_DGRAD:
                     dt2 = torch.empty((rows, mid), **f32)
                     am_d = torch.empty(3 * AMAX_SLOTS, **f32)              # amax records of dt2 | du | dt1
@@ -1363,11 +1364,9 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                         "nw_bn_relu_nhwc_train_bwd_from_partials_f32")
                     # conv1 (1x1)
                     dw1 = torch.empty((mid, 1, 1, c), **f32)
-                    wsb = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, c, mid, 1, 1, 1, 0)
-                    ws = _workspace(wsb, dev)
-                    _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
-                                                              _ptr(ws), wsb, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, st),
-                               "nw_conv2d_nhwc_wgrad_f16x2")
+                    wjobs.append(_lib.WgradJob(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
+                                               n, h, w, c, mid, 1, 1, 1, 0, 0, 0))
+                    wkeep += [du, am_d]
                     dt1 = torch.empty((rows, c), **f32)
                     bs1 = _lib.ConvBnStat(_ptr(slab), ctot, _ptr(m1), _ptr(i1), _ptr(g1), _ptr(b1), _ptr(bpart))
                     _lib.check(lib.nw_conv2d_nhwc_bnstat_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale),
@@ -1397,11 +1396,9 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                                "nw_bn_relu_nhwc_train_bwd_f32")
                     # conv1 (1x1)
                     dw1 = torch.empty((mid, 1, 1, c), **f32)
-                    wsb = lib.nw_conv2d_nhwc_wgrad_workspace_bytes(n, h, w, c, mid, 1, 1, 1, 0)
-                    ws = _workspace(wsb, dev)
-                    _lib.check(lib.nw_conv2d_nhwc_wgrad_f16x2(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
-                                                              _ptr(ws), wsb, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, st),
-                               "nw_conv2d_nhwc_wgrad_f16x2")
+                    wjobs.append(_lib.WgradJob(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
+                                               n, h, w, c, mid, 1, 1, 1, 0, 0, 0))
+                    wkeep += [du, am_d]
                     dt1 = torch.empty((rows, c), **f32)
                     _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,
                                                         None, 0, _ptr(dt1), am_d.data_ptr() + 8 * AMAX_SLOTS, n, h, w, mid, c, 1, 1, 1, 0,
@@ -1413,6 +1410,13 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                                                                  _ptr(G), _ptr(dg1), _ptr(db1), _ptr(G), ctot, ctot, _ptr(am_g),
                                                                  _ptr(wsn), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
                 grads[6 * k:6 * k + 6] = [dg1, db1, dw1.permute(0, 3, 1, 2), dg2, db2, dw2.permute(0, 3, 1, 2)]
+            if wjobs:
+                jobs = (_lib.WgradJob * len(wjobs))(*wjobs)
+                wsb = lib.nw_conv2d_nhwc_wgrad_batch_workspace_bytes(jobs, len(wjobs))
+                ws = _workspace(wsb, dev)
+                _lib.check(lib.nw_conv2d_nhwc_wgrad_batch_f16x2(jobs, len(wjobs), _ptr(ws), wsb, st),
+                           "nw_conv2d_nhwc_wgrad_batch_f16x2")
+        del wkeep
         dx = None
         if ctx.needs_input_grad[0]:
             dx = G[:, :c0].contiguous(memory_format=torch.channels_last)
