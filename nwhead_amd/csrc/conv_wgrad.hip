@@ -427,7 +427,7 @@ struct WgPlan {
 };
 
 bool wgrad_plan(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad,
-                WgPlan* pl) {
+                WgPlan* pl, int target_wgs = 256) {
     if (n <= 0 || H <= 0 || W <= 0 || stride != 1 || KH != KW || (KH != 1 && KH != 3) || pad != (KH - 1) / 2) return false;
     if (Cin % 8 || Cout % 8 || Cin < 8 || Cout < 8) return false;
     pl->taps9 = KH == 3;
@@ -443,7 +443,7 @@ bool wgrad_plan(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int6
     const int64_t tiles = (int64_t)pl->co_tiles * pl->ci_tiles;
     // ~one workgroup per CU, and no more chunks than the output tile is worth: the partial tiles cross memory twice
     // (written, read by the reduction), 2 ks Cout T Cin floats against (Cout + Cin) 32 nstage read by the product
-    int64_t ks = (256 + tiles - 1) / tiles;
+    int64_t ks = (target_wgs + tiles - 1) / tiles;   // (a batch of problems shares the chip: fewer chunks each)
     // at least 4 (3x3: 8, a chunk starts with four steps of rows around its first stage) stages per chunk: small planes are
     // latency-bound and want many workgroups
     int64_t minst = pl->taps9 ? 8 : 4;   // (16 / 8 until round 3: K4 19.05 -> 18.83 ms with twice the workgroups on the small planes)
@@ -521,7 +521,15 @@ extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, c
 }
 
 // ---- a batch of weight gradients (nw_wgrad_job, include/nwhead_hip.h)
-static size_t wgrad_job_ws(const nw_wgrad_job& j) {
+static int batch_target_wgs(int64_t njobs) {
+    const int k = nw::knob(nw::KNOB_WGRAD_BATCH_WGS);
+    if (k > 0) return k;
+    // the jobs share the chip: ~1024 workgroups in all, 64..256 per job (K4: 17.36-17.42 ms at 64 per job, 17.66-17.70 at 256:
+    // fewer chunks = smaller partial tiles and a shorter reduce)
+    const int64_t t = 1024 / (njobs > 0 ? njobs : 1);
+    return (int)(t < 64 ? 64 : (t > 256 ? 256 : t));
+}
+static size_t wgrad_job_ws(const nw_wgrad_job& j) {   // (sized for the largest split: one chunk per ~256 / tiles workgroups)
     const size_t b = nw_conv2d_nhwc_wgrad_workspace_bytes(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad);
     return (b + 255) & ~(size_t)255;
 }
@@ -548,11 +556,12 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
     static const bool attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(nw_conv_wgrad_batch_kernel<false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgCfg<false>::LDS) == hipSuccess;
     if (!attr9 || !attr1) return NW_ERR_LAUNCH;
+    const int tgt = batch_target_wgs(njobs);
     // validate everything first: nothing is launched for a batch with a bad job
     for (int64_t k = 0; k < njobs; ++k) {
         const nw_wgrad_job& j = jobs[k];
         WgPlan pl;
-        if (!wgrad_plan(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad, &pl)) return NW_ERR_UNSUPPORTED;
+        if (!wgrad_plan(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad, &pl, tgt)) return NW_ERR_UNSUPPORTED;
         const int64_t ldx = j.ldx ? j.ldx : j.Cin, ldg = j.ldg ? j.ldg : j.Cout;
         if (!j.x || !j.amax_x || !j.gy || !j.amax_g || !j.dw || ldx < j.Cin || ldg < j.Cout || ldx % 4 || ldg % 4) return NW_ERR_INVALID_ARG;
         if ((reinterpret_cast<uintptr_t>(j.x) | reinterpret_cast<uintptr_t>(j.gy) | reinterpret_cast<uintptr_t>(j.dw) |
@@ -581,7 +590,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
             char* jws = wsp + off;
             off += wsz;
             WgPlan pl;
-            wgrad_plan(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad, &pl);
+            wgrad_plan(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad, &pl, tgt);
             if (pl.taps9 != want9) continue;
             WgradP& q = bt.p[bt.n];
             q.x = j.x; q.amax_x = j.amax_x; q.gy = j.gy; q.amax_g = j.amax_g;
