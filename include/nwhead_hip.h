@@ -441,6 +441,7 @@ typedef struct nw_wgrad_job {
     const float *x, *amax_x, *gy, *amax_g;
     float *dw;
     int64_t n, H, W, Cin, Cout, KH, KW, stride, pad, ldx, ldg;
+    int64_t out_oihw;   /* != 0: dw in torch's contiguous (Cout, Cin, KH, KW) layout instead of (Cout, KH, KW, Cin) */
 } nw_wgrad_job;
 size_t nw_conv2d_nhwc_wgrad_batch_workspace_bytes(const nw_wgrad_job *jobs, int64_t njobs);
 int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job *jobs, int64_t njobs, void *workspace, size_t workspace_bytes,

@@ -383,13 +383,13 @@ __global__ __launch_bounds__(512, 1) void nw_conv_wgrad_batch_kernel(const Wgrad
     wgrad_body<TAPS9>(bt.p[prob], (int)blockIdx.x - bt.first[prob]);
 }
 
-struct RedJob { const float* part; float* dw; long long total4; int ks; int first; };
+struct RedJob { const float* part; float* dw; long long total4; int ks; int first; int T, Cin; };   // T > 1: dw is written as (Cout, Cin, T)
 struct RedBatch { int n; RedJob j[WG_BATCH]; };
 
 // dw[idx] = sum_k part[k][idx] in chunk order: 64 float4 columns x 16 chunk lanes per workgroup -- lane j adds the chunks
 // j, j + 16, ... (coalesced across the columns), the 16 partial sums are added in lane order through LDS (deterministic)
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int64_t total4, int ks,
-                                                  int bx) {
+                                                  int bx, int T = 1, int Cin = 0) {
     __shared__ float4 sh[16][64];
     const int col = threadIdx.x & 63, j = threadIdx.x >> 6;
     const int64_t idx = (int64_t)bx * 64 + col;
@@ -406,7 +406,13 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
             const float4 v = sh[l][col];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        reinterpret_cast<float4*>(dw)[idx] = a;
+        if (T <= 1) {
+            reinterpret_cast<float4*>(dw)[idx] = a;
+        } else {   // partials are (Cout, T, Cin); the caller wants torch's (Cout, Cin, KH, KW): four strided stores (small tensors)
+            const int64_t e = idx * 4, row = e / Cin, ci = e - row * Cin, co = row / T, t = row - co * T;
+            float* o = dw + (co * Cin + ci) * T + t;
+            o[0] = a.x; o[T] = a.y; o[2 * T] = a.z; o[3 * T] = a.w;
+        }
     }
 }
 __global__ __launch_bounds__(1024) void nw_conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
@@ -417,7 +423,8 @@ __global__ __launch_bounds__(1024) void nw_conv_wgrad_reduce_batch_kernel(const 
     int job = 0;
     for (int k = 1; k < rb.n; ++k)
         if ((int)blockIdx.x >= rb.j[k].first) job = k;
-    wgrad_reduce_body(rb.j[job].part, rb.j[job].dw, rb.j[job].total4, rb.j[job].ks, (int)blockIdx.x - rb.j[job].first);
+    wgrad_reduce_body(rb.j[job].part, rb.j[job].dw, rb.j[job].total4, rb.j[job].ks, (int)blockIdx.x - rb.j[job].first, rb.j[job].T,
+                      rb.j[job].Cin);
 }
 
 struct WgPlan {
@@ -530,7 +537,9 @@ static int batch_target_wgs(int64_t njobs) {
     return (int)(t < 64 ? 64 : (t > 256 ? 256 : t));
 }
 static size_t wgrad_job_ws(const nw_wgrad_job& j) {   // (sized for the largest split: one chunk per ~256 / tiles workgroups)
-    const size_t b = nw_conv2d_nhwc_wgrad_workspace_bytes(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad);
+    size_t b = nw_conv2d_nhwc_wgrad_workspace_bytes(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad);
+    const size_t one = (size_t)(j.Cout * j.KH * j.KW * j.Cin) * sizeof(float);
+    if (b < one) b = one;
     return (b + 255) & ~(size_t)255;
 }
 
@@ -594,7 +603,8 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
             if (pl.taps9 != want9) continue;
             WgradP& q = bt.p[bt.n];
             q.x = j.x; q.amax_x = j.amax_x; q.gy = j.gy; q.amax_g = j.amax_g;
-            q.part = pl.ks == 1 ? j.dw : reinterpret_cast<float*>(jws);
+            const bool oihw = j.out_oihw != 0 && j.KH * j.KW > 1;   // torch's weight layout: written by the reduce kernel
+            q.part = (pl.ks == 1 && !oihw) ? j.dw : reinterpret_cast<float*>(jws);
             q.zeros = zeros;
             q.N = (int)j.n; q.H = (int)j.H; q.W = (int)j.W; q.Cin = (int)j.Cin; q.Cout = (int)j.Cout; q.T = (int)(j.KH * j.KW);
             q.KW = (int)j.KW; q.pad = (int)j.pad;
@@ -602,9 +612,10 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
             q.IP = pl.IP; q.IMG = pl.IMG; q.nstage = pl.nstage; q.ks = pl.ks; q.spc = pl.spc; q.co_tiles = pl.co_tiles; q.ci_tiles = pl.ci_tiles;
             bt.first[bt.n + 1] = bt.first[bt.n] + pl.ks * pl.co_tiles * pl.ci_tiles;
             ++bt.n;
-            if (pl.ks > 1) {
+            if (pl.ks > 1 || oihw) {
                 RedJob& r = rb.j[rb.n];
                 r.part = reinterpret_cast<const float*>(jws); r.dw = j.dw; r.total4 = j.Cout * j.KH * j.KW * j.Cin / 4; r.ks = pl.ks;
+                r.T = oihw ? (int)(j.KH * j.KW) : 1; r.Cin = (int)j.Cin;
                 r.first = red_wgs;
                 red_wgs += (int)((r.total4 + 63) / 64);
                 ++rb.n;

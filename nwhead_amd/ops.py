@@ -1338,9 +1338,9 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                 m1, i1, m2, i2 = bstat[:c], bstat[ctot:ctot + c], stats[:mid], stats[mid:2 * mid]
                 gv = G.data_ptr() + 4 * c                              # this layer's window of the gradient slab
                 # conv2 (3x3): weight gradient, data gradient
-                dw2 = torch.empty((growth, kh, kh, mid), **f32)
+                dw2 = torch.empty((growth, mid, kh, kh), **f32)          # torch's layout: autograd takes it without a copy
                 wjobs.append(_lib.WgradJob(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, gv, _ptr(am_g), _ptr(dw2),
-                                           n, h, w, mid, growth, kh, kh, 1, kh // 2, 0, ctot))
+                                           n, h, w, mid, growth, kh, kh, 1, kh // 2, 0, ctot, 1))
                 wkeep.append(am_g)
                 if DENSE_BWD_STATS_IN_DGRAD:
                     dt2 = torch.empty((rows, mid), **f32)
@@ -1365,7 +1365,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                     # conv1 (1x1)
                     dw1 = torch.empty((mid, 1, 1, c), **f32)
                     wjobs.append(_lib.WgradJob(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
-                                               n, h, w, c, mid, 1, 1, 1, 0, 0, 0))
+                                               n, h, w, c, mid, 1, 1, 1, 0, 0, 0, 0))
                     wkeep += [du, am_d]
                     dt1 = torch.empty((rows, c), **f32)
                     bs1 = _lib.ConvBnStat(_ptr(slab), ctot, _ptr(m1), _ptr(i1), _ptr(g1), _ptr(b1), _ptr(bpart))
@@ -1397,7 +1397,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                     # conv1 (1x1)
                     dw1 = torch.empty((mid, 1, 1, c), **f32)
                     wjobs.append(_lib.WgradJob(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
-                                               n, h, w, c, mid, 1, 1, 1, 0, 0, 0))
+                                               n, h, w, c, mid, 1, 1, 1, 0, 0, 0, 0))
                     wkeep += [du, am_d]
                     dt1 = torch.empty((rows, c), **f32)
                     _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,
@@ -1409,7 +1409,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                     _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(slab), ctot, _ptr(dt1), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(i1),
                                                                  _ptr(G), _ptr(dg1), _ptr(db1), _ptr(G), ctot, ctot, _ptr(am_g),
                                                                  _ptr(wsn), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
-                grads[6 * k:6 * k + 6] = [dg1, db1, dw1.permute(0, 3, 1, 2), dg2, db2, dw2.permute(0, 3, 1, 2)]
+                grads[6 * k:6 * k + 6] = [dg1, db1, dw1.permute(0, 3, 1, 2), dg2, db2, dw2]
             if wjobs:
                 jobs = (_lib.WgradJob * len(wjobs))(*wjobs)
                 wsb = lib.nw_conv2d_nhwc_wgrad_batch_workspace_bytes(jobs, len(wjobs))
