@@ -492,6 +492,24 @@ int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, 
                                   void *workspace, size_t workspace_bytes, int64_t rows, int64_t c, int relu, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The pools of the backbones' training path over channels-last fp32 activations (csrc/pool_nhwc.hip): the 2 x 2 / 2
+ * average pool of a DenseNet transition (reference model/densenet.py:83-91, nn.AvgPool2d(2, 2): an odd last row / column
+ * is dropped) and the 3 x 3 / 2 pad 1 max pool of the stems (model/densenet.py:114, model/resnet.py:147; torch's scan:
+ * a later value of the window wins when it is greater or NaN).  x (n, h, w, c), c % 4 == 0, rows may be strided (ld* >= c
+ * floats, 0: dense): a pool can read from / write into a channel prefix of a wider NHWC tensor.  The max pool leaves the
+ * winning tap (ky * 3 + kx) of every output value in `tap` ((n, ho, wo, c) bytes, dense), which is all its backward needs
+ * beside gy; both backwards are gathers over the input pixels (no atomics, deterministic) and write every value of gx.
+ * ------------------------------------------------------------------------------------------- */
+int nw_avgpool2x2_nhwc_f32(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n, int64_t h, int64_t w, int64_t c,
+                           void *stream);
+int nw_avgpool2x2_nhwc_bwd_f32(const float *gy, int64_t ldgy, float *gx, int64_t ldgx, int64_t n, int64_t h, int64_t w,
+                               int64_t c, void *stream);
+int nw_maxpool3x3s2_nhwc_f32(const float *x, int64_t ldx, float *y, int64_t ldy, unsigned char *tap, int64_t n, int64_t h,
+                             int64_t w, int64_t c, void *stream);
+int nw_maxpool3x3s2_nhwc_bwd_f32(const float *gy, int64_t ldgy, const unsigned char *tap, float *gx, int64_t ldgx, int64_t n,
+                                 int64_t h, int64_t w, int64_t c, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): device time of the TILE kernel alone -- the kernel the
  * roofline is quoted on (nw_fused_kernel / nw_fused_f16p_kernel), without the small kernels around
  * it (query split, run tables, merge).  While enabled, every forward brackets its tile-kernel launch
@@ -501,7 +519,8 @@ int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, 
 int nw_debug_tile_timing(int enable);
 /* Diagnostic knobs (timing experiments; process-wide; never needed in normal use).  Names: pvar, qg, tile_rs, merge_mq,
  * merge_per_query, merge_no_global_tables, persistent_any_rs, no_persistent, split_queries, bwd_no_mfma, bwd_split,
- * coeff_threads, xgemm_wgs, xgemm_nbuf, split_lbits, conv_gather, conv_max_wgs.  The Python layer forwards
+ * coeff_threads, xgemm_wgs, xgemm_nbuf, split_lbits, conv_gather, conv_max_wgs, wgrad_min_stages, conv_skip_cfgs,
+ * wgrad_batch_wgs, bn_inline_fin.  The Python layer forwards
  * the NW_<NAME> environment variables once, when it loads the library; the library itself never reads the environment. */
 int nw_debug_set(const char *name, int value);
 int nw_debug_tile_timing_read(double *total_us, int64_t *launches);

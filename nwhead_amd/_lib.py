@@ -74,6 +74,10 @@ SIGNATURES = {
     "nw_bn_nhwc_workspace_bytes": (_sz, [_i64, _i64]),
     "nw_bn_relu_nhwc_train_fwd_f32": (_int, [_p, _i64] + [_p] * 10 + [_sz, _i64, _i64, C.c_float, C.c_float, _int, _p]),
     "nw_bn_relu_nhwc_train_bwd_f32": (_int, [_p, _i64] + [_p] * 9 + [_i64, _i64, _p, _p, _sz, _i64, _i64, _int, _p]),
+    "nw_avgpool2x2_nhwc_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "nw_avgpool2x2_nhwc_bwd_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "nw_maxpool3x3s2_nhwc_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
+    "nw_maxpool3x3s2_nhwc_bwd_f32": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "nw_debug_set": (_int, [C.c_char_p, _int]),
     "nw_debug_tile_timing": (_int, [_int]),
     "nw_debug_tile_timing_read": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -133,7 +137,7 @@ class FwdOpts(C.Structure):
 # forward call's nw_fwd_opts; the others are diagnostic knobs, forwarded once at load time (and again by sync_knobs()).
 KNOBS = ("pvar", "qg", "tile_rs", "merge_mq", "merge_per_query", "merge_no_global_tables", "persistent_any_rs", "no_persistent",
          "split_queries", "bwd_no_mfma", "bwd_split", "coeff_threads", "xgemm_wgs", "xgemm_nbuf", "split_lbits", "conv_gather",
-         "conv_max_wgs", "wgrad_min_stages", "conv_skip_cfgs", "wgrad_batch_wgs")
+         "conv_max_wgs", "wgrad_min_stages", "conv_skip_cfgs", "wgrad_batch_wgs", "bn_inline_fin")
 _KNOB_UNSET = -2 ** 31
 _knob_state = {}
 

@@ -26,6 +26,8 @@ constexpr int BN_MAX_C = 2560;       // channels: the backward apply keeps six p
 constexpr int BN_TC = 64;            // channels per stats workgroup: 16 float4 lanes x 64 row lanes
 constexpr int BN_RL = 64;            // row lanes of a stats workgroup (1024 threads)
 constexpr int BN_GC = 16384;         // chunks x channels of the partial moments (196 KB: what every apply workgroup re-reads)
+constexpr int BN_INLINE_ROWS = 16384;  // backward of maps this small: no finalize launch, the apply workgroups merge
+constexpr int BN_INLINE_GC = 8192;     //   at most this many chunk sums themselves
 
 __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float n2, float mean2, float m22) {
     const float nt = n + n2;
@@ -326,17 +328,42 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_bwd_apply_kernel(const float*
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                      const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                                      const float* __restrict__ k, const float* acc, int64_t ldacc,
-                                                                     float* dx, int64_t lddx, float* __restrict__ amax, int64_t R, int C) {
+                                                                     float* dx, int64_t lddx, float* __restrict__ amax, int64_t R, int C,
+                                                                     const float* __restrict__ part, int G, float inv_m,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
     extern __shared__ float prm[];   // [6][C]: mean, invstd, a, beta, k1, k2
     __shared__ float red[16];
+    if (G > 0) {
+        // few chunks (small maps, C <= 1024): every workgroup sums them itself -- 1024 / C chunk lanes per channel, their
+        // partial sums in order -- and workgroup 0 leaves dgamma / dbeta: one launch less per call
+        __shared__ float fin[2][1024];
+        const int nj = 1024 / C, j = threadIdx.x / C, c = threadIdx.x - j * C;
+        float p1 = 0.f, p2 = 0.f;
+        if (j < nj)
+            for (int g = j; g < G; g += nj) {
+                p1 += part[(int64_t)g * C + c];
+                p2 += part[((int64_t)G + g) * C + c];
+            }
+        fin[0][threadIdx.x] = p1; fin[1][threadIdx.x] = p2;
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            float s1 = fin[0][c], s2 = fin[1][c];
+            for (int jj = 1; jj < nj; ++jj) { s1 += fin[0][jj * C + c]; s2 += fin[1][jj * C + c]; }
+            prm[4 * C + c] = s1 * inv_m;
+            prm[5 * C + c] = s2 * inv_m;
+            if (blockIdx.x == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+        }
+    }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float inv = save_invstd[c];
         prm[c] = save_mean[c];
         prm[C + c] = inv;
         prm[2 * C + c] = gamma[c] * inv;
         prm[3 * C + c] = beta[c];
-        prm[4 * C + c] = k[c];
-        prm[5 * C + c] = k[C + c];
+        if (G <= 0) {
+            prm[4 * C + c] = k[c];
+            prm[5 * C + c] = k[C + c];
+        }
     }
     __syncthreads();
     const int q4 = C >> 2;
@@ -504,6 +531,14 @@ extern "C" int nw_bn_relu_nhwc_train_bwd_f32(const float* x, int64_t ldx, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     int G; int64_t rpc;
     stats_grid(rows, c, &G, &rpc);
+    // small maps: at most 8192 chunk sums, merged by the apply workgroups themselves (no finalize launch)
+    const bool inline_fin = rows <= BN_INLINE_ROWS && c <= 1024 && knob(KNOB_BN_INLINE_FIN) != 0;
+    if (inline_fin && (int64_t)G * c > BN_INLINE_GC) {
+        int64_t g = BN_INLINE_GC / c;
+        if (g < 1) g = 1;
+        rpc = (rows + g - 1) / g;
+        G = (int)((rows + rpc - 1) / rpc);
+    }
     float* part = static_cast<float*>(workspace);
     const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
     const int ag = apply_grid(rows, c);
@@ -513,10 +548,12 @@ extern "C" int nw_bn_relu_nhwc_train_bwd_f32(const float* x, int64_t ldx, const 
     do {                                                                                                                       \
         hipLaunchKernelGGL((nw_bn_nhwc_bwd_stats_kernel<R_>), dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, dy, gamma, beta, \
                            save_mean, save_invstd, part, rows, (int)c, G, rpc);                                               \
-        hipLaunchKernelGGL(nw_bn_nhwc_bwd_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, \
-                           1.f / (float)rows, dgamma, dbeta, k);                                                               \
+        if (!inline_fin)                                                                                                       \
+            hipLaunchKernelGGL(nw_bn_nhwc_bwd_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G,    \
+                               (int)c, 1.f / (float)rows, dgamma, dbeta, k);                                                   \
         hipLaunchKernelGGL((nw_bn_nhwc_bwd_apply_kernel<R_>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, dy, gamma, beta,  \
-                           save_mean, save_invstd, k, acc, ldacc, dx, lddx, amax_out, rows, (int)c);                                 \
+                           save_mean, save_invstd, k, acc, ldacc, dx, lddx, amax_out, rows, (int)c, part, inline_fin ? G : 0,  \
+                           1.f / (float)rows, dgamma, dbeta);                                                                  \
     } while (0)
     if (relu) NW_BNB(true); else NW_BNB(false);
 #undef NW_BNB
@@ -548,7 +585,8 @@ extern "C" int nw_bn_relu_nhwc_train_bwd_from_partials_f32(const float* x, int64
     const int ag = apply_grid(rows, c);
     const size_t lds = (size_t)6 * c * sizeof(float);
     hipLaunchKernelGGL((nw_bn_nhwc_bwd_apply_kernel<true>), dim3((unsigned)ag), dim3(1024), lds, st, x, ldx, dy, gamma, beta, save_mean,
-                       save_invstd, k, acc, ldacc, dx, lddx, amax_out, rows, (int)c);
+                       save_invstd, k, acc, ldacc, dx, lddx, amax_out, rows, (int)c, (const float*)nullptr, 0, 0.f, (float*)nullptr,
+                       (float*)nullptr);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

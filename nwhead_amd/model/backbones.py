@@ -295,6 +295,15 @@ class _DenseBlock(nn.Module):
         return slab
 
 
+def _is_pool(mod, kind, k, s, p):
+    """mod is exactly kind(k, s, p) with the defaults the reference uses (no ceil_mode, dilation 1, padded values counted)."""
+    def same(v, want):
+        return v == want or v == (want, want)
+    return (type(mod) is kind and same(mod.kernel_size, k) and same(mod.stride, s) and same(mod.padding, p)
+            and not mod.ceil_mode and same(getattr(mod, "dilation", 1), 1) and not getattr(mod, "return_indices", False)
+            and getattr(mod, "count_include_pad", True) and getattr(mod, "divisor_override", None) is None)
+
+
 class _Transition(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(OrderedDict([("norm", nn.BatchNorm2d(cin)), ("relu", nn.ReLU(inplace=True)),
@@ -370,14 +379,14 @@ class DenseNet(nn.Module):
             bank = self._nw_bank = ops.ConvWeightBank(convs)
         bank.refresh()
         y = ops.bn_relu_train_nhwc(ops.conv2d_nhwc_train(x, f.conv0.weight, 2, 3, operands=bank.operands(f.conv0.weight)), f.norm0)
-        y = f.pool0(y)
+        y = ops.maxpool3s2_nhwc(y) if _is_pool(f.pool0, nn.MaxPool2d, 3, 2, 1) else f.pool0(y)
         for mod in f.children():
             if isinstance(mod, _DenseBlock):
                 y = mod.forward_nhwc_train(y, bank)
             elif isinstance(mod, _Transition):
                 z = ops.conv2d_nhwc_train(ops.bn_relu_train_nhwc(y, mod.norm), mod.conv.weight, 1, 0,
                                           operands=bank.operands(mod.conv.weight))
-                y = mod.pool(z)
+                y = ops.avgpool2_nhwc(z) if _is_pool(mod.pool, nn.AvgPool2d, 2, 2, 0) else mod.pool(z)
         y = ops.bn_relu_train_nhwc(y, f.norm5)          # (norm5 + the relu of DenseNet.forward)
         return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
 

@@ -1019,6 +1019,87 @@ def bn_relu_train_nhwc(x, bn, relu=True, passthrough=False):
     return _BNReLUNhwcFn.apply(x, bn.weight, bn.bias, bn, bool(relu), bool(passthrough))
 
 
+class _AvgPool2NhwcFn(torch.autograd.Function):
+    """F.avg_pool2d(x, 2, 2) over a channels-last fp32 activation (nw_avgpool2x2_nhwc_f32 / _bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        xv, ldx = _nhwc_rows(x.detach())
+        n, c, h, w = xv.shape
+        y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=xv.device, memory_format=torch.channels_last)
+        with _OnDevice(xv.device):
+            _lib.check(lib.nw_avgpool2x2_nhwc_f32(_ptr(xv), ldx, _ptr(y), c, n, h, w, c, _stream(xv)), "nw_avgpool2x2_nhwc_f32")
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        lib = _lib.load()
+        n, c, h, w = ctx.shape
+        gv, ldg = _nhwc_rows(gy)
+        gx = torch.empty((n, c, h, w), dtype=torch.float32, device=gv.device, memory_format=torch.channels_last)
+        with _OnDevice(gv.device):
+            _lib.check(lib.nw_avgpool2x2_nhwc_bwd_f32(_ptr(gv), ldg, _ptr(gx), c, n, h, w, c, _stream(gv)),
+                       "nw_avgpool2x2_nhwc_bwd_f32")
+        return gx
+
+
+class _MaxPool3s2NhwcFn(torch.autograd.Function):
+    """F.max_pool2d(x, 3, 2, 1) over a channels-last fp32 activation (nw_maxpool3x3s2_nhwc_f32 / _bwd_f32): the winning tap of
+    each window is kept as one byte for the backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        xv, ldx = _nhwc_rows(x.detach())
+        n, c, h, w = xv.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=xv.device, memory_format=torch.channels_last)
+        tap = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=xv.device)
+        with _OnDevice(xv.device):
+            _lib.check(lib.nw_maxpool3x3s2_nhwc_f32(_ptr(xv), ldx, _ptr(y), c, _ptr(tap), n, h, w, c, _stream(xv)),
+                       "nw_maxpool3x3s2_nhwc_f32")
+        ctx.save_for_backward(tap)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        lib = _lib.load()
+        tap, = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        gv, ldg = _nhwc_rows(gy)
+        gx = torch.empty((n, c, h, w), dtype=torch.float32, device=gv.device, memory_format=torch.channels_last)
+        with _OnDevice(gv.device):
+            _lib.check(lib.nw_maxpool3x3s2_nhwc_bwd_f32(_ptr(gv), ldg, _ptr(tap), _ptr(gx), c, n, h, w, c, _stream(gv)),
+                       "nw_maxpool3x3s2_nhwc_bwd_f32")
+        return gx
+
+
+def avgpool2_nhwc(x):
+    """nn.AvgPool2d(2, 2) of a DenseNet transition (reference model/densenet.py:83-91) over a channels-last fp32 activation on
+    the MI355X; the result is channels_last."""
+    _need_hip(x)
+    if x.dim() != 4 or x.shape[1] % 4 or x.shape[2] < 2 or x.shape[3] < 2:
+        raise ValueError(f"avgpool2_nhwc needs (n, c % 4 == 0, h >= 2, w >= 2), got {tuple(x.shape)}")
+    return _AvgPool2NhwcFn.apply(x)
+
+
+def maxpool3s2_nhwc(x):
+    """nn.MaxPool2d(3, 2, 1) of the stems (reference model/densenet.py:114, model/resnet.py:147) over a channels-last fp32
+    activation on the MI355X; the result is channels_last and keeps x's `.nw_amax` bound."""
+    _need_hip(x)
+    if x.dim() != 4 or x.shape[1] % 4:
+        raise ValueError(f"maxpool3s2_nhwc needs (n, c % 4 == 0, h, w), got {tuple(x.shape)}")
+    y = _MaxPool3s2NhwcFn.apply(x)
+    if hasattr(x, "nw_amax"):
+        y.nw_amax = x.nw_amax
+    return y
+
+
 class _WeightOperand:
     """A split-row convolution operand inside a ConvWeightBank (the interface conv2d_nhwc reads: split, scale, shape)."""
     __slots__ = ("split", "scale", "shape")
@@ -1195,7 +1276,7 @@ class _ConvNhwcFn(torch.autograd.Function):
 def conv2d_nhwc_wgrad(x, gy, wshape, stride, pad, amax_x=None, amax_g=None):
     """Weight gradient of conv2d for channels-last x (n, Cin, H, W) and gy (n, Cout, Ho, Wo) -> (Cout, Cin, KH, KW)
     (channels_last strides).  Stride-1 'same' 1x1 / 3x3 shapes run in nw_conv2d_nhwc_wgrad_f16x2; the rest (the strided
-    stem) goes to torch in NCHW."""
+    stem) goes to MIOpen through torch."""
     lib = _lib.load()
     cout, cin, kh, kw = wshape
     n, _, h, w = x.shape
@@ -1212,7 +1293,11 @@ def conv2d_nhwc_wgrad(x, gy, wshape, stride, pad, amax_x=None, amax_g=None):
                                                       n, h, w, cin, cout, kh, kw, stride, pad, 0, 0, _stream(x)),
                        "nw_conv2d_nhwc_wgrad_f16x2")
         return dw.permute(0, 3, 1, 2)
-    return torch.ops.aten.convolution_backward(gy.contiguous(), x.contiguous(), torch.empty(wshape, dtype=x.dtype, device=x.device),
+    # the strided stem: MIOpen's channels-last weight-gradient kernel on channels-last operands (as NCHW tensors it copies gy
+    # and transposes it back: 431 vs 185 us for the 7 x 7 / 2 stem of K4)
+    return torch.ops.aten.convolution_backward(gy.contiguous(memory_format=torch.channels_last),
+                                               x.contiguous(memory_format=torch.channels_last),
+                                               torch.empty(wshape, dtype=x.dtype, device=x.device),
                                                None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
                                                [False, True, False])[1]
 

@@ -231,6 +231,36 @@ def test_bn_relu_nhwc_train_against_fp64(dev, n, c, h, w, prefix, relu):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("n,c,h,w,prefix", [(2, 8, 9, 11, 0), (3, 64, 56, 56, 0), (2, 128, 28, 28, 32), (1, 4, 2, 2, 0),
+                                            (2, 12, 7, 1, 0), (42, 64, 112, 112, 0)])
+def test_pools_nhwc_against_torch(dev, n, c, h, w, prefix):
+    """nw_avgpool2x2_nhwc / nw_maxpool3x3s2_nhwc forward and backward against torch's pools on the same channels-last input:
+    forward bit-equal (same window scan, same tie rule -- quantised values make ties frequent; -inf and NaN included),
+    backward bit-equal for the average pool and to rounding of <= 4-term sums for the max pool; odd sizes, strided rows."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(n * 131 + c + h)
+    full = _cl((torch.randn(n, c + prefix, h, w, generator=g) * 2).round().div(2).to(dev))      # many equal values
+    if full.numel() > 64:
+        full[0, 0, 0, 0] = float("-inf")
+        full[-1, 1, 1, 0] = float("nan")
+    for name, mine, theirs in (("max", ops.maxpool3s2_nhwc, lambda t: F.max_pool2d(t, 3, 2, 1)),
+                               ("avg", ops.avgpool2_nhwc, lambda t: F.avg_pool2d(t, 2, 2))):
+        if name == "avg" and (h < 2 or w < 2):
+            continue
+        x = full[:, :c].detach().requires_grad_(True)
+        xr = full[:, :c].detach().clone().requires_grad_(True)
+        y, yr = mine(x), theirs(xr)
+        assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(torch.nan_to_num(y, nan=123.0), torch.nan_to_num(yr, nan=123.0)), name
+        assert torch.equal(y.isnan(), yr.isnan())
+        t = _cl(torch.randn(y.shape, generator=g).to(dev))
+        y.backward(t); yr.backward(t)
+        if name == "avg":
+            assert torch.equal(x.grad, xr.grad)
+        else:
+            assert (x.grad - xr.grad).abs().max().item() <= 1e-6 * float(t.abs().max()) * 4, name
+
+
 def test_bn_nhwc_statistics_on_awkward_channels(dev):
     """Constant channels, an offset 1e3 with spread 1e-2, a rounding-sized ripple: the chunk moments (shifted sums merged
     with Chan's formula) keep the variance where E[x^2] - E[x]^2 loses it."""
