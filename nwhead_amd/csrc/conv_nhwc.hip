@@ -538,6 +538,14 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             }
             if (MF > PAIR) __builtin_amdgcn_sched_group_barrier(0x008, MF - PAIR, 0);
         };
+        // the epilogue's per-channel factors, requested now: their L2 latency (~1 us, once per tile) passes behind the main loop
+        float4 ws4[NA], b4[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int co = co0 + wco + 16 * a + 4 * g;
+            ws4[a] = *reinterpret_cast<const float4*>(p.wscale + co);
+            b4[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         Frag f0, f1;
         load_frags(f0, 0);
         NW_CSTAMP(3);                                              // tile set-up (+ the first fragments' issue)
@@ -564,18 +572,15 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             const int co = co0 + wco + 16 * a + 4 * g;
-            const float4 ws4 = *reinterpret_cast<const float4*>(p.wscale + co);
-            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + co);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int m = m0 + wpx + 16 * b + i;
                 if (m < p.M) {
                     float4 v;
-                    v.x = __builtin_fmaf(acc[a][b][0], ws4.x * inv_up, b4.x);
-                    v.y = __builtin_fmaf(acc[a][b][1], ws4.y * inv_up, b4.y);
-                    v.z = __builtin_fmaf(acc[a][b][2], ws4.z * inv_up, b4.z);
-                    v.w = __builtin_fmaf(acc[a][b][3], ws4.w * inv_up, b4.w);
+                    v.x = __builtin_fmaf(acc[a][b][0], ws4[a].x * inv_up, b4[a].x);
+                    v.y = __builtin_fmaf(acc[a][b][1], ws4[a].y * inv_up, b4[a].y);
+                    v.z = __builtin_fmaf(acc[a][b][2], ws4[a].z * inv_up, b4[a].z);
+                    v.w = __builtin_fmaf(acc[a][b][3], ws4[a].w * inv_up, b4[a].w);
                     const size_t o = (size_t)m * p.ldy + co;
                     if (p.res) {
                         const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.Cout + co);

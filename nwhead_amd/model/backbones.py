@@ -239,6 +239,10 @@ class _DenseBlock(nn.Module):
         for i in range(num_layers):
             self.add_module(f"denselayer{i + 1}", _DenseLayer(cin + i * growth_rate, growth_rate, bn_size, drop_rate))
 
+    def slab_room(self):
+        """Channels the block's layers append to its input."""
+        return sum(layer.conv2.weight.shape[0] for layer in self.children())
+
     def forward_nhwc_train(self, x, bank=None):
         """Channels-last training forward of the block (DenseNet._forward_nhwc_train): the running concatenation passes
         through norm1's autograd node like in forward() below."""
@@ -377,16 +381,23 @@ class DenseNet(nn.Module):
             # every convolution weight's split-row operands (forward + data gradient), rebuilt by one launch per step
             convs = [(m.weight, m is not f.conv0) for m in self.modules() if isinstance(m, nn.Conv2d)]
             bank = self._nw_bank = ops.ConvWeightBank(convs)
-        bank.refresh()
+        bank.refresh(force=True)        # one launch (80 us); a fused optimizer's step leaves no trace in the version counters
         y = ops.bn_relu_train_nhwc(ops.conv2d_nhwc_train(x, f.conv0.weight, 2, 3, operands=bank.operands(f.conv0.weight)), f.norm0)
-        y = ops.maxpool3s2_nhwc(y) if _is_pool(f.pool0, nn.MaxPool2d, 3, 2, 1) else f.pool0(y)
-        for mod in f.children():
+        mods = list(f.children())
+
+        def room(i):        # the pool in front of a dense block writes into the block's slab-to-be (ops._with_room)
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            return nxt.slab_room() if isinstance(nxt, _DenseBlock) and DENSE_SLAB else 0
+
+        i0 = mods.index(f.pool0)
+        y = ops.maxpool3s2_nhwc(y, room(i0)) if _is_pool(f.pool0, nn.MaxPool2d, 3, 2, 1) else f.pool0(y)
+        for i, mod in enumerate(mods):
             if isinstance(mod, _DenseBlock):
                 y = mod.forward_nhwc_train(y, bank)
             elif isinstance(mod, _Transition):
                 z = ops.conv2d_nhwc_train(ops.bn_relu_train_nhwc(y, mod.norm), mod.conv.weight, 1, 0,
                                           operands=bank.operands(mod.conv.weight))
-                y = ops.avgpool2_nhwc(z) if _is_pool(mod.pool, nn.AvgPool2d, 2, 2, 0) else mod.pool(z)
+                y = ops.avgpool2_nhwc(z, room(i)) if _is_pool(mod.pool, nn.AvgPool2d, 2, 2, 0) else mod.pool(z)
         y = ops.bn_relu_train_nhwc(y, f.norm5)          # (norm5 + the relu of DenseNet.forward)
         return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
 

@@ -92,7 +92,8 @@ class NWNet(nn.Module):
 
     def _weights_signature(self):
         """Changes whenever a parameter or buffer of the featurizer is written in place (optimizer step,
-        load_state_dict, BatchNorm statistics) or replaced: the folded inference copy is rebuilt then."""
+        load_state_dict, BatchNorm statistics) or replaced: the folded inference copy is rebuilt then.  (torch's fused
+        optimizers do not advance version counters; train(), which every training loop passes through, drops the copy.)"""
         ts = list(self.featurizer.parameters()) + list(self.featurizer.buffers())
         return (len(ts), sum(t._version for t in ts), sum(t.data_ptr() & 0xffff for t in ts))
 

@@ -993,6 +993,7 @@ class _BNReLUNhwcFn(torch.autograd.Function):
                                                          ws_bytes, rows, c, int(ctx.relu), _stream(xv)),
                        "nw_bn_relu_nhwc_train_bwd_f32")
         dx.nw_amax = amax
+        dx.nw_fresh = True        # nobody else holds this buffer: a dense block's backward may use it as its gradient slab
         return dx, dg, db, None, None, None
 
 
@@ -1019,17 +1020,29 @@ def bn_relu_train_nhwc(x, bn, relu=True, passthrough=False):
     return _BNReLUNhwcFn.apply(x, bn.weight, bn.bias, bn, bool(relu), bool(passthrough))
 
 
+def _with_room(n, c, h, w, room, dev):
+    """A channels-last (n, c, h, w) result tensor, alone or -- room > 0 -- as the first c channels of a fresh (n, c + room, h, w)
+    allocation it carries as `.nw_slab`: a dense block that follows adopts that allocation as its slab instead of copying its
+    input into one (_DenseBlockNhwcFn).  -> (tensor, row stride)"""
+    if room <= 0:
+        return torch.empty((n, c, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last), c
+    full = torch.empty((n, c + room, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    y = full[:, :c]
+    y.nw_slab = full
+    return y, c + room
+
+
 class _AvgPool2NhwcFn(torch.autograd.Function):
     """F.avg_pool2d(x, 2, 2) over a channels-last fp32 activation (nw_avgpool2x2_nhwc_f32 / _bwd_f32)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, room):
         lib = _lib.load()
         xv, ldx = _nhwc_rows(x.detach())
         n, c, h, w = xv.shape
-        y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=xv.device, memory_format=torch.channels_last)
+        y, ldy = _with_room(n, c, h // 2, w // 2, room, xv.device)
         with _OnDevice(xv.device):
-            _lib.check(lib.nw_avgpool2x2_nhwc_f32(_ptr(xv), ldx, _ptr(y), c, n, h, w, c, _stream(xv)), "nw_avgpool2x2_nhwc_f32")
+            _lib.check(lib.nw_avgpool2x2_nhwc_f32(_ptr(xv), ldx, _ptr(y), ldy, n, h, w, c, _stream(xv)), "nw_avgpool2x2_nhwc_f32")
         ctx.shape = (n, c, h, w)
         return y
 
@@ -1043,7 +1056,7 @@ class _AvgPool2NhwcFn(torch.autograd.Function):
         with _OnDevice(gv.device):
             _lib.check(lib.nw_avgpool2x2_nhwc_bwd_f32(_ptr(gv), ldg, _ptr(gx), c, n, h, w, c, _stream(gv)),
                        "nw_avgpool2x2_nhwc_bwd_f32")
-        return gx
+        return gx, None
 
 
 class _MaxPool3s2NhwcFn(torch.autograd.Function):
@@ -1051,15 +1064,15 @@ class _MaxPool3s2NhwcFn(torch.autograd.Function):
     each window is kept as one byte for the backward."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, room):
         lib = _lib.load()
         xv, ldx = _nhwc_rows(x.detach())
         n, c, h, w = xv.shape
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-        y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=xv.device, memory_format=torch.channels_last)
+        y, ldy = _with_room(n, c, ho, wo, room, xv.device)
         tap = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=xv.device)
         with _OnDevice(xv.device):
-            _lib.check(lib.nw_maxpool3x3s2_nhwc_f32(_ptr(xv), ldx, _ptr(y), c, _ptr(tap), n, h, w, c, _stream(xv)),
+            _lib.check(lib.nw_maxpool3x3s2_nhwc_f32(_ptr(xv), ldx, _ptr(y), ldy, _ptr(tap), n, h, w, c, _stream(xv)),
                        "nw_maxpool3x3s2_nhwc_f32")
         ctx.save_for_backward(tap)
         ctx.shape = (n, c, h, w)
@@ -1076,25 +1089,25 @@ class _MaxPool3s2NhwcFn(torch.autograd.Function):
         with _OnDevice(gv.device):
             _lib.check(lib.nw_maxpool3x3s2_nhwc_bwd_f32(_ptr(gv), ldg, _ptr(tap), _ptr(gx), c, n, h, w, c, _stream(gv)),
                        "nw_maxpool3x3s2_nhwc_bwd_f32")
-        return gx
+        return gx, None
 
 
-def avgpool2_nhwc(x):
+def avgpool2_nhwc(x, room=0):
     """nn.AvgPool2d(2, 2) of a DenseNet transition (reference model/densenet.py:83-91) over a channels-last fp32 activation on
-    the MI355X; the result is channels_last."""
+    the MI355X; the result is channels_last.  room: channels to leave behind every pixel's c (see _with_room)."""
     _need_hip(x)
     if x.dim() != 4 or x.shape[1] % 4 or x.shape[2] < 2 or x.shape[3] < 2:
         raise ValueError(f"avgpool2_nhwc needs (n, c % 4 == 0, h >= 2, w >= 2), got {tuple(x.shape)}")
-    return _AvgPool2NhwcFn.apply(x)
+    return _AvgPool2NhwcFn.apply(x, int(room))
 
 
-def maxpool3s2_nhwc(x):
+def maxpool3s2_nhwc(x, room=0):
     """nn.MaxPool2d(3, 2, 1) of the stems (reference model/densenet.py:114, model/resnet.py:147) over a channels-last fp32
     activation on the MI355X; the result is channels_last and keeps x's `.nw_amax` bound."""
     _need_hip(x)
     if x.dim() != 4 or x.shape[1] % 4:
         raise ValueError(f"maxpool3s2_nhwc needs (n, c % 4 == 0, h, w), got {tuple(x.shape)}")
-    y = _MaxPool3s2NhwcFn.apply(x)
+    y = _MaxPool3s2NhwcFn.apply(x, int(room))
     if hasattr(x, "nw_amax"):
         y.nw_amax = x.nw_amax
     return y
@@ -1162,14 +1175,16 @@ class ConvWeightBank:
             self._ops[id(w)] = tuple(made)
         self._ptrs = tuple(w.data_ptr() for w in self.weights)
 
-    def refresh(self):
-        """Rebuild the operands if any weight changed (in place: its version; replaced: its address)."""
+    def refresh(self, force=False):
+        """Rebuild the operands if any weight changed (in place: its version; replaced: its address).  force: rebuild
+        regardless -- what a training forward asks for, because torch's FUSED optimizers (SGD / Adam(fused=True)) update
+        parameters without advancing their version counters, so an unchanged version proves nothing there."""
         ptrs = tuple(w.data_ptr() for w in self.weights)
         if ptrs != self._ptrs:
             self._build_tables()
             self._sig = None
         sig = tuple(w._version for w in self.weights)
-        if sig == self._sig:
+        if sig == self._sig and not force:
             return
         dev = self.split.device
         with _OnDevice(dev):
@@ -1339,8 +1354,11 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         growth = layers[0].conv2.weight.shape[0]
         mid = layers[0].conv1.weight.shape[0]
         ctot = c0 + L * growth
-        slab = torch.empty((n, ctot, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-        slab[:, :c0] = xv
+        slab = getattr(x, "nw_slab", None)            # the producer left room behind x's channels (_with_room): no copy
+        if not (slab is not None and tuple(slab.shape) == (n, ctot, h, w) and slab.data_ptr() == xv.data_ptr() and ldx0 == ctot
+                and slab.dtype == torch.float32 and slab.is_contiguous(memory_format=torch.channels_last)):
+            slab = torch.empty((n, ctot, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+            slab[:, :c0] = xv
         st = _stream(xv)
         saved, meta = [], []
         f32 = dict(dtype=torch.float32, device=dev)
@@ -1406,8 +1424,9 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         rows, dev = n * h * w, slab.device
         am_g = getattr(gout, "nw_amax", None)
         G = gout.float().contiguous(memory_format=torch.channels_last)
-        if G.data_ptr() == gout.data_ptr():
-            G = G.clone(memory_format=torch.channels_last)             # the gradient slab is updated in place
+        if G.data_ptr() == gout.data_ptr() and not getattr(gout, "nw_fresh", False):
+            G = G.clone(memory_format=torch.channels_last)             # the gradient slab is updated in place: a buffer of
+                                                                       #   our own BatchNorm backward (`nw_fresh`) is adopted
         if am_g is None:
             am_g = absmax(G)
         st = _stream(slab)
@@ -1504,7 +1523,7 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         del wkeep
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = G[:, :c0].contiguous(memory_format=torch.channels_last)
+            dx = G[:, :c0]                  # a channel prefix of the gradient slab (the pools' backward reads strided rows)
             dx.nw_amax = am_g
         return (dx, None, None, *grads)
 

@@ -328,6 +328,37 @@ def test_densenet_training_step_nhwc_against_fp64(dev):
     assert c1 > 0.9999 and (1 - c1) < 3 * (1 - c0) + 1e-7, (c0, c1)
 
 
+def test_training_forward_sees_a_fused_optimizer_step(dev):
+    """torch's fused optimizers update parameters without advancing their version counters: the channels-last training
+    forward must rebuild its weight operands anyway (ConvWeightBank.refresh(force=True)).  After a large fused SGD step the
+    channels-last forward agrees with the NCHW / MIOpen forward of the same, updated weights -- and not with the old ones."""
+    import nwhead_amd.model.backbones as BB
+    from nwhead_amd.model import load_model
+    torch.manual_seed(1)
+    net = load_model("densenet121").to(dev).train()
+    x = torch.randn(4, 3, 64, 64, device=dev)
+    opt = torch.optim.SGD(net.parameters(), lr=0.5, fused=True)
+
+    def fwd(nhwc):
+        old = BB.NHWC_TRAINING
+        BB.NHWC_TRAINING = nhwc
+        try:
+            return net(x)
+        finally:
+            BB.NHWC_TRAINING = old
+
+    before = fwd(True)
+    before.square().mean().backward()
+    versions = [p._version for p in net.parameters()]
+    opt.step()
+    if [p._version for p in net.parameters()] != versions:
+        pytest.skip("this torch build's fused SGD advances the version counters")
+    after, ref = fwd(True).detach(), fwd(False).detach()
+    sc = float(ref.abs().max())
+    assert (after - ref).abs().max().item() < 1e-4 * sc
+    assert (before.detach() - ref).abs().max().item() > 1e-2 * sc     # the step did move the features
+
+
 @pytest.mark.parametrize("n,cin,h,w,cout,k,xw,yw", [(3, 64, 14, 14, 128, 1, 96, 0), (2, 128, 28, 28, 32, 3, 0, 96),
                                                     (2, 32, 14, 14, 128, 3, 160, 0), (5, 128, 7, 7, 32, 3, 0, 864),
                                                     (2, 128, 56, 56, 128, 1, 0, 0)])
