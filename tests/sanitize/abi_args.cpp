@@ -207,6 +207,20 @@ int main() {
            NW_ERR_UNSUPPORTED);                                                                 // c > 2560
     EXPECT(nw_bn_relu_nhwc_train_bwd_f32(F, 64, F, F, F, F, F, F, F, F, nullptr, 0, 32, nullptr, ws, sizeof ws, 100, 64, 1, nullptr),
            NW_ERR_INVALID_ARG);                                                                 // lddx < c
+    // the pools
+    unsigned char* TAP = reinterpret_cast<unsigned char*>(F);
+    EXPECT(nw_avgpool2x2_nhwc_f32(F, 0, F, 0, 2, 8, 8, 6, nullptr), NW_ERR_INVALID_ARG);            // c % 4
+    EXPECT(nw_avgpool2x2_nhwc_f32(F, 0, F, 0, 2, 1, 8, 8, nullptr), NW_ERR_INVALID_ARG);            // no 2 x 2 window
+    EXPECT(nw_avgpool2x2_nhwc_f32(F, 4, F, 0, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);            // ldx < c
+    EXPECT(nw_avgpool2x2_nhwc_f32(nullptr, 0, F, 0, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_avgpool2x2_nhwc_f32(nullptr, 0, nullptr, 0, 0, 8, 8, 8, nullptr), NW_OK);            // empty batch
+    EXPECT(nw_avgpool2x2_nhwc_bwd_f32(F, 0, F, 6, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);        // ldgx < c
+    EXPECT(nw_avgpool2x2_nhwc_bwd_f32(F, 0, nullptr, 0, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_maxpool3x3s2_nhwc_f32(F, 0, F, 0, nullptr, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG); // no tap buffer
+    EXPECT(nw_maxpool3x3s2_nhwc_f32(F, 0, F, 10, TAP, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);    // ldy % 4
+    EXPECT(nw_maxpool3x3s2_nhwc_f32(F, 0, F, 0, TAP, 2, 0, 8, 8, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_maxpool3x3s2_nhwc_bwd_f32(F, 0, nullptr, F, 0, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_maxpool3x3s2_nhwc_bwd_f32(F, 0, TAP, F, 0, -1, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);
     std::printf(failures ? "abi_args: %d FAILED\n" : "abi_args: all argument checks refused as documented\n", failures);
     return failures ? 1 : 0;
 }
