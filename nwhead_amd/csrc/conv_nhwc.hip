@@ -55,6 +55,7 @@ struct ConvP {
     int ldx, ldy;            // floats between consecutive pixels of x / y (>= Cin / Cout: a channel window of a wider tensor)
     int IP, IMG;             // virtual raster of PATCH mode: row stride W + pad, image stride (H + pad) IP
     int M, mtiles, ntiles;
+    int macc;                // moments: ONE group per (workgroup, wave row), merged over the workgroup's tiles (ntiles == 1)
 };
 
 constexpr int CV_GATHER = 0, CV_PATCH = 1, CV_ROWRUN = 2, CV_ROWRUN4 = 3;
@@ -146,6 +147,13 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     const int ntile = tbeg < tend ? (tend - tbeg + nslot - 1) / nslot : 0;
     if (ntile == 0) {
         if (p.amax_out && tid == 0) amax_write(p.amax_out, 0.f, blockIdx.x, gridDim.x);
+        if (p.moments && p.macc) {                                 // its groups exist and are empty
+            const int G = gridDim.x * WN;
+            for (int k = tid; k < 3 * WN * p.Cout; k += 512) {
+                const int w3 = k / p.Cout, c = k - w3 * p.Cout;    // (statistic, wave row)
+                p.moments[((size_t)(w3 / WN) * G + blockIdx.x * WN + w3 % WN) * p.Cout + c] = 0.f;
+            }
+        }
         return;
     }
     const int S = ntile * ST;                                      // stages of this workgroup
@@ -464,6 +472,12 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
 #else
 #define NW_CBAR() tile_barrier()
 #endif
+    // moments of everything this wave row has written so far (p.macc): Chan's merge, tile by tile, in registers
+    float rcnt = 0.f, rmean[NA][4], rm2[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rmean[a][e] = rm2[a][e] = 0.f;
     __builtin_amdgcn_s_barrier();                                  // the prologue's stages have landed
     NW_CSTAMP(0);                                                  // wait for the pipeline fill
     for (int tl = 0; tl < ntile; ++tl) {
@@ -614,6 +628,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 return x;
             };
             const int G = p.mtiles * WN, grp = mt * WN + wave / WM;
+            const float ntot = rcnt + cnt, wt = ntot > 0.f ? cnt / ntot : 0.f;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 float mean[4], m2[4];
@@ -631,13 +646,21 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     }
                     m2[e] = rowsum(q);
                 }
-                if (i == 0) {
+                if (p.macc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = mean[e] - rmean[a][e];
+                        rmean[a][e] = __builtin_fmaf(d, wt, rmean[a][e]);
+                        rm2[a][e] += __builtin_fmaf(d * d, rcnt * wt, m2[e]);
+                    }
+                } else if (i == 0) {
                     const int co = co0 + wco + 16 * a + 4 * g;
                     *reinterpret_cast<float4*>(p.moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(cnt, cnt, cnt, cnt);
                     *reinterpret_cast<float4*>(p.moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(mean[0], mean[1], mean[2], mean[3]);
                     *reinterpret_cast<float4*>(p.moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(m2[0], m2[1], m2[2], m2[3]);
                 }
             }
+            if (p.macc) rcnt = ntot;
         }
         if (p.bnb_part) {
             // y = dL/d relu(bn(x)): sum g and sum g xhat over this wave's pixel rows, g = y where the forward's own
@@ -696,6 +719,16 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         nw_conv_diag[16 * blockIdx.x + 14] = cl_ - cf_;
     }
 #endif
+    if (p.moments && p.macc && i == 0) {
+        const int G = gridDim.x * WN, grp = blockIdx.x * WN + wave / WM;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int co = wco + 16 * a + 4 * g;                   // (ntiles == 1: the tile starts at channel 0)
+            *reinterpret_cast<float4*>(p.moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rcnt, rcnt, rcnt, rcnt);
+            *reinterpret_cast<float4*>(p.moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rmean[a][0], rmean[a][1], rmean[a][2], rmean[a][3]);
+            *reinterpret_cast<float4*>(p.moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
+        }
+    }
     // this workgroup's maximum -> its slot of the output's amax record (no atomics, nothing to clear beforehand)
     amax = wave_max(amax);
     float* red = reinterpret_cast<float*>(smem);
@@ -776,14 +809,17 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
     using C = ConvCfg<NA, NB, WM, MODE>;
     p.mtiles = (p.M + C::BM - 1) / C::BM;
     p.ntiles = p.Cout / C::BN;
-    if (moments_groups) *moments_groups = (int64_t)p.mtiles * C::WN;
-    if (dry) return NW_OK;
     const int64_t total = (int64_t)p.mtiles * p.ntiles;
     int64_t grid = num_cus() < CV_AMAX_SLOTS ? num_cus() : CV_AMAX_SLOTS;
     const int cap = knob(KNOB_CONV_MAX_WGS);   // tests: many tiles per workgroup (diagnostic knob "conv_max_wgs")
     if (cap > 0 && grid > cap) grid = cap;
     if (grid > total) grid = total;
     grid = (grid + 7) / 8 * 8;
+    // one output-channel tile: a workgroup's tiles are all rows of the same channels, and their moments are merged in its
+    // registers -- grid x WN groups for the merge kernel instead of mtiles x WN (2058 -> 512 on the 56 x 56 layers)
+    p.macc = p.ntiles == 1 && knob(KNOB_CONV_MOMENTS_PER_TILE) <= 0;
+    if (moments_groups) *moments_groups = (p.macc ? grid : (int64_t)p.mtiles) * C::WN;
+    if (dry) return NW_OK;
     auto kern = nw_conv_nhwc_kernel<NA, NB, WM, MODE>;
     static const bool attr = [&] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess;

@@ -85,7 +85,10 @@ def test_conv2d_nhwc_many_tiles_per_workgroup():
             "for case in t.CONV_CASES:\n"
             "    y, ref = t._conv_case(dev, ops, case, seed=5)\n"
             "    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()\n"
-            "    assert err < t.TOL, (case, err)\nprint('OK')\n" % (ROOT, ROOT))
+            "    assert err < t.TOL, (case, err)\n"
+            "for args in t.MOMENT_CASES:\n"          # a workgroup's tiles merged into one moments group each (Chan, in registers)
+            "    t.test_conv_channel_windows_and_moments(dev, *args)\n"
+            "print('OK')\n" % (ROOT, ROOT))
     env = dict(os.environ, NW_CONV_MAX_WGS="8")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
@@ -359,9 +362,12 @@ def test_training_forward_sees_a_fused_optimizer_step(dev):
     assert (before.detach() - ref).abs().max().item() > 1e-2 * sc     # the step did move the features
 
 
-@pytest.mark.parametrize("n,cin,h,w,cout,k,xw,yw", [(3, 64, 14, 14, 128, 1, 96, 0), (2, 128, 28, 28, 32, 3, 0, 96),
-                                                    (2, 32, 14, 14, 128, 3, 160, 0), (5, 128, 7, 7, 32, 3, 0, 864),
-                                                    (2, 128, 56, 56, 128, 1, 0, 0)])
+MOMENT_CASES = [(3, 64, 14, 14, 128, 1, 96, 0), (2, 128, 28, 28, 32, 3, 0, 96), (2, 32, 14, 14, 128, 3, 160, 0),
+                (5, 128, 7, 7, 32, 3, 0, 864), (2, 128, 56, 56, 128, 1, 0, 0), (9, 96, 56, 56, 128, 1, 0, 0),
+                (3, 64, 28, 28, 256, 1, 0, 0)]      # (the last: two output-channel tiles, moments per tile)
+
+
+@pytest.mark.parametrize("n,cin,h,w,cout,k,xw,yw", MOMENT_CASES)
 def test_conv_channel_windows_and_moments(dev, n, cin, h, w, cout, k, xw, yw):
     """nw_conv2d_nhwc_f16x2 with ldx / ldy: the input is a channel window of a wider channels-last tensor, the output is
     written into a window of another (the rest of which must stay untouched); `moments`: the groups it leaves merge
