@@ -148,6 +148,55 @@ def test_conv_weight_gradient_against_torch_fp64(dev, n, cin, h, w, cout, k):
     assert torch.equal(dw, dw2)                            # chunk sums added in a fixed order
 
 
+def test_batched_weight_gradients_equal_the_single_calls(dev):
+    """nw_conv2d_nhwc_wgrad_batch_f16x2: 3x3 and 1x1 problems of different sizes in one call -- operands that are channel
+    windows of wider tensors (ldx / ldg), both output layouts (out_oihw) -- against fp64; repeatable bit for bit; a batch
+    with one unsupported job is refused as a whole and launches nothing."""
+    import ctypes
+    from nwhead_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    specs = [(3, 160, 14, 14, 128, 1, 32, 0, 0), (3, 128, 14, 14, 32, 3, 0, 96, 1), (5, 128, 7, 7, 32, 3, 0, 0, 0),
+             (2, 64, 28, 28, 128, 1, 0, 0, 1), (2, 128, 28, 28, 32, 3, 64, 32, 1), (4, 224, 7, 7, 128, 1, 0, 0, 0)]
+    keep, jobs, outs, refs = [], [], [], []
+    for n, cin, h, w, cout, k, xw, gw, oihw in specs:
+        wx = _cl((torch.randn(n, cin + xw, h, w, generator=g) + 0.2).to(dev))
+        wg = _cl(torch.randn(n, cout + gw, h, w, generator=g).to(dev))
+        x, gy = wx[:, xw:], wg[:, :cout]                       # windows: not at channel 0 / a prefix
+        ax, ag = ops.absmax(wx), ops.absmax(wg)
+        dw = torch.full((cout, cin, k, k) if oihw else (cout, k, k, cin), float("nan"), device=dev)
+        pad = (k - 1) // 2
+        jobs.append(_lib.WgradJob(x.data_ptr(), ax.data_ptr(), gy.data_ptr(), ag.data_ptr(), dw.data_ptr(), n, h, w, cin, cout, k, k,
+                                  1, pad, cin + xw, cout + gw, oihw))
+        keep += [wx, wg, ax, ag]
+        outs.append(dw if oihw else dw.permute(0, 3, 1, 2))
+        refs.append(torch.ops.aten.convolution_backward(gy.double().contiguous(), x.double().contiguous(),
+                                                        torch.empty(cout, cin, k, k, dtype=torch.float64, device=dev), None, [1, 1],
+                                                        [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1])
+    arr = (_lib.WgradJob * len(jobs))(*jobs)
+    wsb = lib.nw_conv2d_nhwc_wgrad_batch_workspace_bytes(arr, len(jobs))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    st = ops._stream(keep[0])
+    assert lib.nw_conv2d_nhwc_wgrad_batch_f16x2(arr, len(jobs), ws.data_ptr(), wsb, st) == 0
+    first = [o.clone() for o in outs]
+    for o, r in zip(outs, refs):
+        assert (o.double() - r).abs().max().item() / r.abs().max().item() < TOL
+    assert lib.nw_conv2d_nhwc_wgrad_batch_f16x2(arr, len(jobs), ws.data_ptr(), wsb, st) == 0
+    assert all(torch.equal(a, b) for a, b in zip(first, outs))
+    # too small a workspace; then one job the kernels do not serve (stride 2): refused as a whole, outputs untouched
+    assert lib.nw_conv2d_nhwc_wgrad_batch_f16x2(arr, len(jobs), ws.data_ptr(), max(wsb - 16, 0), st) != 0 or wsb == 0
+    for o in outs:
+        o.fill_(-3.0)
+    bad = list(jobs)
+    j = bad[2]
+    bad[2] = _lib.WgradJob(j.x, j.amax_x, j.gy, j.amax_g, j.dw, j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, 2, j.pad, j.ldx, j.ldg, 0)
+    arr2 = (_lib.WgradJob * len(bad))(*bad)
+    assert lib.nw_conv2d_nhwc_wgrad_batch_f16x2(arr2, len(bad), ws.data_ptr(), wsb, st) != 0
+    torch.cuda.synchronize()
+    assert all(bool((o == -3.0).all()) for o in outs)
+    assert lib.nw_conv2d_nhwc_wgrad_batch_f16x2(arr, 0, None, 0, st) == 0          # an empty batch is a no-op
+
+
 @pytest.mark.parametrize("n,cin,h,w,cout,k,stride,pad", [(3, 64, 14, 14, 128, 1, 1, 0), (2, 128, 28, 28, 32, 3, 1, 1),
                                                          (2, 160, 14, 14, 128, 1, 1, 0), (2, 64, 28, 28, 128, 3, 2, 1),
                                                          (2, 3, 32, 32, 64, 7, 2, 3)])
