@@ -497,7 +497,7 @@ int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, 
  * is dropped) and the 3 x 3 / 2 pad 1 max pool of the stems (model/densenet.py:114, model/resnet.py:147; torch's scan:
  * a later value of the window wins when it is greater or NaN).  x (n, h, w, c), c % 4 == 0, rows may be strided (ld* >= c
  * floats, 0: dense): a pool can read from / write into a channel prefix of a wider NHWC tensor.  The max pool leaves the
- * winning tap (ky * 3 + kx) of every output value in `tap` ((n, ho, wo, c) bytes, dense), which is all its backward needs
+ * winning tap (ky * 3 + kx) of every output value in `tap` ((n, ho, wo, c) bytes, dense; nullable: inference), which is all its backward needs
  * beside gy; both backwards are gathers over the input pixels (no atomics, deterministic) and write every value of gx.
  * ------------------------------------------------------------------------------------------- */
 int nw_avgpool2x2_nhwc_f32(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n, int64_t h, int64_t w, int64_t c,

@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void nw_maxpool3s2_nhwc_kernel(const float* __
             }
         }
         *reinterpret_cast<float4*>(y + p * ldy + c) = make_float4(best[0], best[1], best[2], best[3]);
-        *reinterpret_cast<uchar4*>(tap + p * C + c) = make_uchar4((unsigned char)arg[0], (unsigned char)arg[1], (unsigned char)arg[2],
-                                                                  (unsigned char)arg[3]);
+        if (tap)
+            *reinterpret_cast<uchar4*>(tap + p * C + c) = make_uchar4((unsigned char)arg[0], (unsigned char)arg[1], (unsigned char)arg[2],
+                                                                      (unsigned char)arg[3]);
     }
 }
 
@@ -168,7 +169,7 @@ extern "C" int nw_maxpool3x3s2_nhwc_f32(const float* x, int64_t ldx, float* y, i
     if (ldy == 0) ldy = c;
     if (ldx < c || ldx % 4 || ldy < c || ldy % 4) return NW_ERR_INVALID_ARG;
     if (n == 0) return NW_OK;
-    if (!x || !y || !tap || misaligned(x) || misaligned(y) || (reinterpret_cast<uintptr_t>(tap) & 3)) return NW_ERR_INVALID_ARG;
+    if (!x || !y || misaligned(x) || misaligned(y) || (reinterpret_cast<uintptr_t>(tap) & 3)) return NW_ERR_INVALID_ARG;
     const int Ho = (int)((h - 1) / 2 + 1), Wo = (int)((w - 1) / 2 + 1), q4 = (int)(c / 4);   // floor((h + 2 - 3) / 2) + 1
     const int64_t total = n * Ho * Wo * q4;
     hipLaunchKernelGGL(nw_maxpool3s2_nhwc_kernel, dim3(pool_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, y, ldy,

@@ -114,9 +114,14 @@ class ResNet(nn.Module):
     def forward(self, x):
         if isinstance(self.conv1, ConvBiasAct):      # folded inference copy
             y = self.conv1(x, relu=True)
-            x = self.maxpool(y)
-            if hasattr(y, "nw_amax"):               # a bound on max|.| survives the pooling: the next convolution needs it
-                x.nw_amax = y.nw_amax
+            if (y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and _is_pool(self.maxpool, nn.MaxPool2d, 3, 2, 1)
+                    and y.is_contiguous(memory_format=torch.channels_last) and not torch.is_grad_enabled()):
+                from .. import ops
+                x = ops.maxpool3s2_nhwc(y)          # (keeps y's amax bound: the next convolution needs it)
+            else:
+                x = self.maxpool(y)
+                if hasattr(y, "nw_amax"):           # a bound on max|.| survives the pooling
+                    x.nw_amax = y.nw_amax
         else:
             x = self.maxpool(_bn_relu(self.bn1, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))

@@ -1107,7 +1107,15 @@ def maxpool3s2_nhwc(x, room=0):
     _need_hip(x)
     if x.dim() != 4 or x.shape[1] % 4:
         raise ValueError(f"maxpool3s2_nhwc needs (n, c % 4 == 0, h, w), got {tuple(x.shape)}")
-    y = _MaxPool3s2NhwcFn.apply(x, int(room))
+    if not (torch.is_grad_enabled() and x.requires_grad):       # inference: no tap record
+        xv, ldx = _nhwc_rows(x.detach())
+        n, c, h, w = xv.shape
+        y, ldy = _with_room(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, int(room), xv.device)
+        with _OnDevice(xv.device):
+            _lib.check(_lib.load().nw_maxpool3x3s2_nhwc_f32(_ptr(xv), ldx, _ptr(y), ldy, None, n, h, w, c, _stream(xv)),
+                       "nw_maxpool3x3s2_nhwc_f32")
+    else:
+        y = _MaxPool3s2NhwcFn.apply(x, int(room))
     if hasattr(x, "nw_amax"):
         y.nw_amax = x.nw_amax
     return y

@@ -216,7 +216,7 @@ int main() {
     EXPECT(nw_avgpool2x2_nhwc_f32(nullptr, 0, nullptr, 0, 0, 8, 8, 8, nullptr), NW_OK);            // empty batch
     EXPECT(nw_avgpool2x2_nhwc_bwd_f32(F, 0, F, 6, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);        // ldgx < c
     EXPECT(nw_avgpool2x2_nhwc_bwd_f32(F, 0, nullptr, 0, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);
-    EXPECT(nw_maxpool3x3s2_nhwc_f32(F, 0, F, 0, nullptr, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG); // no tap buffer
+    EXPECT(nw_maxpool3x3s2_nhwc_f32(F, 0, F, 0, TAP + 1, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG); // tap buffer not 4-byte aligned
     EXPECT(nw_maxpool3x3s2_nhwc_f32(F, 0, F, 10, TAP, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);    // ldy % 4
     EXPECT(nw_maxpool3x3s2_nhwc_f32(F, 0, F, 0, TAP, 2, 0, 8, 8, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_maxpool3x3s2_nhwc_bwd_f32(F, 0, nullptr, F, 0, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);

@@ -305,6 +305,9 @@ def test_pools_nhwc_against_torch(dev, n, c, h, w, prefix):
         assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
         assert torch.equal(torch.nan_to_num(y, nan=123.0), torch.nan_to_num(yr, nan=123.0)), name
         assert torch.equal(y.isnan(), yr.isnan())
+        with torch.no_grad():                                      # the inference path (the max pool: no tap record)
+            yi = mine(full[:, :c])
+        assert torch.equal(torch.nan_to_num(yi, nan=123.0), torch.nan_to_num(yr.detach(), nan=123.0)), name
         t = _cl(torch.randn(y.shape, generator=g).to(dev))
         y.backward(t); yr.backward(t)
         if name == "avg":

@@ -9,8 +9,17 @@ os.makedirs("profiles", exist_ok=True)
 def kname(full):
     m = re.search(r"(nw_[a-z_0-9]+(<[^>]*>)?)", full)
     return m.group(1) if m else full[:80]
+def newest(pattern):
+    """gpurun merges a run's files INTO the directory of an earlier run with the same tag: per leaf directory of `src`
+    (trace, pmc1, pmc2, ...) only the most recent file counts."""
+    by_dir = collections.defaultdict(list)
+    for f in glob.glob(pattern, recursive=True):
+        by_dir[os.path.relpath(f, src).split(os.sep)[0]].append(f)
+    return [max(fs, key=os.path.getmtime) for fs in by_dir.values()]
+
+
 stats = []
-for f in glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True):
+for f in newest(src + "/trace/**/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         stats.append({"kernel": kname(r["Name"]), "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                       "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])})
@@ -19,7 +28,7 @@ with open(f"profiles/{name}_stats.csv", "w") as fh:
     w = csv.DictWriter(fh, fieldnames=list(stats[0].keys())); w.writeheader(); w.writerows(stats)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(dict)     # kernel -> {(pass file, dispatch id): microseconds}: the dispatch durations INSIDE the PMC passes
-for f in glob.glob(src + "/pmc*/**/*counter_collection.csv", recursive=True):
+for f in newest(src + "/pmc*/**/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r.get("Start_Timestamp") and r.get("End_Timestamp"):
@@ -68,7 +77,7 @@ with open(f"profiles/{name}_summary.md", "w") as fh:
         fh.write(f"| `{r['kernel']}` | {r['calls']} | {r['avg_us']:.2f} | {r['min_us']:.2f} | {r['max_us']:.2f} | {r['pct']:.1f} |\n")
     # the dominant kernel launch by launch: after an idle period the clocks ramp for ~40 launches,
     # so the all-launch average above sits above the steady state bench.py's timed region runs in
-    for f in glob.glob(src + "/trace/**/*kernel_trace.csv", recursive=True):
+    for f in newest(src + "/trace/**/*kernel_trace.csv"):
         rows = [r for r in csv.DictReader(open(f)) if kname(r["Kernel_Name"]) == stats[0]["kernel"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
