@@ -32,6 +32,8 @@ CONV_CASES = [
     (3, 64, 9, 7, 64, 3, 1, 1, True, True, True),          # PATCH, tiles crossing rows and images, ragged tail
     (2, 64, 56, 56, 64, 3, 1, 1, True, True, True),        # ResNet layer1
     (4, 128, 28, 28, 128, 3, 1, 1, True, True, True),      # layer2, 128 x 128 tiles
+    (16, 64, 56, 56, 64, 3, 1, 1, True, True, True),       # enough pixels for the 256 x 64 tiles (PATCH)
+    (17, 96, 56, 56, 64, 1, 1, 0, True, False, True),      # ... and through GATHER, ragged last tile
     (9, 512, 7, 7, 512, 3, 1, 1, True, True, True),        # layer4: K = 4608
     (3, 128, 56, 56, 32, 3, 1, 1, False, False, False),    # DenseNet conv2
     (2, 64, 56, 56, 128, 1, 1, 0, True, False, True),      # GATHER: 1x1
