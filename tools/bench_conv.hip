@@ -7,7 +7,12 @@
 #include <vector>
 #include <algorithm>
 #include "nw_internal.h"
-namespace nw { int knob(int) { return KNOB_UNSET; } }
+namespace nw {   // the library's knobs from the environment here: NW_CONV_SKIP_CFGS=n passes over the first n fitting tile shapes
+int knob(int id) {
+    const char* e = id == KNOB_CONV_SKIP_CFGS ? getenv("NW_CONV_SKIP_CFGS") : nullptr;
+    return e ? atoi(e) : KNOB_UNSET;
+}
+}
 #include "conv_nhwc.hip"
 int main(int argc, char** argv) {
     if (argc < 7) { std::printf("usage: bench_conv n cin h w cout k [pad]\n"); return 1; }
