@@ -27,6 +27,6 @@ for fmt in (torch.contiguous_format,):
         loss = F.nll_loss(head(feats[:32], feats[32:], ys), yq)
         loss.backward()
         opt.step()
-    t = bench.time_kernel_events(k4, 5, warmup=3)
-    print(arch, fmt, f"{t*1e3:.2f} ms/step", flush=True)
+    ts = sorted(bench.time_kernel_events(k4, 5, warmup=3 if r == 0 else 0) for r in range(int(os.environ.get("NW_K4_REPEATS", "5"))))
+    print(arch, fmt, f"{ts[0]*1e3:.2f} ms/step (best of {len(ts)} x 5 steps; median {ts[len(ts)//2]*1e3:.2f}, worst {ts[-1]*1e3:.2f})", flush=True)
     del dn, opt
