@@ -319,7 +319,8 @@ def measure_backbone_configs(dev):
             loss = F.nll_loss(head(feats[:32], feats[32:], ys), yq)
             loss.backward()
             opt.step()
-        t = time_kernel_events(k4, 8, warmup=10)
+        runs4 = sorted(time_kernel_events(k4, 8, warmup=10 if r == 0 else 0) for r in range(5))
+        t = runs4[2]                                          # median of five runs of 8 steps (a shared host is noisy)
         gf4 = 5.67 * 3 * 42                                   # GFLOP, DenseNet-121 fwd+bwd over 32 + 10 images @224
         import nwhead_amd.model.backbones as BB
         t_nchw = None
@@ -330,6 +331,7 @@ def measure_backbone_configs(dev):
             finally:
                 BB.NHWC_TRAINING = True
         out["config_K4_densenet121_train_step"] = {"B": 32, "n_way": 10, "n_shot": 1, "ms_per_step": t * 1e3,
+                                                   "ms_per_step_runs": [round(r * 1e3, 3) for r in runs4],
                                                    "backbone": "channels-last: nw_conv2d_nhwc_f16x2 / nw_conv2d_nhwc_wgrad_f16x2 "
                                                                "(split-fp16 MFMA, fp32-grade) + nw_bn_relu_nhwc_train_*"
                                                                if BB.NHWC_TRAINING else "torch/MIOpen fp32 (NCHW)",
