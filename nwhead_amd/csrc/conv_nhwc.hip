@@ -147,11 +147,12 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     const int ntile = tbeg < tend ? (tend - tbeg + nslot - 1) / nslot : 0;
     if (ntile == 0) {
         if (p.amax_out && tid == 0) amax_write(p.amax_out, 0.f, blockIdx.x, gridDim.x);
-        if (p.moments && p.macc) {                                 // its groups exist and are empty
-            const int G = gridDim.x * WN;
-            for (int k = tid; k < 3 * WN * p.Cout; k += 512) {
+        if ((p.moments || p.bnb_part) && p.macc) {                 // its groups exist and are empty
+            const int G = gridDim.x * WN, nstat = p.moments ? 3 : 2;
+            float* dst = p.moments ? p.moments : p.bnb_part;
+            for (int k = tid; k < nstat * WN * p.Cout; k += 512) {
                 const int w3 = k / p.Cout, c = k - w3 * p.Cout;    // (statistic, wave row)
-                p.moments[((size_t)(w3 / WN) * G + blockIdx.x * WN + w3 % WN) * p.Cout + c] = 0.f;
+                dst[((size_t)(w3 / WN) * G + blockIdx.x * WN + w3 % WN) * p.Cout + c] = 0.f;
             }
         }
         return;
@@ -582,6 +583,18 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         }
         sg += ST;
         qg += CH;
+        // (bnb_part: the x values its sums need are requested before the stores, in the registers the fragments left: their
+        //  latency passes behind the store loop and the moments)
+        float4 x4[NA][NB];
+        if (p.bnb_part) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int m = min(m0 + wpx + 16 * b + i, p.M - 1);
+                    x4[a][b] = *reinterpret_cast<const float4*>(p.bnb_x + (size_t)m * p.bnb_ldx + (co0 + wco + 16 * a + 4 * g));
+                }
+        }
         // ---- store: acc[a][b][e] of lane (i, g) = y[pixel m0 + wpx + 16 b + i][channel co0 + wco + 16 a + 4 g + e]
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
@@ -673,15 +686,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 return x;
             };
             const int G = p.mtiles * WN, grp = mt * WN + wave / WM;
-            // every x value first (rows past the end clamped: their g is zeroed below), so that the loads fly together
-            float4 x4[NA][NB];
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int m = min(m0 + wpx + 16 * b + i, p.M - 1);
-                    x4[a][b] = *reinterpret_cast<const float4*>(p.bnb_x + (size_t)m * p.bnb_ldx + (co0 + wco + 16 * a + 4 * g));
-                }
+            // (x4: requested in front of the stores; rows past the end clamped, their g is zeroed below)
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const int co = co0 + wco + 16 * a + 4 * g;
@@ -705,7 +710,10 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s1[e] = rowsum(s1[e]); s2[e] = rowsum(s2[e]); }
-                if (i == 0) {
+                if (p.macc) {                                      // one group per workgroup and wave row (rmean / rm2 are free:
+#pragma unroll                                                     //  the moments and these sums have separate entry points)
+                    for (int e = 0; e < 4; ++e) { rmean[a][e] += s1[e]; rm2[a][e] += s2[e]; }
+                } else if (i == 0) {
                     *reinterpret_cast<float4*>(p.bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(s1[0], s1[1], s1[2], s1[3]);
                     *reinterpret_cast<float4*>(p.bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(s2[0], s2[1], s2[2], s2[3]);
                 }
@@ -719,6 +727,15 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         nw_conv_diag[16 * blockIdx.x + 14] = cl_ - cf_;
     }
 #endif
+    if (p.bnb_part && p.macc && i == 0) {
+        const int G = gridDim.x * WN, grp = blockIdx.x * WN + wave / WM;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int co = wco + 16 * a + 4 * g;
+            *reinterpret_cast<float4*>(p.bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rmean[a][0], rmean[a][1], rmean[a][2], rmean[a][3]);
+            *reinterpret_cast<float4*>(p.bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
+        }
+    }
     if (p.moments && p.macc && i == 0) {
         const int G = gridDim.x * WN, grp = blockIdx.x * WN + wave / WM;
 #pragma unroll

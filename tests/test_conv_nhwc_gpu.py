@@ -90,6 +90,8 @@ def test_conv2d_nhwc_many_tiles_per_workgroup():
             "    assert err < t.TOL, (case, err)\n"
             "for args in t.MOMENT_CASES:\n"          # a workgroup's tiles merged into one moments group each (Chan, in registers)
             "    t.test_conv_channel_windows_and_moments(dev, *args)\n"
+            "for flag in (False, True):\n"            # ... and the backward sums of the data gradients' epilogues
+            "    t.test_dense_block_slab_node_against_layer_by_layer(dev, flag)\n"
             "print('OK')\n" % (ROOT, ROOT))
     env = dict(os.environ, NW_CONV_MAX_WGS="8")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
