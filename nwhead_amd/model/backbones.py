@@ -153,6 +153,8 @@ FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.b
 NHWC_TRAINING = _os.environ.get("NW_NHWC_TRAINING", "1") != "0"
 # a dense block of the channels-last training path as one autograd node over one slab (ops._DenseBlockNhwcFn)
 DENSE_SLAB = _os.environ.get("NW_DENSE_SLAB", "1") != "0"
+# a transition of that path as BatchNorm-ReLU -> 2x2 average pool -> 1x1 convolution (pool and convolution commute)
+TRANSITION_POOL_FIRST = _os.environ.get("NW_TRANSITION_POOL_FIRST", "1") != "0"
 
 
 def _fused_training(bn, x):
@@ -400,9 +402,17 @@ class DenseNet(nn.Module):
             if isinstance(mod, _DenseBlock):
                 y = mod.forward_nhwc_train(y, bank)
             elif isinstance(mod, _Transition):
-                z = ops.conv2d_nhwc_train(ops.bn_relu_train_nhwc(y, mod.norm), mod.conv.weight, 1, 0,
-                                          operands=bank.operands(mod.conv.weight))
-                y = ops.avgpool2_nhwc(z, room(i)) if _is_pool(mod.pool, nn.AvgPool2d, 2, 2, 0) else mod.pool(z)
+                t = ops.bn_relu_train_nhwc(y, mod.norm)
+                if TRANSITION_POOL_FIRST and _is_pool(mod.pool, nn.AvgPool2d, 2, 2, 0) and mod.conv.bias is None \
+                        and t.shape[2] % 2 == 0 and t.shape[3] % 2 == 0:
+                    # the 2 x 2 average and the bias-free 1 x 1 convolution commute (both linear, per pixel / per channel):
+                    # pooled first, the convolution and both of its gradients work on a quarter of the pixels
+                    # (densenet.py:83-91 runs conv -> pool; the values differ by fp32 rounding only)
+                    y = ops.conv2d_nhwc_train(ops.avgpool2_nhwc(t), mod.conv.weight, 1, 0, operands=bank.operands(mod.conv.weight),
+                                              room=room(i))
+                else:
+                    z = ops.conv2d_nhwc_train(t, mod.conv.weight, 1, 0, operands=bank.operands(mod.conv.weight))
+                    y = ops.avgpool2_nhwc(z, room(i)) if _is_pool(mod.pool, nn.AvgPool2d, 2, 2, 0) else mod.pool(z)
         y = ops.bn_relu_train_nhwc(y, f.norm5)          # (norm5 + the relu of DenseNet.forward)
         return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
 

@@ -876,11 +876,11 @@ def conv2d_nhwc_supported(x_shape, w_shape, stride, pad):
     return cin == cin2 and bool(_lib.load().nw_conv2d_nhwc_supported(n, h, w, cin, cout, kh, kw, stride, pad))
 
 
-def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0, amax=None, want_amax=True):
+def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0, amax=None, want_amax=True, room=0):
     """y = post(conv2d(x, W, stride, pad) + bias [+ residual]) for a channels_last fp32 (n, Cin, H, W) HIP tensor and a
     SplitConvWeight; returns a channels_last (n, Cout, Ho, Wo) tensor.  `amax`: the amax record of x (AMAX_SLOTS floats
     whose maximum bounds max|x|; default: x.nw_amax when x came out of this function, else one absmax pass); the result
-    carries its own in `.nw_amax` when want_amax."""
+    carries its own in `.nw_amax` when want_amax.  room: channels to leave behind every pixel's Cout (_with_room)."""
     _need_hip(x, bias, residual)
     lib = _lib.load()
     n, cin, h, w = x.shape
@@ -897,7 +897,7 @@ def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0
         if amax is None:
             amax = absmax(x)
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    y, ldy = _with_room(n, cout, ho, wo, room, x.device)
     if residual is not None and (residual.shape != y.shape or residual.dtype != torch.float32
                                  or not residual.is_contiguous(memory_format=torch.channels_last)):
         residual = residual.float().expand_as(y).contiguous(memory_format=torch.channels_last)
@@ -905,8 +905,8 @@ def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0
     with _OnDevice(x.device):
         _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(x), _ptr(amax), _ptr(weight.split), _ptr(weight.scale),
                                             None if bias is None else _ptr(_f32c(bias)), _ptr(residual), int(bool(relu)),
-                                            _ptr(y), _ptr(am_out), n, h, w, cin, cout, kh, kw, int(stride), int(pad), 0, 0,
-                                            None, _stream(x)), "nw_conv2d_nhwc_f16x2")
+                                            _ptr(y), _ptr(am_out), n, h, w, cin, cout, kh, kw, int(stride), int(pad), 0,
+                                            ldy if room > 0 else 0, None, _stream(x)), "nw_conv2d_nhwc_f16x2")
     if want_amax:
         y.nw_amax = am_out
     return y
@@ -1098,7 +1098,10 @@ def avgpool2_nhwc(x, room=0):
     _need_hip(x)
     if x.dim() != 4 or x.shape[1] % 4 or x.shape[2] < 2 or x.shape[3] < 2:
         raise ValueError(f"avgpool2_nhwc needs (n, c % 4 == 0, h >= 2, w >= 2), got {tuple(x.shape)}")
-    return _AvgPool2NhwcFn.apply(x, int(room))
+    y = _AvgPool2NhwcFn.apply(x, int(room))
+    if hasattr(x, "nw_amax"):           # an average is no larger than the largest value averaged: x's bound holds for y
+        y.nw_amax = x.nw_amax
+    return y
 
 
 def maxpool3s2_nhwc(x, room=0):
@@ -1242,14 +1245,14 @@ class _ConvNhwcFn(torch.autograd.Function):
     weight and padding k - 1 - p), weight gradient through nw_conv2d_nhwc_wgrad_f16x2 when it serves the shape."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, amax, operands):
+    def forward(ctx, x, weight, stride, pad, amax, operands, room=0):
         xv = x.detach()
         if xv.dtype != torch.float32 or not xv.is_contiguous(memory_format=torch.channels_last):
             xv = xv.float().contiguous(memory_format=torch.channels_last)
         fw = operands[0] if operands is not None and operands[0] is not None else SplitConvWeight(weight)
         if amax is None and not (xv.shape[1] == 3 and fw.shape[1] == 4):   # (an RGB stem gets its record from the padding pass)
             amax = _amax_of(x)
-        y = conv2d_nhwc(xv, fw, None, None, False, stride, pad, amax=amax)
+        y = conv2d_nhwc(xv, fw, None, None, False, stride, pad, amax=amax, room=room)
         ctx.save_for_backward(xv, weight, amax if amax is not None else torch.empty(0, device=xv.device))
         ctx.stride, ctx.pad = stride, pad
         ctx.dgrad_operand = operands[1] if operands is not None else None
@@ -1293,7 +1296,7 @@ class _ConvNhwcFn(torch.autograd.Function):
             main.wait_stream(side)
         elif ctx.needs_input_grad[1]:
             dw = conv2d_nhwc_wgrad(xv, g, weight.shape, stride, pad, amax_x if amax_x.numel() else None, gam)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 def conv2d_nhwc_wgrad(x, gy, wshape, stride, pad, amax_x=None, amax_g=None):
@@ -1575,9 +1578,9 @@ def dense_block_nhwc_train(x, layers, bank):
     return _DenseBlockNhwcFn.apply(x, tuple(layers), bank, *params)
 
 
-def conv2d_nhwc_train(x, weight, stride=1, pad=0, amax=None, operands=None):
+def conv2d_nhwc_train(x, weight, stride=1, pad=0, amax=None, operands=None, room=0):
     """Differentiable conv2d(x, weight, stride=stride, padding=pad) for channels-last fp32 activations on the MI355X
     (bias-free: the backbones' convolutions have none).  x may carry `.nw_amax`; operands: ConvWeightBank.operands(weight)
     (else the weight is split inside the call, forward and backward)."""
     _need_hip(x, weight)
-    return _ConvNhwcFn.apply(x, weight, int(stride), int(pad), amax, operands)
+    return _ConvNhwcFn.apply(x, weight, int(stride), int(pad), amax, operands, int(room))
