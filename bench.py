@@ -305,8 +305,8 @@ def measure_backbone_configs(dev):
         out["config_K2_resnet18_plus_head"] = {"error": repr(e)[:200]}
     try:
         dn = load_model("densenet121").to(dev).train()
-        opt = torch.optim.SGD(dn.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4,
-                              fused=True)
+        from nwhead_amd.optim import SGD as _NWSGD
+        opt = _NWSGD(dn.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4)
         xq = torch.randn(32, 3, 224, 224, generator=g).to(dev)
         yq = torch.randint(0, 10, (32,), generator=g).to(dev)
         xs = torch.randn(10, 3, 224, 224, generator=g).to(dev)

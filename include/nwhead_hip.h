@@ -510,6 +510,23 @@ int nw_maxpool3x3s2_nhwc_bwd_f32(const float *gy, int64_t ldgy, const unsigned c
                                  int64_t h, int64_t w, int64_t c, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The optimizer step of the training harness (reference train.py:243-247: torch.optim.SGD(momentum 0.9, weight decay,
+ * nesterov)) for all parameter tensors of a network in a few launches (csrc/sgd.hip; 96 tensors per launch, their addresses
+ * in the kernel arguments).  Per element, torch's formula with dampening 0:
+ *   g = grad + weight_decay p;  buf = init_buf ? g : momentum buf + g;  p -= lr (nesterov ? g + momentum buf : buf)
+ * momentum == 0: no buffer is read or written (momentum_buf may be NULL).  init_buf != 0: the first step of these
+ * parameters (torch clones the gradient into the buffer).  fp32, any length; tensors 16-byte aligned take the vector path.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nw_sgd_param {
+    float *param;
+    const float *grad;
+    float *momentum_buf;
+    int64_t n;
+} nw_sgd_param;
+int nw_sgd_step_f32(const nw_sgd_param *params, int64_t nparams, float lr, float momentum, float weight_decay, int nesterov,
+                    int init_buf, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart): device time of the TILE kernel alone -- the kernel the
  * roofline is quoted on (nw_fused_kernel / nw_fused_f16p_kernel), without the small kernels around
  * it (query split, run tables, merge).  While enabled, every forward brackets its tile-kernel launch

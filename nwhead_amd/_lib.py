@@ -78,6 +78,7 @@ SIGNATURES = {
     "nw_avgpool2x2_nhwc_bwd_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "nw_maxpool3x3s2_nhwc_f32": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "nw_maxpool3x3s2_nhwc_bwd_f32": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "nw_sgd_step_f32": (_int, [_p, _i64, C.c_float, C.c_float, C.c_float, _int, _int, _p]),
     "nw_debug_set": (_int, [C.c_char_p, _int]),
     "nw_debug_tile_timing": (_int, [_int]),
     "nw_debug_tile_timing_read": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -119,6 +120,11 @@ class WgradJob(C.Structure):
     """nw_wgrad_job (include/nwhead_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("amax_x", C.c_void_p), ("gy", C.c_void_p), ("amax_g", C.c_void_p), ("dw", C.c_void_p)] + \
                [(k, C.c_int64) for k in ("n", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "ldx", "ldg", "out_oihw")]
+
+
+class SgdParam(C.Structure):
+    """nw_sgd_param (include/nwhead_hip.h)."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("n", C.c_int64)]
 
 
 class ConvBnStat(C.Structure):

@@ -221,6 +221,14 @@ int main() {
     EXPECT(nw_maxpool3x3s2_nhwc_f32(F, 0, F, 0, TAP, 2, 0, 8, 8, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_maxpool3x3s2_nhwc_bwd_f32(F, 0, nullptr, F, 0, 2, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);
     EXPECT(nw_maxpool3x3s2_nhwc_bwd_f32(F, 0, TAP, F, 0, -1, 8, 8, 8, nullptr), NW_ERR_INVALID_ARG);
+    // the optimizer step
+    nw_sgd_param sp[2] = {{F, F, F, 64}, {F, F, nullptr, 64}};
+    EXPECT(nw_sgd_step_f32(sp, 2, 0.1f, 0.9f, 1e-4f, 1, 0, nullptr), NW_ERR_INVALID_ARG);          // momentum without a buffer
+    EXPECT(nw_sgd_step_f32(sp, 1, 0.1f, 0.0f, 1e-4f, 1, 0, nullptr), NW_ERR_INVALID_ARG);          // nesterov without momentum
+    EXPECT(nw_sgd_step_f32(nullptr, 1, 0.1f, 0.9f, 0.f, 0, 0, nullptr), NW_ERR_INVALID_ARG);
+    EXPECT(nw_sgd_step_f32(nullptr, 0, 0.1f, 0.9f, 0.f, 0, 0, nullptr), NW_OK);
+    sp[0].n = -1;
+    EXPECT(nw_sgd_step_f32(sp, 1, 0.1f, 0.9f, 0.f, 0, 0, nullptr), NW_ERR_INVALID_ARG);
     std::printf(failures ? "abi_args: %d FAILED\n" : "abi_args: all argument checks refused as documented\n", failures);
     return failures ? 1 : 0;
 }

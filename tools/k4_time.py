@@ -14,8 +14,9 @@ g = torch.Generator().manual_seed(7)
 arch = sys.argv[1] if len(sys.argv) > 1 else "densenet121"
 for fmt in (torch.contiguous_format,):
     dn = load_model(arch).to(dev).train().to(memory_format=fmt)
-    opt = torch.optim.SGD(dn.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4,
-                              fused=os.environ.get("NW_SGD_FOREACH", "0") != "1")
+    opt = (torch.optim.SGD(dn.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4, fused=True)
+       if os.environ.get("NW_TORCH_SGD", "0") == "1" else
+       __import__("nwhead_amd.optim", fromlist=["SGD"]).SGD(dn.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4))
     xq = torch.randn(32, 3, 224, 224, generator=g).to(dev)
     yq = torch.randint(0, 10, (32,), generator=g).to(dev)
     xs = torch.randn(10, 3, 224, 224, generator=g).to(dev)
