@@ -121,8 +121,12 @@ __device__ unsigned long long nw_conv_diag[16 * 1024];
 #define NW_CSTAMP(k)
 #endif
 
-template <int NA, int NB, int WM, int MODE>
+// STATS = false: the instantiation for launches that leave neither moments nor BatchNorm backward sums (inference, data
+// gradients): none of that code and none of its running registers (their mere presence cost every convolution 1-5 %)
+template <int NA, int NB, int WM, int MODE, bool STATS>
 __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
+    float* const p_moments = STATS ? p.moments : nullptr;
+    float* const p_bnb_part = STATS ? p.bnb_part : nullptr;
     using C = ConvCfg<NA, NB, WM, MODE>;
     constexpr bool PATCH = C::PATCH, ROWRUN = C::ROWRUN;
     constexpr int BN = C::BN, BM = C::BM, NIW = C::NIW, NPASS = C::NPASS, NACT = C::NACT, TI = C::TI, NSET = C::NSET;
@@ -147,9 +151,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     const int ntile = tbeg < tend ? (tend - tbeg + nslot - 1) / nslot : 0;
     if (ntile == 0) {
         if (p.amax_out && tid == 0) amax_write(p.amax_out, 0.f, blockIdx.x, gridDim.x);
-        if ((p.moments || p.bnb_part) && p.macc) {                 // its groups exist and are empty
-            const int G = gridDim.x * WN, nstat = p.moments ? 3 : 2;
-            float* dst = p.moments ? p.moments : p.bnb_part;
+        if ((p_moments || p_bnb_part) && p.macc) {                 // its groups exist and are empty
+            const int G = gridDim.x * WN, nstat = p_moments ? 3 : 2;
+            float* dst = p_moments ? p_moments : p_bnb_part;
             for (int k = tid; k < nstat * WN * p.Cout; k += 512) {
                 const int w3 = k / p.Cout, c = k - w3 * p.Cout;    // (statistic, wave row)
                 dst[((size_t)(w3 / WN) * G + blockIdx.x * WN + w3 % WN) * p.Cout + c] = 0.f;
@@ -583,18 +587,6 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         }
         sg += ST;
         qg += CH;
-        // (bnb_part: the x values its sums need are requested before the stores, in the registers the fragments left: their
-        //  latency passes behind the store loop and the moments)
-        float4 x4[NA][NB];
-        if (p.bnb_part) {
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int m = min(m0 + wpx + 16 * b + i, p.M - 1);
-                    x4[a][b] = *reinterpret_cast<const float4*>(p.bnb_x + (size_t)m * p.bnb_ldx + (co0 + wco + 16 * a + 4 * g));
-                }
-        }
         // ---- store: acc[a][b][e] of lane (i, g) = y[pixel m0 + wpx + 16 b + i][channel co0 + wco + 16 a + 4 g + e]
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
@@ -626,7 +618,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 }
             }
         }
-        if (p.moments) {
+        if (p_moments) {
             // Welford moments of this wave's pixel rows [m0 + wpx, + 16 NB) per output channel, two passes over the values
             // still in registers (mean, then centred squares); the 16 lanes of a row hold 16 pixels of the same 4 channels:
             // summed by four DPP rotations.  One group per (tile row, wave row); merged with Chan's formula by the finalize
@@ -668,14 +660,14 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     }
                 } else if (i == 0) {
                     const int co = co0 + wco + 16 * a + 4 * g;
-                    *reinterpret_cast<float4*>(p.moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(cnt, cnt, cnt, cnt);
-                    *reinterpret_cast<float4*>(p.moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(mean[0], mean[1], mean[2], mean[3]);
-                    *reinterpret_cast<float4*>(p.moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(m2[0], m2[1], m2[2], m2[3]);
+                    *reinterpret_cast<float4*>(p_moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(cnt, cnt, cnt, cnt);
+                    *reinterpret_cast<float4*>(p_moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(mean[0], mean[1], mean[2], mean[3]);
+                    *reinterpret_cast<float4*>(p_moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(m2[0], m2[1], m2[2], m2[3]);
                 }
             }
             if (p.macc) rcnt = ntot;
         }
-        if (p.bnb_part) {
+        if (p_bnb_part) {
             // y = dL/d relu(bn(x)): sum g and sum g xhat over this wave's pixel rows, g = y where the forward's own
             // bn(x) = (x - mean) (gamma invstd) + beta was positive (the same expression nw_bn_nhwc_bwd_stats_kernel uses)
             auto rowsum = [](float x) {
@@ -686,7 +678,17 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 return x;
             };
             const int G = p.mtiles * WN, grp = mt * WN + wave / WM;
-            // (x4: requested in front of the stores; rows past the end clamped, their g is zeroed below)
+            // every x value first (rows past the end clamped: their g is zeroed below), so that the loads fly together.  (Requested
+            // in front of the store loop instead, their registers stay live across it in EVERY instantiation: all convolutions
+            // 4-5 % slower, K2 1.427 -> 1.494 ms.)
+            float4 x4[NA][NB];
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int m = min(m0 + wpx + 16 * b + i, p.M - 1);
+                    x4[a][b] = *reinterpret_cast<const float4*>(p.bnb_x + (size_t)m * p.bnb_ldx + (co0 + wco + 16 * a + 4 * g));
+                }
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const int co = co0 + wco + 16 * a + 4 * g;
@@ -714,8 +716,8 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
 #pragma unroll                                                     //  the moments and these sums have separate entry points)
                     for (int e = 0; e < 4; ++e) { rmean[a][e] += s1[e]; rm2[a][e] += s2[e]; }
                 } else if (i == 0) {
-                    *reinterpret_cast<float4*>(p.bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-                    *reinterpret_cast<float4*>(p.bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                    *reinterpret_cast<float4*>(p_bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                    *reinterpret_cast<float4*>(p_bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(s2[0], s2[1], s2[2], s2[3]);
                 }
             }
         }
@@ -727,23 +729,23 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         nw_conv_diag[16 * blockIdx.x + 14] = cl_ - cf_;
     }
 #endif
-    if (p.bnb_part && p.macc && i == 0) {
+    if (p_bnb_part && p.macc && i == 0) {
         const int G = gridDim.x * WN, grp = blockIdx.x * WN + wave / WM;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             const int co = wco + 16 * a + 4 * g;
-            *reinterpret_cast<float4*>(p.bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rmean[a][0], rmean[a][1], rmean[a][2], rmean[a][3]);
-            *reinterpret_cast<float4*>(p.bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
+            *reinterpret_cast<float4*>(p_bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rmean[a][0], rmean[a][1], rmean[a][2], rmean[a][3]);
+            *reinterpret_cast<float4*>(p_bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
         }
     }
-    if (p.moments && p.macc && i == 0) {
+    if (p_moments && p.macc && i == 0) {
         const int G = gridDim.x * WN, grp = blockIdx.x * WN + wave / WM;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             const int co = wco + 16 * a + 4 * g;                   // (ntiles == 1: the tile starts at channel 0)
-            *reinterpret_cast<float4*>(p.moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rcnt, rcnt, rcnt, rcnt);
-            *reinterpret_cast<float4*>(p.moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rmean[a][0], rmean[a][1], rmean[a][2], rmean[a][3]);
-            *reinterpret_cast<float4*>(p.moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
+            *reinterpret_cast<float4*>(p_moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rcnt, rcnt, rcnt, rcnt);
+            *reinterpret_cast<float4*>(p_moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rmean[a][0], rmean[a][1], rmean[a][2], rmean[a][3]);
+            *reinterpret_cast<float4*>(p_moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
         }
     }
     // this workgroup's maximum -> its slot of the output's amax record (no atomics, nothing to clear beforehand)
@@ -837,12 +839,15 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
     p.macc = p.ntiles == 1 && knob(KNOB_CONV_MOMENTS_PER_TILE) <= 0;
     if (moments_groups) *moments_groups = (p.macc ? grid : (int64_t)p.mtiles) * C::WN;
     if (dry) return NW_OK;
-    auto kern = nw_conv_nhwc_kernel<NA, NB, WM, MODE>;
+    auto kern0 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false>;
+    auto kern1 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, true>;
     static const bool attr = [&] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess;
     }();
     if (!attr) return NW_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS, st, p);
+    if (p.moments || p.bnb_part) hipLaunchKernelGGL(kern1, dim3((unsigned)grid), dim3(512), C::LDS, st, p);
+    else hipLaunchKernelGGL(kern0, dim3((unsigned)grid), dim3(512), C::LDS, st, p);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }
