@@ -123,10 +123,14 @@ __device__ unsigned long long nw_conv_diag[16 * 1024];
 
 // STATS = false: the instantiation for launches that leave neither moments nor BatchNorm backward sums (inference, data
 // gradients): none of that code and none of its running registers (their mere presence cost every convolution 1-5 %)
-template <int NA, int NB, int WM, int MODE, bool STATS>
+// POST = false: likewise without bias, identity and ReLU (the training path's convolutions have none of them)
+template <int NA, int NB, int WM, int MODE, bool STATS, bool POST>
 __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     float* const p_moments = STATS ? p.moments : nullptr;
     float* const p_bnb_part = STATS ? p.bnb_part : nullptr;
+    const float* const p_bias = POST ? p.bias : nullptr;
+    const float* const p_res = POST ? p.res : nullptr;
+    const int p_relu = POST ? p.relu : 0;
     using C = ConvCfg<NA, NB, WM, MODE>;
     constexpr bool PATCH = C::PATCH, ROWRUN = C::ROWRUN;
     constexpr int BN = C::BN, BM = C::BM, NIW = C::NIW, NPASS = C::NPASS, NACT = C::NACT, TI = C::TI, NSET = C::NSET;
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         for (int a = 0; a < NA; ++a) {
             const int co = co0 + wco + 16 * a + 4 * g;
             ws4[a] = *reinterpret_cast<const float4*>(p.wscale + co);
-            b4[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b4[a] = p_bias ? *reinterpret_cast<const float4*>(p_bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         Frag f0, f1;
         load_frags(f0, 0);
@@ -601,11 +605,11 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     v.z = __builtin_fmaf(acc[a][b][2], ws4[a].z * inv_up, b4[a].z);
                     v.w = __builtin_fmaf(acc[a][b][3], ws4[a].w * inv_up, b4[a].w);
                     const size_t o = (size_t)m * p.ldy + co;
-                    if (p.res) {
-                        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.Cout + co);
+                    if (p_res) {
+                        const float4 r = *reinterpret_cast<const float4*>(p_res + (size_t)m * p.Cout + co);
                         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                     }
-                    if (p.relu) {   // (x < 0 ? 0 : x keeps a NaN, like torch's relu)
+                    if (p_relu) {   // (x < 0 ? 0 : x keeps a NaN, like torch's relu)
                         v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
                         v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                     }
@@ -839,15 +843,23 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
     p.macc = p.ntiles == 1 && knob(KNOB_CONV_MOMENTS_PER_TILE) <= 0;
     if (moments_groups) *moments_groups = (p.macc ? grid : (int64_t)p.mtiles) * C::WN;
     if (dry) return NW_OK;
-    auto kern0 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false>;
-    auto kern1 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, true>;
+    // three instantiations: plain (training: data gradients, transitions), with statistics (training forward), with the
+    // inference epilogue (bias / identity / ReLU)
+    auto kern0 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false, false>;
+    auto kern1 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, true, false>;
+    auto kern2 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false, true>;
+    auto kern3 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, true, true>;
     static const bool attr = [&] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess;
+        bool ok = true;
+        for (const void* k : {reinterpret_cast<const void*>(kern0), reinterpret_cast<const void*>(kern1),
+                              reinterpret_cast<const void*>(kern2), reinterpret_cast<const void*>(kern3)})
+            ok = ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess;
+        return ok;
     }();
     if (!attr) return NW_ERR_LAUNCH;
-    if (p.moments || p.bnb_part) hipLaunchKernelGGL(kern1, dim3((unsigned)grid), dim3(512), C::LDS, st, p);
-    else hipLaunchKernelGGL(kern0, dim3((unsigned)grid), dim3(512), C::LDS, st, p);
+    const bool stats = p.moments || p.bnb_part, post = p.bias || p.res || p.relu;
+    auto kern = stats ? (post ? kern3 : kern1) : (post ? kern2 : kern0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS, st, p);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }
