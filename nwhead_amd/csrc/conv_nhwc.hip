@@ -126,6 +126,9 @@ __device__ unsigned long long nw_conv_diag[16 * 1024];
 // POST = false: likewise without bias, identity and ReLU (the training path's convolutions have none of them)
 template <int NA, int NB, int WM, int MODE, bool STATS, bool POST>
 __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
+    // (running moments cost 33 registers across the main loop: the 128 x 128 tile has none to spare -- groups per tile there)
+    constexpr bool MACC_OK = !(NA == 4 && NB == 4);
+    const int p_macc = MACC_OK ? p.macc : 0;
     float* const p_moments = STATS ? p.moments : nullptr;
     float* const p_bnb_part = STATS ? p.bnb_part : nullptr;
     const float* const p_bias = POST ? p.bias : nullptr;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     const int ntile = tbeg < tend ? (tend - tbeg + nslot - 1) / nslot : 0;
     if (ntile == 0) {
         if (p.amax_out && tid == 0) amax_write(p.amax_out, 0.f, blockIdx.x, gridDim.x);
-        if ((p_moments || p_bnb_part) && p.macc) {                 // its groups exist and are empty
+        if ((p_moments || p_bnb_part) && p_macc) {                 // its groups exist and are empty
             const int G = gridDim.x * WN, nstat = p_moments ? 3 : 2;
             float* dst = p_moments ? p_moments : p_bnb_part;
             for (int k = tid; k < nstat * WN * p.Cout; k += 512) {
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
 #else
 #define NW_CBAR() tile_barrier()
 #endif
-    // moments of everything this wave row has written so far (p.macc): Chan's merge, tile by tile, in registers
+    // moments of everything this wave row has written so far (p_macc): Chan's merge, tile by tile, in registers
     float rcnt = 0.f, rmean[NA][4], rm2[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
@@ -561,14 +564,11 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             }
             if (MF > PAIR) __builtin_amdgcn_sched_group_barrier(0x008, MF - PAIR, 0);
         };
-        // the epilogue's per-channel factors, requested now: their L2 latency (~1 us, once per tile) passes behind the main loop
+        // the epilogue's per-channel factors are requested at the top of the tile's LAST stage: their L2 latency (~1 us, once per
+        // tile, on the critical path when they were loaded where they are used) passes behind that stage's MFMAs, in registers
+        // the second fragment set no longer needs (requested at tile set-up they were live across the whole main loop: the
+        // 128 x 128 tiles spilled)
         float4 ws4[NA], b4[NA];
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const int co = co0 + wco + 16 * a + 4 * g;
-            ws4[a] = *reinterpret_cast<const float4*>(p.wscale + co);
-            b4[a] = p_bias ? *reinterpret_cast<const float4*>(p_bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         Frag f0, f1;
         load_frags(f0, 0);
         NW_CSTAMP(3);                                              // tile set-up (+ the first fragments' issue)
@@ -583,11 +583,25 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             interleave();
             NW_CBAR();
         }
-        for (; k < ST; ++k) {
-            if (k + 1 < ST) load_frags(f1, k + 1);
+        auto load_factors = [&]() {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int co = co0 + wco + 16 * a + 4 * g;
+                ws4[a] = *reinterpret_cast<const float4*>(p.wscale + co);
+                b4[a] = p_bias ? *reinterpret_cast<const float4*>(p_bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        if (k + 1 < ST) {                                          // two stages left: the factors ride in f0's registers
+            load_frags(f1, k + 1);
             mfma_stage(f0);
             NW_CBAR();
-            f0 = f1;
+            load_factors();
+            mfma_stage(f1);
+            NW_CBAR();
+        } else {                                                   // one stage left: ... in f1's
+            load_factors();
+            mfma_stage(f0);
+            NW_CBAR();
         }
         sg += ST;
         qg += CH;
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     }
                     m2[e] = rowsum(q);
                 }
-                if (p.macc) {
+                if (p_macc) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float d = mean[e] - rmean[a][e];
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     *reinterpret_cast<float4*>(p_moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(m2[0], m2[1], m2[2], m2[3]);
                 }
             }
-            if (p.macc) rcnt = ntot;
+            if (p_macc) rcnt = ntot;
         }
         if (p_bnb_part) {
             // y = dL/d relu(bn(x)): sum g and sum g xhat over this wave's pixel rows, g = y where the forward's own
@@ -716,7 +730,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s1[e] = rowsum(s1[e]); s2[e] = rowsum(s2[e]); }
-                if (p.macc) {                                      // one group per workgroup and wave row (rmean / rm2 are free:
+                if (p_macc) {                                      // one group per workgroup and wave row (rmean / rm2 are free:
 #pragma unroll                                                     //  the moments and these sums have separate entry points)
                     for (int e = 0; e < 4; ++e) { rmean[a][e] += s1[e]; rm2[a][e] += s2[e]; }
                 } else if (i == 0) {
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         nw_conv_diag[16 * blockIdx.x + 14] = cl_ - cf_;
     }
 #endif
-    if (p_bnb_part && p.macc && i == 0) {
+    if (p_bnb_part && p_macc && i == 0) {
         const int G = gridDim.x * WN, grp = blockIdx.x * WN + wave / WM;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
@@ -742,7 +756,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             *reinterpret_cast<float4*>(p_bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
         }
     }
-    if (p_moments && p.macc && i == 0) {
+    if (p_moments && p_macc && i == 0) {
         const int G = gridDim.x * WN, grp = blockIdx.x * WN + wave / WM;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
@@ -840,7 +854,7 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
     grid = (grid + 7) / 8 * 8;
     // one output-channel tile: a workgroup's tiles are all rows of the same channels, and their moments are merged in its
     // registers -- grid x WN groups for the merge kernel instead of mtiles x WN (2058 -> 512 on the 56 x 56 layers)
-    p.macc = p.ntiles == 1 && knob(KNOB_CONV_MOMENTS_PER_TILE) <= 0;
+    p.macc = p.ntiles == 1 && !(NA == 4 && NB == 4) && knob(KNOB_CONV_MOMENTS_PER_TILE) <= 0;
     if (moments_groups) *moments_groups = (p.macc ? grid : (int64_t)p.mtiles) * C::WN;
     if (dry) return NW_OK;
     // three instantiations: plain (training: data gradients, transitions), with statistics (training forward), with the
