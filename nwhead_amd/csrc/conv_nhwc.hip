@@ -126,9 +126,10 @@ __device__ unsigned long long nw_conv_diag[16 * 1024];
 // POST = false: likewise without bias, identity and ReLU (the training path's convolutions have none of them)
 template <int NA, int NB, int WM, int MODE, bool STATS, bool POST>
 __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
-    // (running moments cost 33 registers across the main loop: the 128 x 128 tile has none to spare -- groups per tile there)
-    constexpr bool MACC_OK = !(NA == 4 && NB == 4);
-    const int p_macc = MACC_OK ? p.macc : 0;
+    // (running moments cost 33 registers across the main loop: the 128 x 128 tile has none to spare and keeps them in LDS, 128
+    //  bytes per wave and lane row behind the rings, touched by the row's first lane only)
+    constexpr bool MACC_LDS = NA == 4 && NB == 4;
+    const int p_macc = p.macc;
     float* const p_moments = STATS ? p.moments : nullptr;
     float* const p_bnb_part = STATS ? p.bnb_part : nullptr;
     const float* const p_bias = POST ? p.bias : nullptr;
@@ -484,12 +485,33 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
 #else
 #define NW_CBAR() tile_barrier()
 #endif
-    // moments of everything this wave row has written so far (p_macc): Chan's merge, tile by tile, in registers
+    // moments of everything this wave row has written so far (p_macc): Chan's merge, tile by tile, in registers (MACC_LDS: in LDS)
     float rcnt = 0.f, rmean[NA][4], rm2[NA][4];
+    float4* const mlds = reinterpret_cast<float4*>(smem + C::LDS) + (wave * 4 + g) * (2 * NA);   // [a]: mean, m2
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
+    for (int a = 0; a < NA; ++a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) rmean[a][e] = rm2[a][e] = 0.f;
+        if (MACC_LDS && STATS && i == 0) mlds[2 * a] = mlds[2 * a + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto run_get = [&](int a, float (&m)[4], float (&q)[4]) {
+        if (MACC_LDS) {
+            const float4 x = mlds[2 * a], y = mlds[2 * a + 1];
+            m[0] = x.x; m[1] = x.y; m[2] = x.z; m[3] = x.w; q[0] = y.x; q[1] = y.y; q[2] = y.z; q[3] = y.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { m[e] = rmean[a][e]; q[e] = rm2[a][e]; }
+        }
+    };
+    auto run_put = [&](int a, const float (&m)[4], const float (&q)[4]) {
+        if (MACC_LDS) {
+            mlds[2 * a] = make_float4(m[0], m[1], m[2], m[3]);
+            mlds[2 * a + 1] = make_float4(q[0], q[1], q[2], q[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { rmean[a][e] = m[e]; rm2[a][e] = q[e]; }
+        }
+    };
     __builtin_amdgcn_s_barrier();                                  // the prologue's stages have landed
     NW_CSTAMP(0);                                                  // wait for the pipeline fill
     for (int tl = 0; tl < ntile; ++tl) {
@@ -670,11 +692,16 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     m2[e] = rowsum(q);
                 }
                 if (p_macc) {
+                    if (!MACC_LDS || i == 0) {
+                        float rm[4], rq[4];
+                        run_get(a, rm, rq);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = mean[e] - rmean[a][e];
-                        rmean[a][e] = __builtin_fmaf(d, wt, rmean[a][e]);
-                        rm2[a][e] += __builtin_fmaf(d * d, rcnt * wt, m2[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = mean[e] - rm[e];
+                            rm[e] = __builtin_fmaf(d, wt, rm[e]);
+                            rq[e] += __builtin_fmaf(d * d, rcnt * wt, m2[e]);
+                        }
+                        run_put(a, rm, rq);
                     }
                 } else if (i == 0) {
                     const int co = co0 + wco + 16 * a + 4 * g;
@@ -730,9 +757,14 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s1[e] = rowsum(s1[e]); s2[e] = rowsum(s2[e]); }
-                if (p_macc) {                                      // one group per workgroup and wave row (rmean / rm2 are free:
-#pragma unroll                                                     //  the moments and these sums have separate entry points)
-                    for (int e = 0; e < 4; ++e) { rmean[a][e] += s1[e]; rm2[a][e] += s2[e]; }
+                if (p_macc) {                                      // one group per workgroup and wave row (the running moments'
+                    if (!MACC_LDS || i == 0) {                     //  storage is free: the two have separate entry points)
+                        float rm[4], rq[4];
+                        run_get(a, rm, rq);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { rm[e] += s1[e]; rq[e] += s2[e]; }
+                        run_put(a, rm, rq);
+                    }
                 } else if (i == 0) {
                     *reinterpret_cast<float4*>(p_bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(s1[0], s1[1], s1[2], s1[3]);
                     *reinterpret_cast<float4*>(p_bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(s2[0], s2[1], s2[2], s2[3]);
@@ -752,8 +784,10 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             const int co = wco + 16 * a + 4 * g;
-            *reinterpret_cast<float4*>(p_bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rmean[a][0], rmean[a][1], rmean[a][2], rmean[a][3]);
-            *reinterpret_cast<float4*>(p_bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
+            float rm[4], rq[4];
+            run_get(a, rm, rq);
+            *reinterpret_cast<float4*>(p_bnb_part + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rm[0], rm[1], rm[2], rm[3]);
+            *reinterpret_cast<float4*>(p_bnb_part + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rq[0], rq[1], rq[2], rq[3]);
         }
     }
     if (p_moments && p_macc && i == 0) {
@@ -762,8 +796,10 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         for (int a = 0; a < NA; ++a) {
             const int co = wco + 16 * a + 4 * g;                   // (ntiles == 1: the tile starts at channel 0)
             *reinterpret_cast<float4*>(p_moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(rcnt, rcnt, rcnt, rcnt);
-            *reinterpret_cast<float4*>(p_moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rmean[a][0], rmean[a][1], rmean[a][2], rmean[a][3]);
-            *reinterpret_cast<float4*>(p_moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(rm2[a][0], rm2[a][1], rm2[a][2], rm2[a][3]);
+            float rm[4], rq[4];
+            run_get(a, rm, rq);
+            *reinterpret_cast<float4*>(p_moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rm[0], rm[1], rm[2], rm[3]);
+            *reinterpret_cast<float4*>(p_moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(rq[0], rq[1], rq[2], rq[3]);
         }
     }
     // this workgroup's maximum -> its slot of the output's amax record (no atomics, nothing to clear beforehand)
@@ -854,9 +890,11 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
     grid = (grid + 7) / 8 * 8;
     // one output-channel tile: a workgroup's tiles are all rows of the same channels, and their moments are merged in its
     // registers -- grid x WN groups for the merge kernel instead of mtiles x WN (2058 -> 512 on the 56 x 56 layers)
-    p.macc = p.ntiles == 1 && !(NA == 4 && NB == 4) && knob(KNOB_CONV_MOMENTS_PER_TILE) <= 0;
+    p.macc = p.ntiles == 1 && knob(KNOB_CONV_MOMENTS_PER_TILE) <= 0;
     if (moments_groups) *moments_groups = (p.macc ? grid : (int64_t)p.mtiles) * C::WN;
     if (dry) return NW_OK;
+    constexpr size_t lds = C::LDS + (NA == 4 && NB == 4 ? 2048 : 0);   // (+ the 128 x 128 tile's running moments)
+    static_assert(lds <= 160 * 1024, "LDS");
     // three instantiations: plain (training: data gradients, transitions), with statistics (training forward), with the
     // inference epilogue (bias / identity / ReLU)
     auto kern0 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false, false>;
@@ -867,13 +905,13 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
         bool ok = true;
         for (const void* k : {reinterpret_cast<const void*>(kern0), reinterpret_cast<const void*>(kern1),
                               reinterpret_cast<const void*>(kern2), reinterpret_cast<const void*>(kern3)})
-            ok = ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) == hipSuccess;
+            ok = ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         return ok;
     }();
     if (!attr) return NW_ERR_LAUNCH;
     const bool stats = p.moments || p.bnb_part, post = p.bias || p.res || p.relu;
     auto kern = stats ? (post ? kern3 : kern1) : (post ? kern2 : kern0);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, p);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }
