@@ -188,3 +188,22 @@ def test_nhwc_training_path_is_chosen_by_architecture():
     assert load_model("densenet121")._nhwc_servable()
     assert load_model("densenet169")._nhwc_servable()
     assert not load_model("densenet161")._nhwc_servable()
+
+
+def test_device_optimizer_has_no_cpu_path_and_the_harness_picks_by_device():
+    """nwhead_amd.optim.SGD: torch's argument checks, torch.optim.SGD's group keys (state_dict()s load either way), and a
+    loud refusal of CPU parameters -- the harness uses torch.optim.SGD on CPU (reference train.py:243-247) instead."""
+    import pytest
+    from nwhead_amd.optim import SGD
+    from nwhead_amd.ops import NWHipError
+    with pytest.raises(ValueError):
+        SGD([torch.nn.Parameter(torch.zeros(3))], lr=0.1, nesterov=True)            # Nesterov needs a momentum
+    p = torch.nn.Parameter(torch.zeros(8))
+    opt = SGD([p], lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    ref = torch.optim.SGD([torch.nn.Parameter(torch.zeros(8))], lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    assert set(ref.param_groups[0]) <= set(opt.param_groups[0])
+    opt.step()                                                                      # no gradient anywhere: nothing to do
+    p.grad = torch.ones(8)
+    with pytest.raises(NWHipError):
+        opt.step()
+    assert torch.equal(p.detach(), torch.zeros(8))                                  # ... and nothing was updated
