@@ -110,6 +110,9 @@ int nw_split_rows_f16x2(const float *x, float *out_split, float *row_scale, floa
  *               nw_bank_tables_build(sy, N, C, ...) for the very sy, N and C of this call: on large launches the forward
  *               walks the bank in tiles of 128 supports and needs, per tile, the runs of equal consecutive labels; without
  *               tables it builds them in its workspace on every call (~5 us + a kernel boundary)
+ *   tables_sy / tables_N   the label array and row count the tables were built from.  The forward uses the tables only
+ *               when these are the call's own sy and N (anything else -- another label array, a shorter struct of an older
+ *               header -- and it builds the tables itself, as without the option)
  *   persistent_wgs  workgroups of the persistent tile kernel, a multiple of 8; 0 = one per CU.  Sharded inference passes
  *               CUs - 8 (one CU per XCD left to the concurrent RCCL kernel)
  *   force_split nonzero: the split-fp16 path whenever the bank is prepared, also below ~2e8 multiply-adds */
@@ -120,6 +123,8 @@ typedef struct nw_fwd_opts {
     int32_t reserved;
     const void *tables;
     size_t tables_bytes;
+    const int64_t *tables_sy;
+    int64_t tables_N;
 } nw_fwd_opts;
 
 size_t nw_fwd_workspace_bytes(int64_t B, int64_t N, int64_t d, int64_t C);

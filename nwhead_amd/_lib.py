@@ -136,7 +136,8 @@ class ConvBnStat(C.Structure):
 class FwdOpts(C.Structure):
     """nw_fwd_opts (include/nwhead_hip.h): the options of ONE forward call."""
     _fields_ = [("struct_size", C.c_uint32), ("persistent_wgs", C.c_int32), ("force_split", C.c_int32),
-                ("reserved", C.c_int32), ("tables", C.c_void_p), ("tables_bytes", C.c_size_t)]
+                ("reserved", C.c_int32), ("tables", C.c_void_p), ("tables_bytes", C.c_size_t),
+                ("tables_sy", C.c_void_p), ("tables_N", C.c_int64)]
 
 
 # Environment switches of the Python layer (the C library never reads the environment).  NW_SPLIT_ALWAYS travels in every
@@ -164,9 +165,10 @@ def force_split():
     return os.environ.get("NW_SPLIT_ALWAYS", "") == "1"
 
 
-def fwd_opts(tables=None, tables_bytes=0, persistent_wgs=0):
+def fwd_opts(tables=None, tables_bytes=0, persistent_wgs=0, tables_sy=None, tables_n=-1):
     """An nw_fwd_opts for one forward call (a ctypes object: keep it alive across the call)."""
-    return FwdOpts(C.sizeof(FwdOpts), int(persistent_wgs), int(force_split()), 0, tables, int(tables_bytes))
+    return FwdOpts(C.sizeof(FwdOpts), int(persistent_wgs), int(force_split()), 0, tables, int(tables_bytes), tables_sy,
+                   int(tables_n))
 
 
 def check(status: int, what: str):

@@ -1,4 +1,5 @@
 // capi.hip -- the extern "C" surface declared in include/nwhead_hip.h (gfx950 / MI355X only).
+#include <cstddef>
 #include <cstdlib>
 #include <string.h>
 #include "nw_internal.h"
@@ -34,11 +35,17 @@ struct OptsGuard {   // the call's options are visible to the launch code of thi
     nw::FwdOpts saved;
     explicit OptsGuard(const nw_fwd_opts* o) : saved(nw::tl_fwd_opts) {
         nw::FwdOpts f;
+        // (a caller built against an older header passes a shorter struct: the fields it has are honoured, and its tables,
+        //  whose label array is then unknown, are not used)
+        if (o && o->struct_size >= offsetof(nw_fwd_opts, tables)) {
+            f.persistent_wgs = o->persistent_wgs;
+            f.force_split = o->force_split;
+        }
         if (o && o->struct_size >= sizeof(nw_fwd_opts)) {
             f.tables = static_cast<const char*>(o->tables);
             f.tables_bytes = o->tables_bytes;
-            f.persistent_wgs = o->persistent_wgs;
-            f.force_split = o->force_split;
+            f.tables_sy = o->tables_sy;
+            f.tables_N = o->tables_N;
         }
         nw::tl_fwd_opts = f;
     }

@@ -500,9 +500,10 @@ size_t bank_tables_layout(int64_t n_stiles, char* base, FusedWs* ws) {
 }
 
 bool bank_tables_take(const int64_t* sy, int N, int C, int n_stiles, int BS, FusedWs* ws) {
-    (void)sy; (void)N; (void)C;
+    (void)C;   // (the tables do not depend on the class count: labels >= C are the caller's check, as in nw_bank_tables_build)
     const FwdOpts& o = fwd_opts();
     if (!o.tables || BS != BANK_BS) return false;
+    if (o.tables_sy != sy || o.tables_N != (int64_t)N) return false;   // tables of another label array: build our own
     if (o.tables_bytes < bank_tables_layout(n_stiles, nullptr, nullptr)) return false;
     bank_tables_layout(n_stiles, const_cast<char*>(o.tables), ws);
     return true;

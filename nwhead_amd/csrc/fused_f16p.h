@@ -242,6 +242,9 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[QB][RS], const float* hd
 // QB = 2     : 128-query tiles (one workgroup per CU, single-buffered fragments): per flop 1/3 fewer
 //              bytes through the LDS fill and 44 % fewer LDS read bytes than the 64-query tile -- on
 //              this power-limited loop (header comment) energy per flop is what sets the pace.
+#if defined(NW_ABL_QREG) && !defined(NW_ABL_NOQ)
+#define NW_ABL_NOQ
+#endif
 template <int RS, int KIND, bool TWO, int QB>
 __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kernel(
     const float* __restrict__ q, const float* __restrict__ s, const float* __restrict__ s_norm2,
@@ -360,6 +363,12 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
 #endif
             for (int m = 0; m < NI; ++m) {
                 if (NI != NI_LO && m == NI - 1 && lw + NLOAD * m >= NT) break;
+#if defined(NW_ABL_NOQ)   // timing experiment: the query rows are not filled (results wrong, half of the LDS-DMA bytes gone)
+                if (8 * NLOAD * m < BQP) continue;
+#endif
+#ifdef NW_ABL_NOS   // ... or the support rows are not
+                if (8 * NLOAD * m >= BQP) continue;
+#endif
                 const char* g = ((8 * NLOAD * m < BQP) ? qb : sb) + voff[m];
 #ifndef NW_ABL_NODMA
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -383,6 +392,21 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
         auto wait_landed = [&](bool issued) {  // everything but the youngest stage of this wave has landed
 #ifdef NW_ABL_AHEAD   // (with fewer stages in flight the youngest must have landed too: the consumers read one stage ahead)
             if (AHEAD < NB - 1) { wait_vmcnt<0>(); return; }
+#endif
+#if defined(NW_ABL_NOQ) || defined(NW_ABL_NOS)
+            {
+                constexpr int NQP = BQP / (8 * NLOAD);
+#ifdef NW_ABL_NOQ
+                constexpr int NP_ = NI - NQP;
+#else
+                constexpr int NP_ = NQP;
+#endif
+                static_assert(NI == NI_LO, "ablation builds: even split of the pieces");
+                if (!issued) wait_vmcnt<0>();
+                else if (young_hdr) wait_vmcnt<NP_ + P::HPW>();
+                else wait_vmcnt<NP_>();
+                return;
+            }
 #endif
             if (!issued) wait_vmcnt<0>();
             else if (long_wave) { if (young_hdr) wait_vmcnt<NI + P::HPW>(); else wait_vmcnt<NI>(); }
@@ -496,8 +520,43 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
                 auto pin = []() { __builtin_amdgcn_sched_barrier(0); };
                 // one stage: ac = this stage's F1, an = the next stage's (filled here), b = this stage's F2 on
                 // entry, the next stage's on exit
+#ifdef NW_ABL_QREG   // timing experiment: the wave's own query rows, global -> VGPR, two stages ahead (values unused)
+                const char* qtile_ = reinterpret_cast<const char*>(q + (size_t)q0 * d);
+                unsigned qlane_[QB];
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+                    qlane_[j] = ((unsigned)(min(q0 + 16 * (QB * wave + j) + i, B - 1) - q0) * (unsigned)d + 4 * g) * 4u;
+                const int krot_ = st % nk;
+                auto qload_ = [&](float4 (&X)[2 * QB], int kt_) {
+                    int kc = min(kt_, nk - 1) + krot_;
+                    if (kc >= nk) kc -= nk;
+                    const char* b_ = qtile_ + (size_t)kc * (BK * 4);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        X[2 * j] = *reinterpret_cast<const float4*>(b_ + qlane_[j]);
+                        X[2 * j + 1] = *reinterpret_cast<const float4*>(b_ + qlane_[j] + 64);
+                    }
+                };
+                float4 qx0_[2 * QB], qx1_[2 * QB];
+                qload_(qx0_, 0);
+                qload_(qx1_, 1);
+                int kt_abs_ = 0;
+#define NW_QREG_STEP(X)                                                                                   \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int e_ = 0; e_ < 2 * QB; ++e_) asm volatile("" ::"v"(__builtin_bit_cast(f32x4, X[e_])));             \
+        qload_(X, kt_abs_ + 2);                                                                           \
+        ++kt_abs_;                                                                                        \
+        pin();                                                                                            \
+    } while (0)
+#else
+#define NW_QREG_STEP(X)
+#endif
                 auto run_stage = [&](const F1& ac, F1& an, F2& b, int buf_next, auto has_next) {
+#ifdef NW_ABL_NORD   // timing experiment: no fragment reads in the loop (the first stage's fragments are reused)
+                    constexpr bool NXT = false;
+#else
                     constexpr bool NXT = decltype(has_next)::value;
+#endif
                     const float4* Sn = stage_base(buf_next);
                     int n = 0;
 #pragma unroll
@@ -550,24 +609,33 @@ __global__ __launch_bounds__(TILE_THREADS, TWO ? 4 : 2) void nw_fused_f16p_kerne
                     for (int j = 0; j < QB; ++j) { a0.bh[j] = rd_bh(S0, j); b0.bl[j] = rd_bl(S0, j); }
 #pragma unroll
                     for (int r = 0; r < RS; ++r) { a0.al[r] = rd_al(S0, r); b0.ah[r] = rd_ah(S0, r); }
+#ifdef NW_ABL_NORD
+                    a1 = a0;
+#endif
                     pin();
                 }
                 int kt = 0;
                 for (; kt + 2 < nk; kt += 2) {
+                    NW_QREG_STEP(qx0_);
                     run_stage(a0, a1, b0, gi + kt + 1, Yes{});
                     tile_barrier_nowait();
+                    NW_QREG_STEP(qx1_);
                     run_stage(a1, a0, b0, gi + kt + 2, Yes{});
                     tile_barrier_nowait();
                 }
                 if (kt + 2 == nk) {
+                    NW_QREG_STEP(qx0_);
                     run_stage(a0, a1, b0, gi + kt + 1, Yes{});
                     tile_barrier_nowait();
+                    NW_QREG_STEP(qx1_);
                     run_stage(a1, a0, b0, 0, No{});
                     tile_barrier_nowait();
                 } else {
+                    NW_QREG_STEP(qx0_);
                     run_stage(a0, a1, b0, 0, No{});
                     tile_barrier_nowait();
                 }
+#undef NW_QREG_STEP
             } else if constexpr (SINGLE) {
                 Frag f0;
                 for (int kt = 0; kt < nk; ++kt) {

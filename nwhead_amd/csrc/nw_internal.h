@@ -68,6 +68,8 @@ int launch_xgemm(bool x_km, const float* X, int64_t ldx, int64_t x_rows, const f
 struct FwdOpts {
     const char* tables = nullptr;   // run tables of the call's labels (nw_bank_tables_build), or null
     size_t tables_bytes = 0;
+    const int64_t* tables_sy = nullptr;   // ... the label array and row count they were built from
+    int64_t tables_N = -1;
     int persistent_wgs = 0;         // workgroups of the persistent tile kernel (0: one per CU)
     int force_split = 0;            // split-fp16 path at every size
 };

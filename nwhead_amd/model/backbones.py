@@ -680,9 +680,9 @@ class ConvBiasAct(nn.Conv2d):
 
     def _split_weight(self):
         w = self.weight
-        key = (w.data_ptr(), w._version, str(w.device))
+        from .. import ops
+        key = (w.data_ptr(), ops._ver(w), str(w.device))   # (a copy folded under inference_mode has no version counter)
         if getattr(self, "_nw_split_key", None) != key:
-            from .. import ops
             self._nw_split, self._nw_split_key = ops.SplitConvWeight(w), key
         return self._nw_split
 

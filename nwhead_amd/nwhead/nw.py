@@ -95,7 +95,7 @@ class NWNet(nn.Module):
         load_state_dict, BatchNorm statistics) or replaced: the folded inference copy is rebuilt then.  (torch's fused
         optimizers do not advance version counters; train(), which every training loop passes through, drops the copy.)"""
         ts = list(self.featurizer.parameters()) + list(self.featurizer.buffers())
-        return (len(ts), sum(t._version for t in ts), sum(t.data_ptr() & 0xffff for t in ts))
+        return (len(ts), sum(0 if t.is_inference() else t._version for t in ts), sum(t.data_ptr() & 0xffff for t in ts))
 
     def _eval_featurizer(self, rebuild=False):
         if not getattr(self, '_fold_bn', False) or self.featurizer.training:

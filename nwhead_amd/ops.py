@@ -47,7 +47,13 @@ class _OnDevice:
 def _sig(t):
     """(storage address, shape, in-place version) of a tensor: what 'the very tensor, unmodified' means for the cached
     banks and run tables.  Inference tensors (torch.inference_mode) carry no version counter: None stands in."""
-    return (t.data_ptr(), tuple(t.shape), None if t.is_inference() else t._version)
+    return (t.data_ptr(), tuple(t.shape), _ver(t))
+
+
+def _ver(t):
+    """In-place version of a tensor, None for inference tensors (they have no counter and cannot be written in place
+    outside inference mode; a replaced one shows up in its address)."""
+    return None if t.is_inference() else t._version
 
 
 _WS_BYTES = {}
@@ -259,17 +265,23 @@ class SplitBank:
                        "nw_bank_tables_build")
         self.tables, self._tables_src, self._opts = tables, _sig(labels), {}
 
-    def call_opts(self, sy, n_classes, persistent_wgs=0):
+    def call_opts(self, sy, n_classes, persistent_wgs=0, sy_call=None):
         """Address of the nw_fwd_opts for a forward call with labels ``sy``: names the cached run tables when ``sy`` is the
-        label tensor they were built from (same storage, unmodified) -- the object stays alive in this bank."""
+        label tensor they were built from (same storage, unmodified) -- the object stays alive in this bank.  ``sy_call``:
+        the int64 tensor whose address the call passes as its labels (``sy`` itself unless it had to be converted); the
+        library uses the tables only for that address and row count."""
         if self.tables is not None and _sig(sy) == self._tables_src:
+            syc = sy if sy_call is None else sy_call
             if self.tables_label_max >= int(n_classes):
                 raise ValueError(f"support label {self.tables_label_max} is outside [0, n_classes={int(n_classes)}) "
                                  "(the reference's F.one_hot, nw.py:276, raises)")
-            key = (int(persistent_wgs), _lib.force_split())
+            key = (int(persistent_wgs), _lib.force_split(), syc.data_ptr(), syc.numel())
             op = self._opts.get(key)
             if op is None:
-                op = self._opts[key] = _lib.fwd_opts(self.tables.data_ptr(), self.tables.numel(), persistent_wgs)
+                if len(self._opts) > 64:
+                    self._opts.clear()
+                op = self._opts[key] = _lib.fwd_opts(self.tables.data_ptr(), self.tables.numel(), persistent_wgs,
+                                                     syc.data_ptr(), syc.numel())
             return C_addr(op)
         return _default_opts(persistent_wgs)
 
@@ -348,7 +360,7 @@ class _NWHeadFn(torch.autograd.Function):
         ws_bytes = _fwd_ws_bytes(lib, B, N, d, n_classes)
         st = _stream(qc)
         ws = _workspace(ws_bytes, dev, st) if ws_bytes else None
-        opts = cache.call_opts(sy, n_classes) if cache is not None else _default_opts()
+        opts = cache.call_opts(sy, n_classes, sy_call=syc) if cache is not None else _default_opts()
         with _OnDevice(dev):
             rc = lib.nw_fwd_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale), _ptr(out),
                                 _ptr(scores), _ptr(lse),
@@ -482,7 +494,7 @@ def nw_partials_into(packed, qc, sc, syc, n_classes, kind="euclidean", logit_sca
             raise ValueError("this SplitBank holds a class-sorted copy of its support: pass cache.sorted_rows / "
                              "cache.sorted_labels (or call nw_partials, which does)")
         sn2, ssplit, sscale = cache.norm2, cache.split, cache.scale
-    opts = cache.call_opts(syc, C, persistent_wgs) if cache is not None else _default_opts(persistent_wgs)
+    opts = cache.call_opts(syc, C, persistent_wgs, sy_call=syc) if cache is not None else _default_opts(persistent_wgs)
     with torch.cuda.device(qc.device):
         _lib.check(lib.nw_fwd_partial_f32(_ptr(qc), _ptr(sc), _ptr(syc), _ptr(sn2), _ptr(ssplit), _ptr(sscale),
                                           _ptr(m), _ptr(den), _ptr(num),
@@ -1194,7 +1206,7 @@ class ConvWeightBank:
         if ptrs != self._ptrs:
             self._build_tables()
             self._sig = None
-        sig = tuple(w._version for w in self.weights)
+        sig = tuple(_ver(w) for w in self.weights)
         if sig == self._sig and not force:
             return
         dev = self.split.device

@@ -34,6 +34,7 @@ class SGD(torch.optim.Optimizer):
                 raise NWHipError("nwhead_amd.optim.SGD: dampening and maximize are not served (torch.optim.SGD is)")
             fresh, old = [], []                    # parameters taking their first step (buffer := gradient) / all later ones
             keep = []
+            touched = []                           # tensors the launches below write through raw pointers
             for p in group["params"]:
                 g = p.grad
                 if g is None:
@@ -55,6 +56,9 @@ class SGD(torch.optim.Optimizer):
                         first = True
                     buf_ptr = buf.data_ptr()
                 (fresh if first else old).append((p.device, p.data_ptr(), g.data_ptr(), buf_ptr, p.numel()))
+                touched.append(p)
+                if mu != 0.0:
+                    touched.append(buf)
             for jobs, init in ((fresh, 1), (old, 0)):
                 by_dev = {}
                 for dev, *rest in jobs:
@@ -66,4 +70,10 @@ class SGD(torch.optim.Optimizer):
                         _lib.check(lib.nw_sgd_step_f32(arr, len(rows), float(group["lr"]), mu, float(group["weight_decay"]),
                                                        int(bool(group["nesterov"])), init, stream), "nw_sgd_step_f32")
             del keep
+            # The kernel writes through data_ptr(): tell autograd.  Everything that caches on `_version` (NWNet's folded
+            # inference copy, ConvBiasAct's split weights, ConvWeightBank.refresh) and autograd's own saved-tensor check
+            # (step() between forward and backward) relies on it; host-only, no launch.
+            for t in touched:
+                if not t.is_inference():
+                    torch.autograd.graph.increment_version(t)
         return loss

@@ -263,3 +263,103 @@ def test_bank_backward_at_widths_that_are_not_multiples_of_64(dev, d):
     gq, gs = O.nw_head_bwd_f64(qc, sc, syc, C, gout)
     assert (q.grad.cpu().double() - gq).abs().max().item() < 2e-5 * gq.abs().max().item() + 1e-9
     assert (s.grad.cpu().double() - gs).abs().max().item() < 2e-5 * gs.abs().max().item() + 1e-9
+
+
+class _TinyDS(torch.utils.data.Dataset):
+    def __init__(self, n=60, c=4, hw=8):
+        g = torch.Generator().manual_seed(1)
+        self.data, self.targets = torch.randn(n, 3, hw, hw, generator=g), (torch.arange(n) % c).tolist()
+
+    def __len__(self):
+        return len(self.targets)
+
+    def __getitem__(self, i):
+        return self.data[i], self.targets[i]
+
+
+def test_eval_mode_step_of_the_device_optimizer_refreshes_inference_state(dev):
+    """nw_sgd_step_f32 writes parameters through raw pointers; nwhead_amd.optim.SGD must advance their version
+    counters, or frozen-BatchNorm fine-tuning (eval mode, grads on, step(), predict()) serves the stale folded copy."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from nwhead_amd.nwhead.nw import NWNet
+    from nwhead_amd.optim import SGD
+    feat = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten())
+    net = NWNet(feat, 4, support_dataset=_TinyDS(), n_shot_full=10, device="cuda:0").to(dev).eval()
+    net.enable_bn_folding(True)
+    net.precompute()
+    x = torch.randn(5, 3, 8, 8, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        a = net.predict(x, "full")
+    opt = SGD(net.parameters(), lr=0.5, momentum=0.9, nesterov=True)
+    w = net.featurizer[0].weight
+    v0 = w._version
+    out = net.nwhead(net.featurizer(x), net.full_feat, net.full_y)        # eval mode, gradients on
+    F.nll_loss(out, torch.tensor([0, 1, 2, 3, 0], device=dev)).backward()
+    opt.step()
+    assert w._version > v0 and opt.state[w]["momentum_buffer"]._version > 0
+    with torch.no_grad():
+        b = net.predict(x, "full")
+        want = net.nwhead(net.featurizer(x), net.full_feat, net.full_y)   # the unfolded featurizer with the new weights
+    assert not torch.allclose(a, b)
+    np.testing.assert_allclose(b.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=3e-5)
+    # autograd's saved-tensor check sees the step too: stepping between forward and backward is refused, as with torch's SGD
+    out = net.nwhead(net.featurizer(x), net.full_feat, net.full_y)
+    opt.step()
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.sum().backward()
+
+
+def test_folded_resnet_predict_under_inference_mode(dev):
+    """a folded copy built inside torch.inference_mode() holds inference tensors, which have no version
+    counter; ConvBiasAct._split_weight and NWNet._weights_signature must not read `_version` from them."""
+    from nwhead_amd.model import load_model
+    from nwhead_amd.nwhead.nw import NWNet
+    torch.manual_seed(0)
+    net = NWNet(load_model("resnet18"), 4, support_dataset=_TinyDS(40, 4, 64), feat_dim=512, n_shot_full=10,
+                device="cuda:0").to(dev).eval()
+    net.enable_bn_folding(True)
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(3)).to(dev)
+    with torch.inference_mode():
+        net.precompute()
+        a = net.predict(x, "full")
+        b = net.predict(x, "full")                                        # second call: the cached keys are compared
+    with torch.no_grad():
+        want = net.nwhead(net.featurizer(x), net.full_feat.clone(), net.full_y.clone())
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_run_tables_of_another_label_array_are_not_used(dev):
+    """nw_fwd_opts.tables are used only for the label array and row count they were built from
+    (tables_sy / tables_N); handed the tables of ANOTHER labelling with the same N, the library builds its own."""
+    import ctypes as C
+    from nwhead_amd import _lib, ops
+    torch.manual_seed(1)
+    B, N, d, nc = 2048, 20000, 128, 50
+    q, s = torch.randn(B, d, device=dev), torch.randn(N, d, device=dev)
+    sy = (torch.arange(N, device=dev) * nc // N)
+    other = sy.flip(0).contiguous()                       # a different labelling, same N
+    bank = ops.SplitBank(s, labels=sy)
+    want = ops.nw_head(q, s, sy, nc, support_cache=bank)
+    want_other = ops.nw_head(q, s, other, nc, support_cache=ops.SplitBank(s))
+    assert not torch.equal(want, want_other)
+    lib = _lib.load()
+    ws_bytes = lib.nw_fwd_workspace_bytes(B, N, d, nc)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def call(labels, tables_sy, tables_n):
+        out = torch.empty(B, nc, device=dev)
+        o = _lib.fwd_opts(bank.tables.data_ptr(), bank.tables.numel(), 0, tables_sy, tables_n)
+        o.force_split = 1
+        rc = lib.nw_fwd_f32(q.data_ptr(), s.data_ptr(), labels.data_ptr(), bank.norm2.data_ptr(), bank.split.data_ptr(),
+                            bank.scale.data_ptr(), out.data_ptr(), None, None, None, ws.data_ptr(), ws_bytes, B, N, d, nc, 0,
+                            None, 0, 0, C.addressof(o), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out
+    assert torch.equal(call(sy, sy.data_ptr(), N), want)                      # the tables' own labels: used
+    assert torch.equal(call(other, sy.data_ptr(), N), want_other)             # another array: ignored, own tables built
+    assert torch.equal(call(other, other.data_ptr(), N - 1), want_other)      # another row count: ignored
+    assert torch.equal(call(other, None, -1), want_other)                     # identity not given: ignored
