@@ -66,7 +66,8 @@ struct PCfg {
 // Epilogue of one tile for the consumer waves: scores -> tile-local softmax statistics -> run sums.
 // Same arithmetic as fused_epilogue<.., MODE_F16> (fused_impl.h); the header comes from LDS only.
 // A wave owns QB blocks of 16 queries (rows 16*(QB*wave + j) + i of the tile) x all 16*RS supports.
-template <int RS, int KIND, int QB>
+// NCW = waves that own query rows (the header's query arrays hold 16 * QB * NCW entries).
+template <int RS, int KIND, int QB, int NCW = NCONS>
 __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[QB][RS], const float* hdr, int nrun, int2 bnd,
                                            const float* __restrict__ logit_scale, float* __restrict__ ws_m,
                                            float* __restrict__ ws_den, float* __restrict__ ws_num, int B, int N,
@@ -84,7 +85,7 @@ __device__ __forceinline__ void epilogue_p(f32x4 (&acc)[QB][RS], const float* hd
     const float* ssc = hdr + P::NH;
     const int* runid = reinterpret_cast<const int*>(hdr + 2 * P::NH);
     const float* qn2 = hdr + 3 * P::NH;
-    const float* qsc_s = qn2 + P::BQP;
+    const float* qsc_s = qn2 + 16 * QB * NCW;
     const int i = lane & 15, g = lane >> 4;
     float scale = 1.f;
     if (KIND == NW_SCORE_CLIP) scale = expf(*logit_scale);

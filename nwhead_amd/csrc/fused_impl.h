@@ -470,6 +470,9 @@ int launch_fused_kind(const float* q, const float* s, const int64_t* sy, const f
 
 }  // namespace nw
 #include "fused_f16p.h"
+#ifdef NW_WITH_P8   // tools/bench_fused.hip only: the eight-multiplying-wave experiment (tools/experiments/fused_f16p8.h)
+#include "fused_f16p8.h"
+#endif
 namespace nw {
 namespace {
 template <int RS, int KIND>
@@ -489,6 +492,23 @@ int launch_f16p(const float* q, const float* s, const int64_t* sy, const float* 
         int variant = persistent_variant();
         if (variant < 0) variant = ((B + 127) / 128 * 128 <= 1.15 * ((B + 63) / 64 * 64)) ? 2 : 1;
         (void)n_qtiles;
+#ifdef NW_WITH_P8   // NW_PVAR=3 in tools/bench_fused.hip: 256-query tiles, eight multiplying waves (measured slower)
+        if constexpr (RS == 8) {
+            if (variant == 3) {
+                static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(nw_fused_f16p8_kernel<KIND>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8::LDS_BYTES) == hipSuccess;
+                (void)attr;
+                int qgrp = persistent_qgroup() / 2;   // the same bytes of queries resident per XCD as with 128-query tiles
+                if (qgrp < 1) qgrp = 1;
+                hipLaunchKernelGGL((nw_fused_f16p8_kernel<KIND>), dim3(cus), dim3(TILE_THREADS), P8::LDS_BYTES, st, q, s, s_norm2,
+                                   s_scale, q_norm2, q_scale, ls, ws.runid, ws.nrun, ws.bnd, ws.m, ws.den, ws.num, B, N, d, n_stiles,
+                                   (B + P8::BQP - 1) / P8::BQP, qgrp);
+                NW_CHECK_LAUNCH();
+                return NW_OK;
+            }
+        }
+#endif
+        if (variant > 2) variant = 2;
 #define NW_LAUNCH_P(TWO_, QB_, GRID_, NBUF_)                                                                      \
     do {                                                                                                          \
         using PC_ = PCfg<RS, QB_>;                                                                                \
