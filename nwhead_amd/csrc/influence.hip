@@ -29,6 +29,15 @@ __device__ __forceinline__ float infl_one(float p, float w, bool same) {
 // SCORES: `w` holds raw scores, the weight is exp(score - lse[b]) (the forward's log-sum-exp) and p is
 // exp(logp[b, qy_b]): the influence straight from the fused forward's score matrix, in place if infl == w.
 constexpr int IROWS = 4;
+typedef float infl_f4 __attribute__((ext_vector_type(4)));
+typedef long long infl_l2 __attribute__((ext_vector_type(2)));
+// Round 4: at BASELINE's shape (256 x 10000, 20.6 MB) the kernel is a handful of memory latencies
+// long, and the first version spent most of them in its prologue -- per row a scalar load of qy[b], a wait, a
+// (conditional) scalar load of probs[b, qy_b], a wait: eight dependent round trips in front of the first vector load.
+// Now the first chunk's label and weight loads are issued at the top, the IROWS labels of the query rows come with one
+// load, the IROWS probabilities with independent unconditional loads (index clamped, value selected afterwards), so the
+// prologue is two overlapped round trips under the weights' own latency; weights and influences are streamed with
+// non-temporal accesses (read once / written once).
 template <bool SCORES>
 __global__ __launch_bounds__(256) void nw_influence_kernel(
     const float* __restrict__ probs, const int64_t* __restrict__ qy, const float* w,
@@ -36,39 +45,61 @@ __global__ __launch_bounds__(256) void nw_influence_kernel(
     const int64_t b0 = (int64_t)blockIdx.y * IROWS;
     const int64_t n4 = N >> 2;
     const bool vec = ((N & 3) == 0) && (((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(infl)) & 15) == 0);
+    const bool full = b0 + IROWS <= B;            // (the last row group of a batch may be short)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    infl_l2 ya = {0, 0}, yb = {0, 0};
+    infl_f4 v[IROWS];
+    auto load_chunk = [&](int64_t jj) {
+        const infl_l2* y = reinterpret_cast<const infl_l2*>(sy + 4 * jj);
+        ya = y[0];
+        yb = y[1];
+#pragma unroll
+        for (int r = 0; r < IROWS; ++r)
+            if (full || b0 + r < B) v[r] = __builtin_nontemporal_load(reinterpret_cast<const infl_f4*>(w + (b0 + r) * N) + jj);
+    };
+    // program order = issue order: the rows' labels (scalar loads), the first chunk (vector loads, independent of them),
+    // then the probabilities, whose addresses need the labels.  (Loading the IROWS rows of `probs` whole and handing
+    // p = probs[b, qy_b] over through LDS removes the dependent load, but every column block re-reads the rows -- 10 %
+    // more bytes at 256 x 10000 x 200: 6.2 us against 5.8.)
     int64_t q[IROWS];
     float p[IROWS], l[IROWS];
 #pragma unroll
+    for (int r = 0; r < IROWS; ++r) q[r] = qy[full ? b0 + r : min(b0 + r, B - 1)];
+    bool have = vec && j < n4;
+    if (have) load_chunk(j);
+#pragma unroll
     for (int r = 0; r < IROWS; ++r) {
-        const int64_t b = min(b0 + r, B - 1);
-        q[r] = qy[b];
-        const float pv = ((uint64_t)q[r] < (uint64_t)C) ? probs[b * C + q[r]] : (SCORES ? -INFINITY : 0.f);
-        p[r] = SCORES ? expf(pv) : pv;
+        const int64_t b = full ? b0 + r : min(b0 + r, B - 1);
+        const bool ok = (uint64_t)q[r] < (uint64_t)C;
+        const float pv = probs[b * C + (ok ? q[r] : 0)];       // always loaded: four independent loads, one wait
+        const float pe = ok ? pv : (SCORES ? -INFINITY : 0.f);
+        p[r] = SCORES ? expf(pe) : pe;
         l[r] = SCORES ? lse[b] : 0.f;
     }
     if (vec) {
-        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
-            const int64_t* y = sy + 4 * j;
-            const int64_t y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
-            float4 v[IROWS];
-#pragma unroll
-            for (int r = 0; r < IROWS; ++r)
-                if (b0 + r < B) v[r] = reinterpret_cast<const float4*>(w + (b0 + r) * N)[j];
+        while (have) {
+            infl_f4 o[IROWS];
 #pragma unroll
             for (int r = 0; r < IROWS; ++r) {
-                if (b0 + r >= B) continue;
-                float4 x = v[r];
-                if (SCORES) x = make_float4(expf(x.x - l[r]), expf(x.y - l[r]), expf(x.z - l[r]), expf(x.w - l[r]));
-                float4 o;
-                o.x = infl_one(p[r], x.x, y0 == q[r]);
-                o.y = infl_one(p[r], x.y, y1 == q[r]);
-                o.z = infl_one(p[r], x.z, y2 == q[r]);
-                o.w = infl_one(p[r], x.w, y3 == q[r]);
-                reinterpret_cast<float4*>(infl + (b0 + r) * N)[j] = o;
+                if (!(full || b0 + r < B)) continue;
+                infl_f4 x = v[r];
+                if (SCORES) x = infl_f4{expf(x[0] - l[r]), expf(x[1] - l[r]), expf(x[2] - l[r]), expf(x[3] - l[r])};
+                o[r][0] = infl_one(p[r], x[0], ya[0] == q[r]);
+                o[r][1] = infl_one(p[r], x[1], ya[1] == q[r]);
+                o[r][2] = infl_one(p[r], x[2], yb[0] == q[r]);
+                o[r][3] = infl_one(p[r], x[3], yb[1] == q[r]);
             }
+            const int64_t jc = j;
+            j += stride;
+            have = j < n4;
+            if (have) load_chunk(j);              // (N > 65536: more than one chunk per thread)
+#pragma unroll
+            for (int r = 0; r < IROWS; ++r)
+                if (full || b0 + r < B) __builtin_nontemporal_store(o[r], reinterpret_cast<infl_f4*>(infl + (b0 + r) * N) + jc);
         }
     } else {
-        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < N; j += (int64_t)gridDim.x * 256) {
+        for (; j < N; j += stride) {
             const int64_t y = sy[j];
 #pragma unroll
             for (int r = 0; r < IROWS; ++r) {
