@@ -361,8 +361,21 @@ int nw_conv2d_nhwc_f16x2(const float *x, const float *amax_in, const float *w_sp
 /* moments (nullable, Cin % 32 == 0): the convolution also leaves BatchNorm's batch statistics of y, so the BatchNorm that
  * follows (model/densenet.py:33-60: conv1 -> norm2; the next layers' norm1 over conv2's channels) needs no pass over y:
  * per group g of output pixels and channel co, moments[(k G + g) Cout + co] = k 0: pixels in the group, 1: their mean,
- * 2: the sum of squared deviations from it; G = nw_conv2d_nhwc_moments_groups(same shape arguments) groups (3 G Cout
- * floats), merged by nw_bn_nhwc_moments_from_partials_f32. */
+ * 2: the sum of squared deviations from it, 3: their minimum, 4: their maximum; G = nw_conv2d_nhwc_moments_groups(same shape
+ * arguments) groups (5 G Cout floats), merged by nw_bn_nhwc_moments_from_partials_f32 / nw_bn_nhwc_prep_from_partials_f32. */
+/* Round 4 -- BatchNorm + ReLU in front of a convolution, applied by the convolution's loaders on the way into LDS
+ * (model/densenet.py:36-45: norm1 -> relu1 -> conv1, norm2 -> relu2 -> conv2 without the tensors in between;
+ * :86-90 likewise): y = conv(relu((x - mean) a + beta)), a = gamma / sqrt(var + eps).
+ *   pre      3 Cin floats: mean | a | beta of the Cin channels the convolution reads (nw_bn_nhwc_prep_f32 /
+ *            nw_bn_nhwc_prep_from_partials_f32 make it; an inference caller fills it from the running statistics)
+ *   amax_in  bounds |relu((x - mean) a + beta)| (the same two entries leave the exact bound; any upper bound is legal)
+ *   bias / relu: the inference epilogue (a folded BatchNorm behind the convolution); moments: as nw_conv2d_nhwc_f16x2.
+ * `moments` of this and of nw_conv2d_nhwc_f16x2 hold FIVE rows per group since round 4: count, mean, M2, minimum,
+ * maximum (5 G Cout floats). */
+int nw_conv2d_nhwc_bnrelu_f16x2(const float *x, const float *pre, const float *amax_in, const float *w_split,
+                                const float *w_scale, const float *bias, int relu, float *y, float *amax_out, int64_t n,
+                                int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                                int64_t pad, int64_t ldx, int64_t ldy, float *moments, void *stream);
 int64_t nw_conv2d_nhwc_moments_groups(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                                       int64_t stride, int64_t pad);
 /* The data gradient of a convolution whose input was relu(batch_norm(x)) (model/densenet.py:33-60: norm - relu - conv):
@@ -447,6 +460,8 @@ typedef struct nw_wgrad_job {
     float *dw;
     int64_t n, H, W, Cin, Cout, KH, KW, stride, pad, ldx, ldg;
     int64_t out_oihw;   /* != 0: dw in torch's contiguous (Cout, Cin, KH, KW) layout instead of (Cout, KH, KW, Cin) */
+    const float *pre_x; /* nullable: 3 Cin floats mean | a | beta -- the x operand is relu((x - mean) a + beta), as the forward
+                           convolution read it (nw_conv2d_nhwc_bnrelu_f16x2); amax_x then bounds THAT tensor */
 } nw_wgrad_job;
 size_t nw_conv2d_nhwc_wgrad_batch_workspace_bytes(const nw_wgrad_job *jobs, int64_t njobs);
 int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job *jobs, int64_t njobs, void *workspace, size_t workspace_bytes,
@@ -479,6 +494,33 @@ int nw_bn_nhwc_moments_f32(const float *x, int64_t ldx, int64_t rows, int64_t c,
                            float *var, void *workspace, size_t workspace_bytes, void *stream);
 int nw_bn_nhwc_moments_from_partials_f32(float *partials, int64_t groups, int64_t c, float eps, float *mean,
                                          float *invstd, float *var, void *stream);
+/* Round 4: what a convolution that applies the BatchNorm itself needs (nw_conv2d_nhwc_bnrelu_f16x2).
+ *   nw_bn_nhwc_moments_minmax_f32        nw_bn_nhwc_moments_f32 + every channel's minimum and maximum
+ *                                        (workspace: nw_bn_nhwc_minmax_workspace_bytes)
+ *   nw_bn_nhwc_prep_from_partials_f32    statistics (mean, invstd, var, vmin, vmax) from a convolution's 5-row `moments`
+ *                                        and, with gamma != NULL, the table `tab` (3 c floats mean | a | beta), the exact
+ *                                        bound on |act((x - mean) a + beta)| as an amax record, the layer's running
+ *                                        statistics (nullable) and step counter (nullable), in the same launch
+ *   nw_bn_nhwc_prep_f32                  the table and bound from statistics that exist (rows = samples per channel) */
+int nw_bn_nhwc_moments_minmax_f32(const float *x, int64_t ldx, int64_t rows, int64_t c, float eps, float *mean, float *invstd,
+                                  float *var, float *vmin, float *vmax, void *workspace, size_t workspace_bytes, void *stream);
+size_t nw_bn_nhwc_minmax_workspace_bytes(int64_t rows, int64_t c);
+int nw_bn_nhwc_prep_from_partials_f32(float *partials, int64_t groups, int64_t c, float eps, float *mean, float *invstd,
+                                      float *var, float *vmin, float *vmax, const float *gamma, const float *beta,
+                                      float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
+                                      int relu, float *tab, float *amax_out, void *stream);
+/* ... the same where the fresh channels are a WINDOW [offset, offset + c) of wider statistics arrays (a dense block's slab:
+ * mean .. vmax are the slab-wide arrays) and the BatchNorm to prepare (gamma, beta, running statistics: offset + c channels) also
+ * reads the n_old <= offset channels in front of it, whose statistics exist: one launch does both (rows: samples per channel). */
+int nw_bn_nhwc_prep_window_from_partials_f32(float *partials, int64_t groups, int64_t c, int64_t offset, int64_t n_old, int64_t rows,
+                                             float eps, float *mean, float *invstd, float *var, float *vmin, float *vmax,
+                                             const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                             int64_t *num_batches_tracked, float momentum, int relu, float *tab, float *amax_out,
+                                             void *stream);
+int nw_bn_nhwc_prep_f32(const float *mean, const float *invstd, const float *var, const float *vmin, const float *vmax,
+                        const float *gamma, const float *beta, float *running_mean, float *running_var,
+                        int64_t *num_batches_tracked, float momentum, int relu, int64_t rows, int64_t c, float *tab,
+                        float *amax_out, void *stream);
 int nw_bn_relu_nhwc_apply_f32(const float *x, int64_t ldx, const float *mean, const float *invstd, const float *var,
                               const float *gamma, const float *beta, float *running_mean, float *running_var,
                               int64_t *num_batches_tracked, float momentum, float *y, float *amax_out, int64_t rows,

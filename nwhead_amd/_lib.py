@@ -63,6 +63,14 @@ SIGNATURES = {
                                                            _i64, _p]),
     "nw_bn_nhwc_moments_f32": (_int, [_p, _i64, _i64, _i64, C.c_float, _p, _p, _p, _p, _sz, _p]),
     "nw_bn_nhwc_moments_from_partials_f32": (_int, [_p, _i64, _i64, C.c_float, _p, _p, _p, _p]),
+    "nw_bn_nhwc_moments_minmax_f32": (_int, [_p, _i64, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "nw_bn_nhwc_minmax_workspace_bytes": (_sz, [_i64, _i64]),
+    "nw_bn_nhwc_prep_from_partials_f32": (_int, [_p, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_float, _int,
+                                                 _p, _p, _p]),
+    "nw_bn_nhwc_prep_window_from_partials_f32": (_int, [_p, _i64, _i64, _i64, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                                        _p, C.c_float, _int, _p, _p, _p]),
+    "nw_bn_nhwc_prep_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_float, _int, _i64, _i64, _p, _p, _p]),
+    "nw_conv2d_nhwc_bnrelu_f16x2": (_int, [_p] * 6 + [_int, _p, _p] + [_i64] * 11 + [_p, _p]),
     "nw_bn_relu_nhwc_apply_f32": (_int, [_p, _i64] + [_p] * 8 + [C.c_float, _p, _p, _i64, _i64, _int, _p]),
     "nw_split_conv_weights_f16x2": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "nw_conv2d_nhwc_wgrad_supported": (_int, [_i64] * 9),
@@ -119,7 +127,8 @@ def load():
 class WgradJob(C.Structure):
     """nw_wgrad_job (include/nwhead_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("amax_x", C.c_void_p), ("gy", C.c_void_p), ("amax_g", C.c_void_p), ("dw", C.c_void_p)] + \
-               [(k, C.c_int64) for k in ("n", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "ldx", "ldg", "out_oihw")]
+               [(k, C.c_int64) for k in ("n", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "ldx", "ldg", "out_oihw")] + \
+               [("pre_x", C.c_void_p)]
 
 
 class SgdParam(C.Structure):

@@ -40,14 +40,16 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 }
 
 // partial moments of rows [r0, r1) for the 64 channels of tile blockIdx.y: part[(k * G + g) * C + c], k = 0 count, 1 mean, 2 M2
+// mm != 0: also k = 3 minimum, 4 maximum of the chunk (what a consumer that applies BatchNorm + ReLU on the fly needs to bound it)
 __global__ __launch_bounds__(1024) void nw_bn_nhwc_stats_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ part,
-                                                                 int64_t R, int C, int G, int64_t rows_per_chunk) {
+                                                                 int64_t R, int C, int G, int64_t rows_per_chunk, int mm) {
     __shared__ float sh[3][BN_RL][BN_TC + 1];
     const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
     const int c0 = blockIdx.y * BN_TC + 4 * cq;
     const int g = blockIdx.x;
     const int64_t r0 = (int64_t)g * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
     float n = 0.f, K[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float vlo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, vhi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     if (c0 < C) {
         int64_t r = r0 + rl;
         if (r < r1) {   // the shift: this thread's first value per channel
@@ -57,10 +59,13 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_stats_kernel(const float* __r
         for (; r < r1; r += BN_RL) {
             const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c0);
             const float d[4] = {v.x - K[0], v.y - K[1], v.z - K[2], v.w - K[3]};
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 s1[j] += d[j];
                 s2[j] = __builtin_fmaf(d[j], d[j], s2[j]);
+                vlo[j] = fminf(vlo[j], vv[j]);
+                vhi[j] = fmaxf(vhi[j], vv[j]);
             }
             n += 1.f;
         }
@@ -89,6 +94,18 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_stats_kernel(const float* __r
         part[((int64_t)1 * G + g) * C + cc] = mean;
         part[((int64_t)2 * G + g) * C + cc] = m2;
     }
+    if (!mm) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[0][rl][4 * cq + j] = vlo[j]; sh[1][rl][4 * cq + j] = vhi[j]; }
+    __syncthreads();
+    if (tid < BN_TC && blockIdx.y * BN_TC + tid < C) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int l = 0; l < BN_RL; ++l) { lo = fminf(lo, sh[0][l][tid]); hi = fmaxf(hi, sh[1][l][tid]); }
+        const int cc = blockIdx.y * BN_TC + tid;
+        part[((int64_t)3 * G + g) * C + cc] = lo;
+        part[((int64_t)4 * G + g) * C + cc] = hi;
+    }
 }
 
 // Merge of the G chunk moments: 64 channels x 16 chunk lanes per workgroup -- lane j merges the chunks j, j + 16, ... of
@@ -97,8 +114,10 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_finalize_kernel(const float* 
                                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                     float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                                     int64_t* __restrict__ num_batches_tracked, float momentum, float eps,
-                                                                    float* __restrict__ save_var) {
+                                                                    float* __restrict__ save_var, float* __restrict__ save_min = nullptr,
+                                                                    float* __restrict__ save_max = nullptr) {
     __shared__ float sh[3][16][64];
+    __shared__ float shm[2][16][64];
     const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
@@ -107,9 +126,24 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_finalize_kernel(const float* 
         for (int g = j; g < G; g += 16)
             chan_merge(n, mean, m2, part[(int64_t)g * C + c], part[((int64_t)G + g) * C + c], part[((int64_t)2 * G + g) * C + c]);
     sh[0][j][cl] = n; sh[1][j][cl] = mean; sh[2][j][cl] = m2;
+    if (save_min) {   // (the statistics pass left rows 3 and 4: nw_bn_nhwc_stats_kernel's mm)
+        float lo = INFINITY, hi = -INFINITY;
+        if (c < C)
+            for (int g = j; g < G; g += 16) {
+                lo = fminf(lo, part[((int64_t)3 * G + g) * C + c]);
+                hi = fmaxf(hi, part[((int64_t)4 * G + g) * C + c]);
+            }
+        shm[0][j][cl] = lo; shm[1][j][cl] = hi;
+    }
     __syncthreads();
     if (j != 0 || c >= C) return;
     for (int k = 1; k < 16; ++k) chan_merge(n, mean, m2, sh[0][k][cl], sh[1][k][cl], sh[2][k][cl]);
+    if (save_min) {
+        float lo = shm[0][0][cl], hi = shm[1][0][cl];
+        for (int k = 1; k < 16; ++k) { lo = fminf(lo, shm[0][k][cl]); hi = fmaxf(hi, shm[1][k][cl]); }
+        save_min[c] = lo;
+        save_max[c] = hi;
+    }
     const float var = n > 0.f ? fmaxf(m2 / n, 0.f) : 0.f;
     save_mean[c] = mean;
     save_invstd[c] = 1.f / sqrtf(var + eps);
@@ -124,9 +158,26 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_finalize_kernel(const float* 
 // lane over groups j, j + 256, ... and over the lanes in a fixed order (deterministic).  (Chan's pairwise merge of
 // nw_bn_nhwc_finalize_kernel is a serial chain per lane: fine for <= 256 chunks, 130 dependent steps at 2058 groups; a
 // first version with 16 channels x 64 lanes per workgroup ran on C / 16 = 2..8 CUs: 26 us on the 56 x 56 layers.)
+// Round 4: the groups may carry minima and maxima too (rows 3, 4: save_min / save_max), and the BatchNorm that reads this tensor
+// next can be PREPARED here (prep.tab != nullptr): its per-channel table mean | a | beta for the convolution that applies it in
+// its loaders (conv_nhwc.hip's ConvP::pre), the exact bound on |act((x - mean) a + beta)| as slot blockIdx.x of an amax record,
+// its running statistics and step counter.
+struct BnPrep {
+    const float* gamma; const float* beta;
+    float* tab;              // [3][C]
+    float* amax;             // BN_SLOTS floats
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    float momentum; int relu;
+};
+// bound of act((x - mean) a + beta) over x in [lo, hi]: the map is monotone in x, and computed exactly as the loaders compute it
+__device__ __forceinline__ float prep_bound(float lo, float hi, float mean, float a, float b, int relu) {
+    const float u = __builtin_fmaf(lo - mean, a, b), v = __builtin_fmaf(hi - mean, a, b);
+    return relu ? fmaxf(fmaxf(u, v), 0.f) : fmaxf(fabsf(u), fabsf(v));
+}
 __global__ __launch_bounds__(1024) void nw_bn_nhwc_merge_groups_kernel(const float* __restrict__ part, int G, int C, float eps,
                                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                                        float* __restrict__ save_var) {
+                                                                        float* __restrict__ save_var, float* __restrict__ save_min,
+                                                                        float* __restrict__ save_max, const BnPrep prep) {
     __shared__ float4 sh[1024];
     const int t = threadIdx.x;
     const int c0 = blockIdx.x * 4;                               // this workgroup's four channels (C % 4 == 0)
@@ -163,15 +214,215 @@ __global__ __launch_bounds__(1024) void nw_bn_nhwc_merge_groups_kernel(const flo
         q.z += __builtin_fmaf(n.z * dz, dz, m2.z); q.w += __builtin_fmaf(n.w * dw, dw, m2.w);
     }
     const float4 tq = block_sum4(q);
+    float4 tlo = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), thi = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (save_min) {
+        for (int g = t; g < G; g += 1024) {
+            const float4 a = *reinterpret_cast<const float4*>(part + ((int64_t)3 * G + g) * C + c0);
+            const float4 b = *reinterpret_cast<const float4*>(part + ((int64_t)4 * G + g) * C + c0);
+            tlo = make_float4(fminf(tlo.x, a.x), fminf(tlo.y, a.y), fminf(tlo.z, a.z), fminf(tlo.w, a.w));
+            thi = make_float4(fmaxf(thi.x, b.x), fmaxf(thi.y, b.y), fmaxf(thi.z, b.z), fmaxf(thi.w, b.w));
+        }
+        auto block_ext4 = [&](float4 v, bool mx) {
+            __syncthreads();
+            sh[t] = v;
+            __syncthreads();
+            for (int w = 512; w > 0; w >>= 1) {
+                if (t < w) {
+                    const float4 a = sh[t], b = sh[t + w];
+                    sh[t] = mx ? make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w))
+                               : make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w));
+                }
+                __syncthreads();
+            }
+            return sh[0];
+        };
+        tlo = block_ext4(tlo, false);
+        thi = block_ext4(thi, true);
+    }
     if (t != 0) return;
     const float mn[4] = {mean.x, mean.y, mean.z, mean.w}, nn[4] = {tn.x, tn.y, tn.z, tn.w}, qq[4] = {tq.x, tq.y, tq.z, tq.w};
+    const float lo4[4] = {tlo.x, tlo.y, tlo.z, tlo.w}, hi4[4] = {thi.x, thi.y, thi.z, thi.w};
+    float bound = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float var = nn[k] > 0.f ? fmaxf(qq[k] / nn[k], 0.f) : 0.f;
+        const float inv = 1.f / sqrtf(var + eps);
         save_mean[c0 + k] = mn[k];
-        save_invstd[c0 + k] = 1.f / sqrtf(var + eps);
+        save_invstd[c0 + k] = inv;
         save_var[c0 + k] = var;
+        if (save_min) { save_min[c0 + k] = lo4[k]; save_max[c0 + k] = hi4[k]; }
+        if (prep.tab) {
+            const int c = c0 + k;
+            const float a = prep.gamma[c] * inv, b = prep.beta[c];
+            prep.tab[c] = mn[k];
+            prep.tab[C + c] = a;
+            prep.tab[2 * C + c] = b;
+            bound = fmaxf(bound, prep_bound(lo4[k], hi4[k], mn[k], a, b, prep.relu));
+            if (prep.running_mean) prep.running_mean[c] = (1.f - prep.momentum) * prep.running_mean[c] + prep.momentum * mn[k];
+            if (prep.running_var)
+                prep.running_var[c] = (1.f - prep.momentum) * prep.running_var[c] + prep.momentum * var * (nn[k] > 1.f ? nn[k] / (nn[k] - 1.f) : 1.f);
+        }
     }
+    if (prep.tab) {
+        if (prep.num_batches_tracked && blockIdx.x == 0) *prep.num_batches_tracked += 1;
+        if (prep.amax)
+            for (int k = blockIdx.x; k < BN_SLOTS; k += gridDim.x) prep.amax[k] = k == (int)blockIdx.x ? bound : 0.f;
+    }
+}
+
+// The same preparation from statistics that exist already (a dense block's slab channels: one layer's norm1 after another
+// reads them, each with its own gamma / beta): 256 channels per workgroup.
+__global__ __launch_bounds__(256) void nw_bn_nhwc_prep_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ var, const float* __restrict__ vmin,
+                                                              const float* __restrict__ vmax, int C, float unbias, const BnPrep prep) {
+    __shared__ float red[8];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float bound = 0.f;
+    if (c < C) {
+        const float m = mean[c], a = prep.gamma[c] * invstd[c], b = prep.beta[c];
+        prep.tab[c] = m;
+        prep.tab[C + c] = a;
+        prep.tab[2 * C + c] = b;
+        bound = prep_bound(vmin[c], vmax[c], m, a, b, prep.relu);
+        if (prep.running_mean) prep.running_mean[c] = (1.f - prep.momentum) * prep.running_mean[c] + prep.momentum * m;
+        if (prep.running_var) prep.running_var[c] = (1.f - prep.momentum) * prep.running_var[c] + prep.momentum * var[c] * unbias;
+    }
+    if (prep.num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *prep.num_batches_tracked += 1;
+    bound = block_max(bound, red);
+    if (prep.amax && (int)threadIdx.x % (int)gridDim.x == (int)blockIdx.x) prep.amax[threadIdx.x] = threadIdx.x == blockIdx.x ? bound : 0.f;
+}
+
+// Merge + preparation in ONE launch of 256-thread workgroups (round 4; the first version -- nw_bn_nhwc_merge_groups_kernel with
+// its five 1024-thread tree reductions over uncoalesced float4 gathers and a one-thread tail of dependent loads, then
+// nw_bn_nhwc_prep_kernel -- cost 13.7 + 7.9 us per BatchNorm, 1.9 ms per K4 step):
+//   workgroups [0, ceil(C / 64)): up to 64 channels each of the tensor a convolution has just written.  Thread (quad q, lane j)
+//     merges the groups j, j + GL, ... of its four channels (coalesced rows; Chan's merge, minima, maxima) in ONE pass, the GL
+//     lane results of a channel are merged in lane order by the thread that owns the channel -- which requested gamma, beta and
+//     the running statistics at the top of the kernel;
+//   workgroups behind them: channels [0, nold) whose statistics exist already, 256 per workgroup.
+// The statistics go to entries [off, off + C) of the arrays (a dense block's slab-wide ones, or a tensor's own with off = 0);
+// with prep.tab != nullptr every workgroup also writes its channels' entries of the NEXT BatchNorm's table (row stride tc:
+// mean | a | beta) and its bound into its slots of the amax record.
+struct MergeP {
+    const float* part; int G, C, off;
+    float eps;
+    float *mean, *invstd, *var, *vmin, *vmax;     // statistics arrays (entries [off, off + C) written, [0, nold) read)
+    int nold, tc;
+    float unbias_old;                             // rows / (rows - 1) for the old channels' running variance
+    BnPrep prep;
+};
+__global__ __launch_bounds__(1024) void nw_bn_nhwc_merge_prep_kernel(const MergeP p) {
+    // 16 channels per workgroup of 1024 threads: thread t = 4 j + q reads float4 quad q of the groups j, j + 256, ... (a wave-
+    // instruction covers 16 rows x 64 contiguous bytes; the partials are ~1/3 of the tensor the convolution wrote, so the
+    // lanes in flight matter: 256 threads x 64 channels took 18 us, one wave per quad -- 64 rows per instruction -- 14 us).
+    // Lane sums by shuffles inside a wave, the 16 waves' results through LDS; two passes of plain sums (Chan's pairwise merge
+    // needs a division per step): the weighted mean, then sum(M2_g + n_g (mean_g - mean)^2) with the minima and maxima.
+    __shared__ float sh[5][16][17];
+    __shared__ float redb[16], redm[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const BnPrep& pr = p.prep;
+    const int nm = (p.C + 15) >> 4;
+    float bound = 0.f;
+    if (pr.tab && pr.num_batches_tracked && blockIdx.x == 0 && t == 0) *pr.num_batches_tracked += 1;
+    if ((int)blockIdx.x < nm) {
+        const int cb = blockIdx.x * 16;
+        const int nch = min(16, p.C - cb);
+        const float* part = p.part;
+        const int G = p.G, C = p.C;
+        float f_gamma = 1.f, f_beta = 0.f, f_rm = 0.f, f_rv = 0.f;
+        const float Kc_ = t < nch ? part[(int64_t)G * C + cb + t] : 0.f;   // group 0's mean of channel t: the shift (below)
+        if (t < nch && pr.tab) {
+            const int c = p.off + cb + t;
+            f_gamma = pr.gamma[c];
+            f_beta = pr.beta[c];
+            if (pr.running_mean) f_rm = pr.running_mean[c];
+            if (pr.running_var) f_rv = pr.running_var[c];
+        }
+        const int q = t & 3, j = t >> 2;
+        const bool live = 4 * q < nch;
+        // sums over the lanes with equal (lane & 3): two DPP row rotations inside each row of 16, then the four rows by permlane
+        // swaps -- VALU only (as 80 ds_bpermute per thread the reductions alone were ~2 us of LDS traffic)
+        auto ror = [](float x, auto ctl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctl)::value, 0xf, 0xf, false));
+        };
+        using R8 = std::integral_constant<int, 0x128>;
+        using R4 = std::integral_constant<int, 0x124>;
+        auto xsum = [&](float v) { v += ror(v, R8{}); v += ror(v, R4{}); return group4_sum(v); };
+        auto xmin = [&](float v) { v = fminf(v, ror(v, R8{})); v = fminf(v, ror(v, R4{})); return group4_min(v); };
+        auto xmax = [&](float v) { v = fmaxf(v, ror(v, R8{})); v = fmaxf(v, ror(v, R4{})); return group4_max(v); };
+        // ONE pass (the partials come from another XCD's L2 through memory: every dependent round of loads is ~2 us):
+        // sums shifted by K = the mean of group 0 -- a group mean lies within a fraction of sigma of the batch mean, so
+        // var = (S2 - S1^2 / N) / N loses nothing to cancellation -- with the minima and maxima in the same loop
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        float lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        float K[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const float4 k4 = *reinterpret_cast<const float4*>(part + (int64_t)G * C + cb + 4 * q);
+            K[0] = k4.x; K[1] = k4.y; K[2] = k4.z; K[3] = k4.w;
+#pragma unroll 4
+            for (int g = j; g < G; g += 256) {
+                const float* row = part + (int64_t)g * C + cb + 4 * q;
+                const float4 a = *reinterpret_cast<const float4*>(row);
+                const float4 b = *reinterpret_cast<const float4*>(row + (int64_t)G * C);
+                const float4 c2 = *reinterpret_cast<const float4*>(row + (int64_t)2 * G * C);
+                const float4 d = *reinterpret_cast<const float4*>(row + (int64_t)3 * G * C);
+                const float4 e = *reinterpret_cast<const float4*>(row + (int64_t)4 * G * C);
+                const float an[4] = {a.x, a.y, a.z, a.w}, bm[4] = {b.x, b.y, b.z, b.w}, cc[4] = {c2.x, c2.y, c2.z, c2.w};
+                const float dl[4] = {d.x, d.y, d.z, d.w}, eh[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dd = bm[k] - K[k], nd = an[k] * dd;
+                    s0[k] += an[k];
+                    s1[k] += nd;
+                    s2[k] += __builtin_fmaf(nd, dd, cc[k]);
+                    lo[k] = fminf(lo[k], dl[k]);
+                    hi[k] = fmaxf(hi[k], eh[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = xsum(s0[k]), b = xsum(s1[k]), c3 = xsum(s2[k]), d = xmin(lo[k]), e = xmax(hi[k]);
+            if (lane < 4) { sh[0][w][4 * q + k] = a; sh[1][w][4 * q + k] = b; sh[2][w][4 * q + k] = c3; sh[3][w][4 * q + k] = d; sh[4][w][4 * q + k] = e; }
+        }
+        __syncthreads();
+        if (t < nch) {
+            float n0 = 0.f, t1 = 0.f, t2 = 0.f, lo1 = INFINITY, hi1 = -INFINITY;
+            for (int l = 0; l < 16; ++l) {
+                n0 += sh[0][l][t]; t1 += sh[1][l][t]; t2 += sh[2][l][t];
+                lo1 = fminf(lo1, sh[3][l][t]);
+                hi1 = fmaxf(hi1, sh[4][l][t]);
+            }
+            const float Kc = Kc_;                                  // (the same value every lane of the channel used)
+            const float dm = n0 > 0.f ? t1 / n0 : 0.f;
+            const float mn = Kc + dm;
+            const float var = n0 > 0.f ? fmaxf((t2 - dm * t1) / n0, 0.f) : 0.f;
+            const float nn = n0;
+            const int c = p.off + cb + t;
+            const float inv = 1.f / sqrtf(var + p.eps);
+            p.mean[c] = mn; p.invstd[c] = inv; p.var[c] = var; p.vmin[c] = lo1; p.vmax[c] = hi1;
+            if (pr.tab) {
+                const float a = f_gamma * inv;
+                pr.tab[c] = mn; pr.tab[p.tc + c] = a; pr.tab[2 * p.tc + c] = f_beta;
+                bound = prep_bound(lo1, hi1, mn, a, f_beta, pr.relu);
+                if (pr.running_mean) pr.running_mean[c] = (1.f - pr.momentum) * f_rm + pr.momentum * mn;
+                if (pr.running_var) pr.running_var[c] = (1.f - pr.momentum) * f_rv + pr.momentum * var * (nn > 1.f ? nn / (nn - 1.f) : 1.f);
+            }
+        }
+    } else if (pr.tab) {
+        const int c = ((int)blockIdx.x - nm) * 1024 + t;
+        if (c < p.nold) {
+            const float m = p.mean[c], a = pr.gamma[c] * p.invstd[c], b = pr.beta[c];
+            pr.tab[c] = m; pr.tab[p.tc + c] = a; pr.tab[2 * p.tc + c] = b;
+            bound = prep_bound(p.vmin[c], p.vmax[c], m, a, b, pr.relu);
+            if (pr.running_mean) pr.running_mean[c] = (1.f - pr.momentum) * pr.running_mean[c] + pr.momentum * m;
+            if (pr.running_var) pr.running_var[c] = (1.f - pr.momentum) * pr.running_var[c] + pr.momentum * p.var[c] * p.unbias_old;
+        }
+    }
+    if (!pr.tab) return;
+    bound = block_max(bound, redb);
+    // the record's slots b, b + g, ... belong to workgroup b of g: its bound in the first, zeros in the others, one store per thread
+    if (pr.amax && t < BN_SLOTS && t % (int)gridDim.x == (int)blockIdx.x) pr.amax[t] = t == (int)blockIdx.x ? bound : 0.f;
 }
 
 // y[r][c] = act((x[r][c] - mean[c]) a[c] + beta[c]), a = gamma invstd; amax record of y
@@ -439,7 +690,7 @@ extern "C" int nw_bn_relu_nhwc_train_fwd_f32(const float* x, int64_t ldx, const 
     stats_grid(rows, c, &G, &rpc);
     float* part = static_cast<float*>(workspace);
     const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
-    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, part, rows, (int)c, G, rpc);
+    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, part, rows, (int)c, G, rpc, 0);
     hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, running_mean,
                        running_var, save_mean, save_invstd, num_batches_tracked, momentum, eps, (float*)nullptr);
     const int ag = apply_grid(rows, c);
@@ -470,7 +721,7 @@ extern "C" int nw_bn_nhwc_moments_f32(const float* x, int64_t ldx, int64_t rows,
     stats_grid(rows, c, &G, &rpc);
     float* part = static_cast<float*>(workspace);
     const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
-    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, part, rows, (int)c, G, rpc);
+    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, part, rows, (int)c, G, rpc, 0);
     hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, (float*)nullptr,
                        (float*)nullptr, mean, invstd, (int64_t*)nullptr, 0.f, eps, var);
     NW_CHECK_LAUNCH();
@@ -485,7 +736,92 @@ extern "C" int nw_bn_nhwc_moments_from_partials_f32(float* partials, int64_t gro
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (c % 4 || (reinterpret_cast<uintptr_t>(partials) & 15)) return NW_ERR_INVALID_ARG;
     hipLaunchKernelGGL(nw_bn_nhwc_merge_groups_kernel, dim3((unsigned)(c / 4)), dim3(1024), 0, st, partials, (int)groups, (int)c, eps,
-                       mean, invstd, var);
+                       mean, invstd, var, (float*)nullptr, (float*)nullptr, BnPrep{});
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+// ---- round 4: BatchNorm + ReLU applied by the consuming convolution's loaders (nw_conv2d_nhwc_bnrelu_f16x2).  These entries
+// produce what it takes: the per-channel table mean | a | beta (3 c floats) and the amax record bounding |relu(bn(x))|, from
+// statistics that include each channel's minimum and maximum.
+static bool prep_args_ok(const float* gamma, const float* beta, float* tab, float* amax) {
+    return gamma && beta && tab && amax && !nw::bad_align(tab, amax);
+}
+extern "C" int nw_bn_nhwc_moments_minmax_f32(const float* x, int64_t ldx, int64_t rows, int64_t c, float eps, float* mean,
+                                             float* invstd, float* var, float* vmin, float* vmax, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    using namespace nw;
+    if (rows <= 0 || c <= 0 || c % 4 || ldx < c || ldx % 4) return NW_ERR_INVALID_ARG;
+    if (!x || !mean || !invstd || !var || !vmin || !vmax) return NW_ERR_INVALID_ARG;
+    if (bad_align(x, workspace) || bad_align(mean, invstd, var)) return NW_ERR_INVALID_ARG;
+    int G; int64_t rpc;
+    stats_grid(rows, c, &G, &rpc);
+    if (!workspace || workspace_bytes < ((size_t)5 * G * c + 2 * c) * sizeof(float)) return NW_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    const unsigned ct = (unsigned)((c + BN_TC - 1) / BN_TC);
+    hipLaunchKernelGGL(nw_bn_nhwc_stats_kernel, dim3((unsigned)G, ct), dim3(1024), 0, st, x, ldx, part, rows, (int)c, G, rpc, 1);
+    hipLaunchKernelGGL(nw_bn_nhwc_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(1024), 0, st, part, G, (int)c, (float*)nullptr,
+                       (float*)nullptr, mean, invstd, (int64_t*)nullptr, 0.f, eps, var, vmin, vmax);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+extern "C" size_t nw_bn_nhwc_minmax_workspace_bytes(int64_t rows, int64_t c) {
+    if (rows <= 0 || c <= 0) return 0;
+    int G; int64_t rpc;
+    nw::stats_grid(rows, c, &G, &rpc);
+    return ((size_t)5 * G * c + 2 * c) * sizeof(float);
+}
+
+/* partials: 5 rows per group (count, mean, M2, minimum, maximum: what nw_conv2d_nhwc_f16x2 / _bnrelu_f16x2 leave in `moments`).
+ * gamma == NULL: statistics only (mean, invstd, var, vmin, vmax); else also the table and bound of the BatchNorm (gamma, beta)
+ * that reads this tensor next, and that layer's running statistics (nullable) and step counter (nullable). */
+extern "C" int nw_bn_nhwc_prep_window_from_partials_f32(float* partials, int64_t groups, int64_t c, int64_t offset, int64_t n_old,
+                                                        int64_t rows, float eps, float* mean, float* invstd, float* var, float* vmin,
+                                                        float* vmax, const float* gamma, const float* beta, float* running_mean,
+                                                        float* running_var, int64_t* num_batches_tracked, float momentum, int relu,
+                                                        float* tab, float* amax_out, void* stream) {
+    using namespace nw;
+    if (groups <= 0 || groups >= (1LL << 30) || c <= 0 || c % 4 || offset < 0 || n_old < 0 || n_old > offset) return NW_ERR_INVALID_ARG;
+    if (!partials || !mean || !invstd || !var || !vmin || !vmax || (reinterpret_cast<uintptr_t>(partials) & 15)) return NW_ERR_INVALID_ARG;
+    MergeP p{};
+    p.part = partials; p.G = (int)groups; p.C = (int)c; p.off = (int)offset; p.eps = eps;
+    p.mean = mean; p.invstd = invstd; p.var = var; p.vmin = vmin; p.vmax = vmax;
+    p.nold = 0; p.tc = (int)(offset + c);
+    p.unbias_old = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+    int64_t grid = (c + 15) / 16;
+    if (gamma) {
+        if (!prep_args_ok(gamma, beta, tab, amax_out)) return NW_ERR_INVALID_ARG;
+        p.prep = BnPrep{gamma, beta, tab, amax_out, running_mean, running_var, num_batches_tracked, momentum, relu};
+        p.nold = (int)n_old;
+        grid += (n_old + 1023) / 1024;
+        if (grid > BN_SLOTS) return NW_ERR_UNSUPPORTED;         // (one amax slot per workgroup)
+    }
+    hipLaunchKernelGGL(nw_bn_nhwc_merge_prep_kernel, dim3((unsigned)grid), dim3(1024), 0, static_cast<hipStream_t>(stream), p);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+extern "C" int nw_bn_nhwc_prep_from_partials_f32(float* partials, int64_t groups, int64_t c, float eps, float* mean, float* invstd,
+                                                 float* var, float* vmin, float* vmax, const float* gamma, const float* beta,
+                                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                                 float momentum, int relu, float* tab, float* amax_out, void* stream) {
+    return nw_bn_nhwc_prep_window_from_partials_f32(partials, groups, c, 0, 0, 2, eps, mean, invstd, var, vmin, vmax, gamma, beta,
+                                                    running_mean, running_var, num_batches_tracked, momentum, relu, tab, amax_out, stream);
+}
+
+/* the table and bound of a BatchNorm (gamma, beta) over channels whose statistics exist (rows = samples per channel, for the
+ * unbiased running variance) */
+extern "C" int nw_bn_nhwc_prep_f32(const float* mean, const float* invstd, const float* var, const float* vmin, const float* vmax,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float momentum, int relu, int64_t rows, int64_t c, float* tab,
+                                   float* amax_out, void* stream) {
+    using namespace nw;
+    if (c <= 0 || rows <= 0 || !mean || !invstd || !var || !vmin || !vmax || !prep_args_ok(gamma, beta, tab, amax_out)) return NW_ERR_INVALID_ARG;
+    if ((c + 255) / 256 > BN_SLOTS) return NW_ERR_UNSUPPORTED;
+    const BnPrep pr{gamma, beta, tab, amax_out, running_mean, running_var, num_batches_tracked, momentum, relu};
+    const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+    hipLaunchKernelGGL(nw_bn_nhwc_prep_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), mean,
+                       invstd, var, vmin, vmax, (int)c, unbias, pr);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

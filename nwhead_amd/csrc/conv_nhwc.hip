@@ -43,8 +43,12 @@ struct ConvP {
     const float* res;        // nullable (M, Cout)
     float* y;
     float* amax_out;         // nullable: CV_AMAX_SLOTS floats
-    float* moments;          // nullable: per (tile row, wave row) group and output channel the count, mean and M2 of y
-                             //   (part[(k G + group) Cout + co], G = mtiles WN): BatchNorm's statistics of y without a pass over it
+    float* moments;          // nullable: per (tile row, wave row) group and output channel the count, mean, M2, minimum and
+                             //   maximum of y (part[(k G + group) Cout + co], k = 0 .. 4, G = mtiles WN): BatchNorm's statistics
+                             //   of y, and the bound on |relu(bn(y))| its consumer's split needs, without a pass over it
+    const float* pre;        // nullable: [3][Cin] = mean | a | beta -- the convolution reads x' = relu((x - mean) a + beta), a
+                             //   BatchNorm + ReLU applied by the loaders on the way into LDS (round 4: model/densenet.py:36-45's
+                             //   norm1-relu1-conv1 / norm2-relu2-conv2 without the tensors between them); amax_in bounds |x'|
     const float4* zeros;     // 32 bytes of zeros (what a loader reads for a pixel that does not exist)
     // nullable (bnb_part): y is the gradient of relu(batch_norm(bnb_x)) -- the epilogue also leaves, per pixel group and
     // channel, sum g and sum g xhat with g = y [bn(x) > 0]: BatchNorm's backward statistics without a pass over (x, y)
@@ -61,20 +65,23 @@ struct ConvP {
 constexpr int CV_GATHER = 0, CV_PATCH = 1, CV_ROWRUN = 2, CV_ROWRUN4 = 3;
 constexpr int CV_AMAX_SLOTS = 256;   // floats of an `amax` record: one partial maximum per workgroup of its producer
 
-template <int NA, int NB, int WM, int MODE>
+template <int NA, int NB, int WM, int MODE, bool PRE = false>
 struct ConvCfg {
     static constexpr bool PATCH = MODE == CV_PATCH, ROWRUN = MODE == CV_ROWRUN || MODE == CV_ROWRUN4;
+    static_assert(!(PRE && ROWRUN), "the few-channel stems have no BatchNorm in front");
+    static constexpr int NPRE = PRE ? 6 : 0;                      // factor loads per lane per chunk (mean, a, beta of 8 channels)
     static constexpr int WN = 4 / WM;
     static constexpr int BN = 16 * NA * WM, BM = 16 * NB * WN;
     static constexpr int NIW = BN / 32;                           // weight DMAs per loader wave per stage
     static constexpr int EMAX = PATCH ? BM + 192 : BM;            // activation entries (pixels) per buffer
     static constexpr int NPASS = EMAX / 64;
-    static constexpr int NACT = (MODE == CV_ROWRUN ? 8 : 2) * NPASS;   // global loads per lane per chunk
+    static constexpr int NACT = (MODE == CV_ROWRUN ? 8 : 2) * NPASS + NPRE;   // global loads per lane per chunk
     static constexpr int TI = PATCH ? 9 : 1;                      // stages per activation chunk
     // register sets of activation loads in flight: a one-stage chunk (GATHER) needs several to cover the memory latency
     static constexpr int NSET = PATCH ? 1 : (MODE == CV_ROWRUN ? 2 : 4);
     static constexpr int UNR = PATCH ? 9 : NSET;                  // the loaders' loop is unrolled over one period of their issue order
-    static constexpr int NWR = MODE == CV_ROWRUN ? 4 : (BN == 128 ? (PATCH ? 4 : 6) : 8);   // weight ring depth
+    // weight ring depth (with the factor loads of PRE the loads in flight of the deepest ring would pass the 6-bit vmcnt)
+    static constexpr int NWR = MODE == CV_ROWRUN ? 4 : (BN == 128 ? (PATCH ? 4 : 6) : (PRE && !PATCH && NPASS >= 4 ? 6 : 8));
     static constexpr int AH = NWR - 1;                            // weight stages issued ahead
     static constexpr int WST = BN * 128, PB = EMAX * 128;
     // activation buffers: a chunk is written two stages before its first stage; the first stage of a TILE is read at
@@ -124,7 +131,8 @@ __device__ unsigned long long nw_conv_diag[16 * 1024];
 // STATS = false: the instantiation for launches that leave neither moments nor BatchNorm backward sums (inference, data
 // gradients): none of that code and none of its running registers (their mere presence cost every convolution 1-5 %)
 // POST = false: likewise without bias, identity and ReLU (the training path's convolutions have none of them)
-template <int NA, int NB, int WM, int MODE, bool STATS, bool POST>
+// PRE = true: the loaders apply relu((x - mean) a + beta) per input channel (ConvP::pre) in front of the split
+template <int NA, int NB, int WM, int MODE, bool STATS, bool POST, bool PRE = false>
 __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     // (running moments cost 33 registers across the main loop: the 128 x 128 tile has none to spare and keeps them in LDS, 128
     //  bytes per wave and lane row behind the rings, touched by the row's first lane only)
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     const float* const p_bias = POST ? p.bias : nullptr;
     const float* const p_res = POST ? p.res : nullptr;
     const int p_relu = POST ? p.relu : 0;
-    using C = ConvCfg<NA, NB, WM, MODE>;
+    using C = ConvCfg<NA, NB, WM, MODE, PRE>;
     constexpr bool PATCH = C::PATCH, ROWRUN = C::ROWRUN;
     constexpr int BN = C::BN, BM = C::BM, NIW = C::NIW, NPASS = C::NPASS, NACT = C::NACT, TI = C::TI, NSET = C::NSET;
     constexpr int NWR = C::NWR, AH = C::AH, WST = C::WST, PB = C::PB, NPB = C::NPB, UNR = C::UNR, WN = C::WN;
@@ -160,11 +168,12 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     if (ntile == 0) {
         if (p.amax_out && tid == 0) amax_write(p.amax_out, 0.f, blockIdx.x, gridDim.x);
         if ((p_moments || p_bnb_part) && p_macc) {                 // its groups exist and are empty
-            const int G = gridDim.x * WN, nstat = p_moments ? 3 : 2;
+            const int G = gridDim.x * WN, nstat = p_moments ? 5 : 2;
             float* dst = p_moments ? p_moments : p_bnb_part;
             for (int k = tid; k < nstat * WN * p.Cout; k += 512) {
                 const int w3 = k / p.Cout, c = k - w3 * p.Cout;    // (statistic, wave row)
-                dst[((size_t)(w3 / WN) * G + blockIdx.x * WN + w3 % WN) * p.Cout + c] = 0.f;
+                const int stat = w3 / WN;                          // (an empty group: count 0, minimum +inf, maximum -inf)
+                dst[((size_t)stat * G + blockIdx.x * WN + w3 % WN) * p.Cout + c] = stat == 3 ? INFINITY : (stat == 4 ? -INFINITY : 0.f);
             }
         }
         return;
@@ -288,17 +297,28 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         auto ldg2 = [](float4& a, float4& b, const float4* src) { a = src[0]; b = src[1]; };
         auto ldg1 = [](float4& a, const float4* src) { a = src[0]; };
         float4 ld[NSET][NPASS][2];
+        float4 pf[NSET][PRE ? 6 : 1];                                  // PRE: mean, a, beta of the lane's eight channels of the chunk
         unsigned ldvalid[NSET];
-        auto issue_a = [&](float4 (&L)[NPASS][2], unsigned& valid) {   // loads of the cursor's chunk
+        auto issue_a = [&](float4 (&L)[NPASS][2], unsigned& valid, float4 (&F)[PRE ? 6 : 1]) {   // loads of the cursor's chunk
             const bool live = a_skip == 0 && a_g < QT;
             if (a_skip > 0) --a_skip;
             if (live && a_q == 0) setup_tile();
             valid = 0xffffffffu;
+            if (PRE) {   // the chunk's per-channel factors (always loaded: the issue order stays periodic); pixels that do not
+                         // exist must come out as ZERO behind the BatchNorm: bit q of `valid` = pass q holds a real pixel
+                const int cch = live ? (PATCH ? a_q : a_q % nc) : 0;
+                const float* fb = p.pre + 32 * cch + 8 * lj;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ldg2(F[2 * k], F[2 * k + 1], reinterpret_cast<const float4*>(fb + (size_t)k * p.Cin));
+                valid = 0;
+            }
             if (PATCH) {
                 const float* base = p.x + 32 * a_q;
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q) {
-                    ldg2(L[q][0], L[q][1], pick(live && ((avalid >> q) & 1), base + aoff[q]));
+                    const bool ok = live && ((avalid >> q) & 1);
+                    if (PRE) valid |= ok ? (1u << q) : 0u;
+                    ldg2(L[q][0], L[q][1], pick(ok, base + aoff[q]));
                 }
             } else if (MODE == CV_ROWRUN4) {                       // Cin == 4: a pixel is one aligned float4, two pixels per lane
 #pragma unroll
@@ -336,6 +356,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     const int yi = gy[q] + dy, xi = gx[q] + dx;
                     const bool ok = live && gn[q] >= 0 && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
                     const unsigned off = (unsigned)(((gn[q] + yi) * p.W + xi) * p.ldx + 32 * c + 8 * lj);
+                    if (PRE) valid |= ok ? (1u << q) : 0u;
                     ldg2(L[q][0], L[q][1], pick(ok, p.x + off));
                 }
             }
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         };
         // the tensor's scale: one power of two from the bound its producer left (read behind the first loads)
         float up = 1.f;
-        auto write_pass = [&](const float4& L0, const float4& L1, unsigned valid, int g, int q) {   // pass q of a loaded chunk -> split -> buffer g % NPB
+        auto write_pass = [&](const float4& L0, const float4& L1, unsigned valid, int g, int q, const float4 (&F)[PRE ? 6 : 1]) {   // pass q of a loaded chunk -> split -> buffer g % NPB
             char* pb = pbuf + (g % NPB) * PB;
 #ifdef NW_CABL_NOCVT
             if (L0.x != 12345.678f) return;
@@ -356,6 +377,18 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 float xv[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) xv[k] = (MODE == CV_ROWRUN && !((valid >> (8 * q + k)) & 1)) ? 0.f : xs[k];
+                float upq = up;
+                if constexpr (PRE) {   // BatchNorm + ReLU in front of the split: bn_nhwc.hip's centred form, its NaN-keeping ReLU
+                    const float mu[8] = {F[0].x, F[0].y, F[0].z, F[0].w, F[1].x, F[1].y, F[1].z, F[1].w};
+                    const float sa[8] = {F[2].x, F[2].y, F[2].z, F[2].w, F[3].x, F[3].y, F[3].z, F[3].w};
+                    const float sb[8] = {F[4].x, F[4].y, F[4].z, F[4].w, F[5].x, F[5].y, F[5].z, F[5].w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float t = __builtin_fmaf(xv[k] - mu[k], sa[k], sb[k]);
+                        xv[k] = t < 0.f ? 0.f : t;
+                    }
+                    upq = ((valid >> q) & 1) ? up : 0.f;           // a pixel that does not exist: h = l = 0
+                }
                 // h = fp16(2^e x), l = fp16(2^e x - h): two mixed-precision FMAs per element, written by hand (hipcc
                 // builds three quarters of them from packed fp32 FMAs and conversions: 22 instructions for these 16).
                 // A half-register write is followed by a read of that register no sooner than two instructions later
@@ -374,7 +407,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                         "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n"
                         "s_nop 0"
                         : "=&v"(hh[2 * u]), "=&v"(hh[2 * u + 1]), "=&v"(ll[2 * u]), "=&v"(ll[2 * u + 1])
-                        : "v"(xv[4 * u]), "v"(xv[4 * u + 1]), "v"(xv[4 * u + 2]), "v"(xv[4 * u + 3]), "v"(up));
+                        : "v"(xv[4 * u]), "v"(xv[4 * u + 1]), "v"(xv[4 * u + 2]), "v"(xv[4 * u + 3]), "v"(upq));
                 const int e = le + 64 * q;
                 // the LDS stores by hand too: a wave with LDS-DMAs in flight gets an s_waitcnt vmcnt(0) from hipcc in front
                 // of every LDS access it can see (it cannot tell the DMA's target from this buffer)
@@ -386,9 +419,9 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %2, %3" ::"v"(ah_), "v"(hv), "v"(al_), "v"(lv) : "memory");
             }
         };
-        auto write_a = [&](const float4 (&L)[NPASS][2], unsigned valid, int g) {   // a loaded chunk -> split -> buffer g % NPB
+        auto write_a = [&](const float4 (&L)[NPASS][2], unsigned valid, int g, const float4 (&F)[PRE ? 6 : 1]) {   // a loaded chunk -> split -> buffer g % NPB
 #pragma unroll
-            for (int q = 0; q < NPASS; ++q) write_pass(L[q][0], L[q][1], valid, g, q);
+            for (int q = 0; q < NPASS; ++q) write_pass(L[q][0], L[q][1], valid, g, q, F);
         };
         // Iteration s (from -2; a barrier closes it from -1 on, the first one releases the consumers):
         //   A  the chunk whose first stage is s + 2 goes to LDS (its buffer was last read for a stage whose reads are
@@ -420,6 +453,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 if (!PATCH || u == 0) {
                     constexpr int SET_MASK = NSET - 1;
                     float4 (&L)[NPASS][2] = ld[PATCH ? 0 : (u & SET_MASK)];
+                    float4 (&F_)[PRE ? 6 : 1] = pf[PATCH ? 0 : (u & SET_MASK)];
                     unsigned& V_ = ldvalid[PATCH ? 0 : (u & SET_MASK)];
                     // the chunk's loads have landed: all but what was issued after them
                     NW_CSTAMP(0);                                                  // bookkeeping
@@ -427,11 +461,11 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     else wait_vmcnt<NSET * NIW + (NSET - 1) * NACT>();
                     NW_CSTAMP(1);                                                  // wait: the chunk's loads
                     if (si >= -2) {
-                        if (w_g < QT) write_a(L, V_, w_g);
+                        if (w_g < QT) write_a(L, V_, w_g, F_);
                         ++w_g;
                     }
                     NW_CSTAMP(2);                                                  // convert + LDS stores
-                    issue_a(L, V_);
+                    issue_a(L, V_, F_);
                     NW_CSTAMP(3);                                                  // issue of the next chunk's loads
                 }
                 issue_w();
@@ -486,17 +520,40 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
 #define NW_CBAR() tile_barrier()
 #endif
     // moments of everything this wave row has written so far (p_macc): Chan's merge, tile by tile, in registers (MACC_LDS: in LDS)
-    float rcnt = 0.f, rmean[NA][4], rm2[NA][4];
-    float4* const mlds = reinterpret_cast<float4*>(smem + C::LDS) + (wave * 4 + g) * (2 * NA);   // [a]: mean, m2
+    float rcnt = 0.f, rmean[NA][4], rm2[NA][4], rlo[NA][4], rhi[NA][4];
+    float4* const mlds = reinterpret_cast<float4*>(smem + C::LDS) + (wave * 4 + g) * (4 * NA);   // [a]: mean, m2, min, max
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rmean[a][e] = rm2[a][e] = 0.f;
-        if (MACC_LDS && STATS && i == 0) mlds[2 * a] = mlds[2 * a + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = 0; e < 4; ++e) { rmean[a][e] = rm2[a][e] = 0.f; rlo[a][e] = INFINITY; rhi[a][e] = -INFINITY; }
+        if (MACC_LDS && STATS && i == 0) {
+            mlds[4 * a] = mlds[4 * a + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            mlds[4 * a + 2] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+            mlds[4 * a + 3] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
     }
+    auto run_mm = [&](int a, const float (&lo)[4], const float (&hi)[4]) {   // running minimum / maximum of the workgroup's rows
+        if (MACC_LDS) {
+            const float4 x = mlds[4 * a + 2], y = mlds[4 * a + 3];
+            mlds[4 * a + 2] = make_float4(fminf(x.x, lo[0]), fminf(x.y, lo[1]), fminf(x.z, lo[2]), fminf(x.w, lo[3]));
+            mlds[4 * a + 3] = make_float4(fmaxf(y.x, hi[0]), fmaxf(y.y, hi[1]), fmaxf(y.z, hi[2]), fmaxf(y.w, hi[3]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { rlo[a][e] = fminf(rlo[a][e], lo[e]); rhi[a][e] = fmaxf(rhi[a][e], hi[e]); }
+        }
+    };
+    auto run_get_mm = [&](int a, float (&lo)[4], float (&hi)[4]) {
+        if (MACC_LDS) {
+            const float4 x = mlds[4 * a + 2], y = mlds[4 * a + 3];
+            lo[0] = x.x; lo[1] = x.y; lo[2] = x.z; lo[3] = x.w; hi[0] = y.x; hi[1] = y.y; hi[2] = y.z; hi[3] = y.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = rlo[a][e]; hi[e] = rhi[a][e]; }
+        }
+    };
     auto run_get = [&](int a, float (&m)[4], float (&q)[4]) {
         if (MACC_LDS) {
-            const float4 x = mlds[2 * a], y = mlds[2 * a + 1];
+            const float4 x = mlds[4 * a], y = mlds[4 * a + 1];
             m[0] = x.x; m[1] = x.y; m[2] = x.z; m[3] = x.w; q[0] = y.x; q[1] = y.y; q[2] = y.z; q[3] = y.w;
         } else {
 #pragma unroll
@@ -505,8 +562,8 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     };
     auto run_put = [&](int a, const float (&m)[4], const float (&q)[4]) {
         if (MACC_LDS) {
-            mlds[2 * a] = make_float4(m[0], m[1], m[2], m[3]);
-            mlds[2 * a + 1] = make_float4(q[0], q[1], q[2], q[3]);
+            mlds[4 * a] = make_float4(m[0], m[1], m[2], m[3]);
+            mlds[4 * a + 1] = make_float4(q[0], q[1], q[2], q[3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { rmean[a][e] = m[e]; rm2[a][e] = q[e]; }
@@ -674,14 +731,28 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             };
             const int G = p.mtiles * WN, grp = mt * WN + wave / WM;
             const float ntot = rcnt + cnt, wt = ntot > 0.f ? cnt / ntot : 0.f;
+            auto rowmin = [](float x) {
+                x = fminf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false)));
+                x = fminf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false)));
+                x = fminf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4e, 0xf, 0xf, false)));
+                x = fminf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xb1, 0xf, 0xf, false)));
+                return x;
+            };
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                float mean[4], m2[4];
+                float mean[4], m2[4], lo[4], hi[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float s = 0.f;
+                    float s = 0.f, vlo = INFINITY, vhi = -INFINITY;
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) s += (m0 + wpx + 16 * b + i < p.M) ? acc[a][b][e] : 0.f;
+                    for (int b = 0; b < NB; ++b) {
+                        const bool ok = m0 + wpx + 16 * b + i < p.M;
+                        s += ok ? acc[a][b][e] : 0.f;
+                        vlo = fminf(vlo, ok ? acc[a][b][e] : INFINITY);
+                        vhi = fmaxf(vhi, ok ? acc[a][b][e] : -INFINITY);
+                    }
+                    lo[e] = rowmin(vlo);
+                    hi[e] = -rowmin(-vhi);
                     mean[e] = rowsum(s) * rc;
                     float q = 0.f;
 #pragma unroll
@@ -702,9 +773,12 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                             rq[e] += __builtin_fmaf(d * d, rcnt * wt, m2[e]);
                         }
                         run_put(a, rm, rq);
+                        run_mm(a, lo, hi);
                     }
                 } else if (i == 0) {
                     const int co = co0 + wco + 16 * a + 4 * g;
+                    *reinterpret_cast<float4*>(p_moments + ((size_t)3 * G + grp) * p.Cout + co) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+                    *reinterpret_cast<float4*>(p_moments + ((size_t)4 * G + grp) * p.Cout + co) = make_float4(hi[0], hi[1], hi[2], hi[3]);
                     *reinterpret_cast<float4*>(p_moments + ((size_t)0 * G + grp) * p.Cout + co) = make_float4(cnt, cnt, cnt, cnt);
                     *reinterpret_cast<float4*>(p_moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(mean[0], mean[1], mean[2], mean[3]);
                     *reinterpret_cast<float4*>(p_moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(m2[0], m2[1], m2[2], m2[3]);
@@ -800,6 +874,10 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             run_get(a, rm, rq);
             *reinterpret_cast<float4*>(p_moments + ((size_t)1 * G + grp) * p.Cout + co) = make_float4(rm[0], rm[1], rm[2], rm[3]);
             *reinterpret_cast<float4*>(p_moments + ((size_t)2 * G + grp) * p.Cout + co) = make_float4(rq[0], rq[1], rq[2], rq[3]);
+            float lo[4], hi[4];
+            run_get_mm(a, lo, hi);
+            *reinterpret_cast<float4*>(p_moments + ((size_t)3 * G + grp) * p.Cout + co) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+            *reinterpret_cast<float4*>(p_moments + ((size_t)4 * G + grp) * p.Cout + co) = make_float4(hi[0], hi[1], hi[2], hi[3]);
         }
     }
     // this workgroup's maximum -> its slot of the output's amax record (no atomics, nothing to clear beforehand)
@@ -895,7 +973,7 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
     p.macc = p.ntiles == 1 && knob(KNOB_CONV_MOMENTS_PER_TILE) <= 0;
     if (moments_groups) *moments_groups = (p.macc ? grid : (int64_t)p.mtiles) * C::WN;
     if (dry) return NW_OK;
-    constexpr size_t lds = C::LDS + (NA == 4 && NB == 4 ? 2048 : 0);   // (+ the 128 x 128 tile's running moments)
+    constexpr size_t lds = C::LDS + (NA == 4 && NB == 4 ? 4096 : 0);   // (+ the 128 x 128 tile's running moments, minima, maxima)
     static_assert(lds <= 160 * 1024, "LDS");
     // three instantiations: plain (training: data gradients, transitions), with statistics (training forward), with the
     // inference epilogue (bias / identity / ReLU)
@@ -912,6 +990,30 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
     }();
     if (!attr) return NW_ERR_LAUNCH;
     const bool stats = p.moments || p.bnb_part, post = p.bias || p.res || p.relu;
+    if (p.pre) {   // BatchNorm + ReLU in the loaders: training forward (statistics), inference (bias / ReLU behind it) or plain
+        if constexpr (MODE == CV_GATHER || MODE == CV_PATCH) {
+            using CP = ConvCfg<NA, NB, WM, MODE, true>;
+            constexpr size_t ldsp = CP::LDS + (NA == 4 && NB == 4 ? 4096 : 0);
+            static_assert(ldsp <= 160 * 1024, "LDS");
+            auto kp0 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false, false, true>;
+            auto kp1 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, true, false, true>;
+            auto kp2 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false, true, true>;
+            static const bool attrp = [&] {
+                bool ok = true;
+                for (const void* k : {reinterpret_cast<const void*>(kp0), reinterpret_cast<const void*>(kp1), reinterpret_cast<const void*>(kp2)})
+                    ok = ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp) == hipSuccess;
+                return ok;
+            }();
+            if (!attrp) return NW_ERR_LAUNCH;
+            if (stats && post) return NW_ERR_UNSUPPORTED;
+            auto kp = stats ? kp1 : (post ? kp2 : kp0);
+            hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), ldsp, st, p);
+            NW_CHECK_LAUNCH();
+            return NW_OK;
+        } else {
+            return NW_ERR_UNSUPPORTED;
+        }
+    }
     auto kern = stats ? (post ? kern3 : kern1) : (post ? kern2 : kern0);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, p);
     NW_CHECK_LAUNCH();
@@ -966,7 +1068,7 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
                            const float* bias, const float* residual, int relu, float* y, float* amax_out,
                            int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                            int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, float* moments, int64_t* moments_groups,
-                           bool dry, void* stream, const nw_conv_bnstat* bnstat = nullptr) {
+                           bool dry, void* stream, const nw_conv_bnstat* bnstat = nullptr, const float* pre = nullptr) {
     if (n < 0 || H < 0 || W < 0) return NW_ERR_INVALID_ARG;
     if (moments_groups) *moments_groups = 0;
     if (n == 0) return NW_OK;
@@ -989,6 +1091,8 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
     nw::ConvP p;
     p.x = x; p.amax_in = amax_in; p.ws = reinterpret_cast<const char*>(w_split); p.wscale = w_scale; p.bias = bias;
     p.res = residual; p.y = y; p.amax_out = amax_out; p.moments = moments;
+    p.pre = pre;
+    if (pre && (Cin % 32 || (reinterpret_cast<uintptr_t>(pre) & 15))) return NW_ERR_INVALID_ARG;
     p.bnb_x = p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_part = nullptr; p.bnb_ldx = 0;
     if (bnstat) {
         if (Cin % 32) return NW_ERR_UNSUPPORTED;
@@ -1057,6 +1161,16 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
     int64_t groups = 0;
     return conv2d_nhwc_impl(x, amax_in, w_split, w_scale, bias, residual, relu, y, amax_out, n, H, W, Cin, Cout, KH, KW, stride,
                             pad, ldx, ldy, moments, moments ? &groups : nullptr, false, stream);
+}
+
+extern "C" int nw_conv2d_nhwc_bnrelu_f16x2(const float* x, const float* pre, const float* amax_in, const float* w_split,
+                                           const float* w_scale, const float* bias, int relu, float* y, float* amax_out, int64_t n,
+                                           int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                                           int64_t pad, int64_t ldx, int64_t ldy, float* moments, void* stream) {
+    if (!pre) return NW_ERR_INVALID_ARG;
+    int64_t groups = 0;
+    return conv2d_nhwc_impl(x, amax_in, w_split, w_scale, bias, nullptr, relu, y, amax_out, n, H, W, Cin, Cout, KH, KW, stride, pad,
+                            ldx, ldy, moments, moments ? &groups : nullptr, false, stream, nullptr, pre);
 }
 
 extern "C" int nw_conv2d_nhwc_bnstat_f16x2(const float* x, const float* amax_in, const float* w_split, const float* w_scale, float* y,

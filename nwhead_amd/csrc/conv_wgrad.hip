@@ -27,6 +27,8 @@ constexpr int WG_SLOTS = 256;
 struct WgradP {
     const float* x;
     const float* amax_x;
+    const float* pre_x;      // nullable: [3][Cin] = mean | a | beta -- the x operand is relu((x - mean) a + beta), applied by the loaders
+                             //   (a convolution whose forward read x that way: conv_nhwc.hip's ConvP::pre); amax_x bounds that tensor
     const float* gy;
     const float* amax_g;
     float* part;             // [ks][Cout][T][Cin]
@@ -87,8 +89,18 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int bx) {
         // lane -> (row in pass, 8-channel group): COT / 8 (CIT / 8) lanes per row
         constexpr int GL = COT / 8, XL = CIT / 8, GROWS = 256 / GL, XROWS = 256 / XL;
         const int g_r = lt / GL, g_c = lt % GL, x_r = lt / XL, x_c = lt % XL;
-        struct Set { float4 g[GP][2]; float4 x[XP][2]; };
+        struct Set { float4 g[GP][2]; float4 x[XP][2]; unsigned xok; };
         Set ld[NSET];
+        // BatchNorm + ReLU in front of x: a lane's eight channels never change, their factors are loaded once
+        float pmu[8] = {0, 0, 0, 0, 0, 0, 0, 0}, psa[8] = {1, 1, 1, 1, 1, 1, 1, 1}, psb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool pre = p.pre_x != nullptr;
+        if (pre && ci0 + 8 * x_c < p.Cin) {
+            const float4* f = reinterpret_cast<const float4*>(p.pre_x + ci0 + 8 * x_c);
+            const float4 m0 = f[0], m1 = f[1], a0 = f[p.Cin / 4], a1 = f[p.Cin / 4 + 1], b0 = f[p.Cin / 2], b1 = f[p.Cin / 2 + 1];
+            pmu[0] = m0.x; pmu[1] = m0.y; pmu[2] = m0.z; pmu[3] = m0.w; pmu[4] = m1.x; pmu[5] = m1.y; pmu[6] = m1.z; pmu[7] = m1.w;
+            psa[0] = a0.x; psa[1] = a0.y; psa[2] = a0.z; psa[3] = a0.w; psa[4] = a1.x; psa[5] = a1.y; psa[6] = a1.z; psa[7] = a1.w;
+            psb[0] = b0.x; psb[1] = b0.y; psb[2] = b0.z; psb[3] = b0.w; psb[4] = b1.x; psb[5] = b1.y; psb[6] = b1.z; psb[7] = b1.w;
+        }
         // A lane's rows move 32 virtual positions per step: (n, y, x) of each is kept and advanced (no division per load).
         struct Pos { int n, y, x; };
         const int RI = p.IMG / p.IP, q32 = 32 / p.IP, r32 = 32 - q32 * p.IP;
@@ -128,6 +140,7 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int bx) {
                 L.g[q][1] = src[1];
                 advance(pg[q]);
             }
+            L.xok = 0;
 #pragma unroll
             for (int q = 0; q < XP; ++q) {
                 const int row = x_r + XROWS * q;
@@ -141,6 +154,7 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int bx) {
                 const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.x + (size_t)px * p.ldx + ch) : zpage);
                 L.x[q][0] = src[0];
                 L.x[q][1] = src[1];
+                L.xok |= ok ? (1u << q) : 0u;
                 advance(px_[q]);
             }
         };
@@ -189,6 +203,17 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int bx) {
                 const int row = x_r + XROWS * q;
                 if (row < 32) {
                     uint4 hv, lv;
+                    if (pre) {   // the forward's relu((x - mean) a + beta), NaN-keeping; a position that is no pixel stays zero
+                        const float xs[8] = {L.x[q][0].x, L.x[q][0].y, L.x[q][0].z, L.x[q][0].w, L.x[q][1].x, L.x[q][1].y, L.x[q][1].z, L.x[q][1].w};
+                        float xv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float t = __builtin_fmaf(xs[k] - pmu[k], psa[k], psb[k]);
+                            xv[k] = t < 0.f ? 0.f : t;
+                        }
+                        split8(make_float4(xv[0], xv[1], xv[2], xv[3]), make_float4(xv[4], xv[5], xv[6], xv[7]),
+                               ((L.xok >> q) & 1) ? upx : 0.f, hv, lv);
+                    } else
                     split8(L.x[q][0], L.x[q][1], upx, hv, lv);
                     const int rr = (32 * sx + row) & (RING - 1);
                     store8(xring + rr * XRS, rr, x_c, hv, lv);
@@ -499,7 +524,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, c
     if (!workspace || workspace_bytes < need) return NW_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     WgradP p;
-    p.x = x; p.amax_x = amax_x; p.gy = gy; p.amax_g = amax_g;
+    p.x = x; p.amax_x = amax_x; p.gy = gy; p.amax_g = amax_g; p.pre_x = nullptr;
     p.part = pl.ks == 1 ? dw : static_cast<float*>(workspace);
     p.zeros = static_cast<const float4*>(nw_conv_zero_page());
     if (!p.zeros) return NW_ERR_LAUNCH;
@@ -574,7 +599,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
         const int64_t ldx = j.ldx ? j.ldx : j.Cin, ldg = j.ldg ? j.ldg : j.Cout;
         if (!j.x || !j.amax_x || !j.gy || !j.amax_g || !j.dw || ldx < j.Cin || ldg < j.Cout || ldx % 4 || ldg % 4) return NW_ERR_INVALID_ARG;
         if ((reinterpret_cast<uintptr_t>(j.x) | reinterpret_cast<uintptr_t>(j.gy) | reinterpret_cast<uintptr_t>(j.dw) |
-             reinterpret_cast<uintptr_t>(j.amax_x) | reinterpret_cast<uintptr_t>(j.amax_g)) & 15)
+             reinterpret_cast<uintptr_t>(j.amax_x) | reinterpret_cast<uintptr_t>(j.amax_g) | reinterpret_cast<uintptr_t>(j.pre_x)) & 15)
             return NW_ERR_INVALID_ARG;
     }
     char* wsp = static_cast<char*>(workspace);
@@ -602,7 +627,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
             wgrad_plan(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad, &pl, tgt);
             if (pl.taps9 != want9) continue;
             WgradP& q = bt.p[bt.n];
-            q.x = j.x; q.amax_x = j.amax_x; q.gy = j.gy; q.amax_g = j.amax_g;
+            q.x = j.x; q.amax_x = j.amax_x; q.gy = j.gy; q.amax_g = j.amax_g; q.pre_x = j.pre_x;
             const bool oihw = j.out_oihw != 0 && j.KH * j.KW > 1;   // torch's weight layout: written by the reduce kernel
             q.part = (pl.ks == 1 && !oihw) ? j.dw : reinterpret_cast<float*>(jws);
             q.zeros = zeros;

@@ -1389,49 +1389,64 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         # Batch statistics per slab channel, computed ONCE: a channel's mean and variance are the same for every later layer's
         # norm1, the block's input channels get one pass here, and each convolution leaves the moments of the channels it writes
         # (nw_conv2d_nhwc_f16x2's `moments`), so no BatchNorm of the block reads its input for statistics.
-        bstat = torch.empty(3 * ctot, **f32)                               # mean | invstd | var of the slab's channels
-        bm, bi, bv = bstat[:ctot], bstat[ctot:2 * ctot], bstat[2 * ctot:]
+        bstat = torch.empty(5 * ctot, **f32)                       # mean | invstd | var | min | max of the slab's channels
+        bm, bi, bv, blo, bhi = (bstat[k * ctot:(k + 1) * ctot] for k in range(5))
         with _OnDevice(dev):
-            wsb = lib.nw_bn_nhwc_workspace_bytes(rows, c0)
+            wsb = lib.nw_bn_nhwc_minmax_workspace_bytes(rows, c0)
             ws = _workspace(wsb, dev)
-            _lib.check(lib.nw_bn_nhwc_moments_f32(_ptr(slab), ctot, rows, c0, eps, _ptr(bm), _ptr(bi), _ptr(bv), _ptr(ws), wsb, st),
-                       "nw_bn_nhwc_moments_f32")
+            _lib.check(lib.nw_bn_nhwc_moments_minmax_f32(_ptr(slab), ctot, rows, c0, eps, _ptr(bm), _ptr(bi), _ptr(bv), _ptr(blo),
+                                                         _ptr(bhi), _ptr(ws), wsb, st), "nw_bn_nhwc_moments_minmax_f32")
+            def layer_params(k):
+                g1, b1, w1, g2, b2, w2 = (t.detach() for t in params[6 * k:6 * k + 6])
+                return _f32c(g1), _f32c(b1), w1, _f32c(g2), _f32c(b2), w2
+            # Round 4: neither t1 = relu(norm1(prefix)) nor t2 = relu(norm2(u)) exists: the convolutions' loaders apply the
+            # BatchNorm + ReLU on the way into LDS (nw_conv2d_nhwc_bnrelu_f16x2) from a per-channel table mean | a | beta, with
+            # the exact bound on the transformed tensor (from each channel's minimum and maximum, which the producing
+            # convolution's epilogue leaves beside the moments) as its amax record.  The table of a layer's norm1 is written by
+            # the launch that merges the previous layer's fresh channels (nw_bn_nhwc_prep_window_from_partials_f32): four
+            # launches per layer -- conv1, merge + norm2's table, conv2, merge + the next norm1's table.
+            g1, b1, w1, g2, b2, w2 = layer_params(0)
+            tab1 = torch.empty(3 * c0, **f32)
+            am1 = torch.empty(AMAX_SLOTS, **f32)
+            rm, rv, mom, nbt = _bn_tracking(layers[0].norm1)
+            _lib.check(lib.nw_bn_nhwc_prep_f32(_ptr(bm), _ptr(bi), _ptr(bv), _ptr(blo), _ptr(bhi), _ptr(g1), _ptr(b1), _ptr(rm), _ptr(rv),
+                                               _ptr(nbt), mom, 1, rows, c0, _ptr(tab1), _ptr(am1), st), "nw_bn_nhwc_prep_f32")
             for k, layer in enumerate(layers):
                 c = c0 + k * growth
-                g1, b1, w1, g2, b2, w2 = (t.detach() for t in params[6 * k:6 * k + 6])
-                g1, b1, g2, b2 = _f32c(g1), _f32c(b1), _f32c(g2), _f32c(b2)
                 o1, o2 = bank.operands(layer.conv1.weight), bank.operands(layer.conv2.weight)
                 kh = w2.shape[2]
-                t1 = torch.empty((rows, c), **f32)
                 u = torch.empty((rows, mid), **f32)
-                t2 = torch.empty((rows, mid), **f32)
-                stats = torch.empty(3 * mid, **f32)                        # norm2: mean | invstd | var
-                am = torch.empty(2 * AMAX_SLOTS, **f32)                    # amax records of t1 | t2
-                m2, i2, v2 = stats[:mid], stats[mid:2 * mid], stats[2 * mid:]
+                stats = torch.empty(5 * mid, **f32)                        # norm2: mean | invstd | var | min | max
+                tab2 = torch.empty(3 * mid, **f32)
+                am2 = torch.empty(AMAX_SLOTS, **f32)                       # amax record of relu(norm2(u)) (am1: of relu(norm1(prefix)))
+                m2, i2, v2, lo2, hi2 = (stats[j * mid:(j + 1) * mid] for j in range(5))
                 G1 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, c, mid, 1, 1, 1, 0)
                 G2 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, mid, growth, kh, kh, 1, kh // 2)
-                part = _workspace(4 * 3 * max(G1 * mid, G2 * growth), dev)
-                rm, rv, mom, nbt = _bn_tracking(layer.norm1)
-                _lib.check(lib.nw_bn_relu_nhwc_apply_f32(_ptr(slab), ctot, _ptr(bm), _ptr(bi), _ptr(bv), _ptr(g1), _ptr(b1), _ptr(rm),
-                                                         _ptr(rv), _ptr(nbt), mom, _ptr(t1), _ptr(am), rows, c, 1, st),
-                           "nw_bn_relu_nhwc_apply_f32")
-                _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(t1), _ptr(am), _ptr(o1[0].split), _ptr(o1[0].scale), None, None, 0,
-                                                    _ptr(u), None, n, h, w, c, mid, 1, 1, 1, 0, 0, 0, _ptr(part), st),
-                           "nw_conv2d_nhwc_f16x2")
-                _lib.check(lib.nw_bn_nhwc_moments_from_partials_f32(_ptr(part), G1, mid, eps, _ptr(m2), _ptr(i2), _ptr(v2), st),
-                           "nw_bn_nhwc_moments_from_partials_f32")
+                part = _workspace(4 * 5 * max(G1 * mid, G2 * growth), dev)
+                _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(_ptr(slab), _ptr(tab1), _ptr(am1), _ptr(o1[0].split), _ptr(o1[0].scale), None, 0,
+                                                           _ptr(u), None, n, h, w, c, mid, 1, 1, 1, 0, ctot, 0, _ptr(part), st),
+                           "nw_conv2d_nhwc_bnrelu_f16x2")
                 rm, rv, mom, nbt = _bn_tracking(layer.norm2)
-                _lib.check(lib.nw_bn_relu_nhwc_apply_f32(_ptr(u), mid, _ptr(m2), _ptr(i2), _ptr(v2), _ptr(g2), _ptr(b2), _ptr(rm),
-                                                         _ptr(rv), _ptr(nbt), mom, _ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, rows,
-                                                         mid, 1, st), "nw_bn_relu_nhwc_apply_f32")
-                _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, _ptr(o2[0].split), _ptr(o2[0].scale),
-                                                    None, None, 0, slab.data_ptr() + 4 * c, None, n, h, w, mid, growth, kh, kh, 1,
-                                                    kh // 2, 0, ctot, _ptr(part), st), "nw_conv2d_nhwc_f16x2")
-                _lib.check(lib.nw_bn_nhwc_moments_from_partials_f32(_ptr(part), G2, growth, eps, bm.data_ptr() + 4 * c,
-                                                                    bi.data_ptr() + 4 * c, bv.data_ptr() + 4 * c, st),
-                           "nw_bn_nhwc_moments_from_partials_f32")
-                saved += [t1, u, t2, stats, am, g1, b1, g2, b2]
+                _lib.check(lib.nw_bn_nhwc_prep_from_partials_f32(_ptr(part), G1, mid, eps, _ptr(m2), _ptr(i2), _ptr(v2), _ptr(lo2),
+                                                                 _ptr(hi2), _ptr(g2), _ptr(b2), _ptr(rm), _ptr(rv), _ptr(nbt), mom, 1,
+                                                                 _ptr(tab2), _ptr(am2), st), "nw_bn_nhwc_prep_from_partials_f32")
+                _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(_ptr(u), _ptr(tab2), _ptr(am2), _ptr(o2[0].split), _ptr(o2[0].scale), None, 0,
+                                                           slab.data_ptr() + 4 * c, None, n, h, w, mid, growth, kh, kh, 1, kh // 2, 0,
+                                                           ctot, _ptr(part), st), "nw_conv2d_nhwc_bnrelu_f16x2")
+                saved += [u, stats, tab1, am1, tab2, am2, g1, b1, g2, b2]
                 meta.append((c, kh, o1[1], o2[1], tuple(w1.shape), tuple(w2.shape)))
+                if k + 1 < L:      # the fresh channels' statistics + the whole table of the next layer's norm1
+                    g1, b1, w1, g2, b2, w2 = layer_params(k + 1)
+                    tab1 = torch.empty(3 * (c + growth), **f32)
+                    am1 = torch.empty(AMAX_SLOTS, **f32)
+                    rm, rv, mom, nbt = _bn_tracking(layers[k + 1].norm1)
+                    _lib.check(lib.nw_bn_nhwc_prep_window_from_partials_f32(
+                        _ptr(part), G2, growth, c, c, rows, eps, _ptr(bm), _ptr(bi), _ptr(bv), _ptr(blo), _ptr(bhi), _ptr(g1), _ptr(b1),
+                        _ptr(rm), _ptr(rv), _ptr(nbt), mom, 1, _ptr(tab1), _ptr(am1), st), "nw_bn_nhwc_prep_window_from_partials_f32")
+                else:
+                    _lib.check(lib.nw_bn_nhwc_prep_window_from_partials_f32(
+                        _ptr(part), G2, growth, c, 0, rows, eps, _ptr(bm), _ptr(bi), _ptr(bv), _ptr(blo), _ptr(bhi), None, None, None,
+                        None, None, 0.0, 1, None, None, st), "nw_bn_nhwc_prep_window_from_partials_f32")
         saved.append(bstat)
         ctx.save_for_backward(slab, *saved)
         ctx.meta, ctx.dims = meta, (n, c0, h, w, growth, mid, ctot)
@@ -1461,13 +1476,15 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         with _OnDevice(dev):
             for k in range(len(ctx.meta) - 1, -1, -1):
                 c, kh, d1, d2, w1s, w2s = ctx.meta[k]
-                t1, u, t2, stats, am, g1, b1, g2, b2 = saved[9 * k:9 * k + 9]
+                u, stats, tab1, am1, tab2, am2, g1, b1, g2, b2 = saved[10 * k:10 * k + 10]
                 m1, i1, m2, i2 = bstat[:c], bstat[ctot:ctot + c], stats[:mid], stats[mid:2 * mid]
+                # (tab1 / tab2: the forward's tables -- the weight gradients' x operands are relu(norm(.)) again, applied by
+                #  THEIR loaders)
                 gv = G.data_ptr() + 4 * c                              # this layer's window of the gradient slab
                 # conv2 (3x3): weight gradient, data gradient
                 dw2 = torch.empty((growth, mid, kh, kh), **f32)          # torch's layout: autograd takes it without a copy
-                wjobs.append(_lib.WgradJob(_ptr(t2), am.data_ptr() + 4 * AMAX_SLOTS, gv, _ptr(am_g), _ptr(dw2),
-                                           n, h, w, mid, growth, kh, kh, 1, kh // 2, 0, ctot, 1))
+                wjobs.append(_lib.WgradJob(_ptr(u), _ptr(am2), gv, _ptr(am_g), _ptr(dw2),
+                                           n, h, w, mid, growth, kh, kh, 1, kh // 2, 0, ctot, 1, _ptr(tab2)))
                 wkeep.append(am_g)
                 if DENSE_BWD_STATS_IN_DGRAD:
                     dt2 = torch.empty((rows, mid), **f32)
@@ -1491,8 +1508,8 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                         "nw_bn_relu_nhwc_train_bwd_from_partials_f32")
                     # conv1 (1x1)
                     dw1 = torch.empty((mid, 1, 1, c), **f32)
-                    wjobs.append(_lib.WgradJob(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
-                                               n, h, w, c, mid, 1, 1, 1, 0, 0, 0, 0))
+                    wjobs.append(_lib.WgradJob(_ptr(slab), _ptr(am1), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
+                                               n, h, w, c, mid, 1, 1, 1, 0, ctot, 0, 0, _ptr(tab1)))
                     wkeep += [du, am_d]
                     dt1 = torch.empty((rows, c), **f32)
                     bs1 = _lib.ConvBnStat(_ptr(slab), ctot, _ptr(m1), _ptr(i1), _ptr(g1), _ptr(b1), _ptr(bpart))
@@ -1523,8 +1540,8 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                                "nw_bn_relu_nhwc_train_bwd_f32")
                     # conv1 (1x1)
                     dw1 = torch.empty((mid, 1, 1, c), **f32)
-                    wjobs.append(_lib.WgradJob(_ptr(t1), _ptr(am), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
-                                               n, h, w, c, mid, 1, 1, 1, 0, 0, 0, 0))
+                    wjobs.append(_lib.WgradJob(_ptr(slab), _ptr(am1), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
+                                               n, h, w, c, mid, 1, 1, 1, 0, ctot, 0, 0, _ptr(tab1)))
                     wkeep += [du, am_d]
                     dt1 = torch.empty((rows, c), **f32)
                     _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,

@@ -441,7 +441,7 @@ def test_conv_channel_windows_and_moments(dev, n, cin, h, w, cout, k, xw, yw):
     am = ops.absmax(wide_x)
     G = lib.nw_conv2d_nhwc_moments_groups(n, h, w, cin, cout, k, k, 1, pad)
     assert G > 0
-    part = torch.empty(3 * G * cout, dtype=torch.float32, device=dev)
+    part = torch.empty(5 * G * cout, dtype=torch.float32, device=dev)     # count, mean, M2, minimum, maximum per group
     am_out = torch.empty(ops.AMAX_SLOTS, dtype=torch.float32, device=dev)
     st = ops._stream(wide_x)
     _lib.check(lib.nw_conv2d_nhwc_f16x2(x.data_ptr(), am.data_ptr(), sw.split.data_ptr(), sw.scale.data_ptr(), None, None, 0,
@@ -461,6 +461,109 @@ def test_conv_channel_windows_and_moments(dev, n, cin, h, w, cout, k, xw, yw):
     assert ((stats[:cout].double() - mean).abs() / sd).max().item() < 1e-5
     assert ((stats[2 * cout:].double() - var).abs() / var).max().item() < 1e-5
     assert ((stats[cout:2 * cout].double() - (var + 1e-5).rsqrt()).abs() * sd).max().item() < 1e-5
+    # round 4: the same groups with their minima and maxima (the values the kernel itself stored), statistics-only merge
+    st5 = torch.empty(5 * cout, dtype=torch.float32, device=dev)
+    _lib.check(lib.nw_bn_nhwc_prep_from_partials_f32(part.data_ptr(), G, cout, 1e-5, *(st5.data_ptr() + 4 * cout * j for j in range(5)),
+                                                     None, None, None, None, None, 0.0, 1, None, None, st), "merge5")
+    np.testing.assert_allclose(st5[:3 * cout].cpu().numpy(), stats.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    assert torch.equal(st5[3 * cout:4 * cout], y.amin((0, 2, 3))) and torch.equal(st5[4 * cout:], y.amax((0, 2, 3)))
+
+
+BNRELU_CASES = [
+    # n, cin, h, w, cout, k, wide (channels of the tensor x is a prefix of; 0: dense), moments
+    (2, 64, 12, 12, 128, 1, 96, True),       # GATHER, 64 x 64 tiles, a channel prefix
+    (3, 160, 28, 28, 128, 1, 0, True),       # GATHER, 128-pixel tiles
+    (9, 96, 56, 56, 128, 1, 0, True),        # GATHER, 128 x 128 tiles, moments merged per workgroup
+    (3, 992, 7, 7, 128, 1, 1024, False),     # DenseNet block 4 conv1: 31 chunks, ragged tile
+    (16, 64, 56, 56, 32, 1, 0, False),       # 256-pixel tiles of 32 channels (the shallower ring)
+    (2, 128, 14, 14, 32, 3, 0, True),        # PATCH: padding must stay ZERO behind the BatchNorm
+    (3, 128, 9, 7, 32, 3, 0, True),          # PATCH, tiles crossing rows and images
+    (3, 128, 56, 56, 32, 3, 0, False),       # DenseNet conv2 at 56 x 56 (256-pixel tiles)
+    (5, 128, 7, 7, 32, 3, 0, True),
+]
+
+
+@pytest.mark.parametrize("n,cin,h,w,cout,k,wide,moments", BNRELU_CASES)
+def test_conv_with_batchnorm_relu_in_the_loaders(dev, n, cin, h, w, cout, k, wide, moments):
+    """nw_conv2d_nhwc_bnrelu_f16x2 (round 4, model/densenet.py:36-45 without t1 / t2): y = conv(relu((x - mean) a + beta)),
+    the table and the exact bound from nw_bn_nhwc_moments_minmax_f32 + nw_bn_nhwc_prep_f32, against fp64 -- channels with
+    an offset, negative gamma, a constant channel; zero padding of the TRANSFORMED map in 3x3 mode; the moments it leaves;
+    and nw_conv2d_nhwc_wgrad_batch_f16x2 with the same table on its x operand."""
+    from nwhead_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7 * cin + cout + k)
+    pad = k // 2
+    ctot = wide if wide else cin
+    xw = torch.randn(n, ctot, h, w, generator=g) * (0.2 + 2.0 * torch.rand(1, ctot, 1, 1, generator=g)) + 3.0 * torch.randn(1, ctot, 1, 1, generator=g)
+    xw[:, 1] = 0.75                                                   # a constant channel (variance 0)
+    xw = _cl(xw.to(dev))
+    x = xw[:, :cin]
+    gamma = (torch.rand(cin, generator=g) + 0.5) * torch.where(torch.rand(cin, generator=g) < 0.2, -1.0, 1.0)
+    beta = torch.randn(cin, generator=g) * 0.5
+    gamma, beta = gamma.to(dev), beta.to(dev)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
+    sw = ops.SplitConvWeight(wt)
+    rows, eps, st = n * h * w, 1e-5, ops._stream(xw)
+    f32 = dict(dtype=torch.float32, device=dev)
+    stats = torch.empty(5 * cin, **f32)
+    sp = [stats.data_ptr() + 4 * cin * j for j in range(5)]
+    wsb = lib.nw_bn_nhwc_minmax_workspace_bytes(rows, cin)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.nw_bn_nhwc_moments_minmax_f32(x.data_ptr(), ctot, rows, cin, eps, *sp, ws.data_ptr(), wsb, st), "moments")
+    xd = x.double()
+    mean, var = xd.mean((0, 2, 3)), xd.var((0, 2, 3), unbiased=False)
+    assert torch.equal(stats[3 * cin:4 * cin], x.amin((0, 2, 3))) and torch.equal(stats[4 * cin:], x.amax((0, 2, 3)))
+    rm, rv = torch.zeros(cin, **f32), torch.ones(cin, **f32)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    tab, am = torch.empty(3 * cin, **f32), torch.empty(ops.AMAX_SLOTS, **f32)
+    _lib.check(lib.nw_bn_nhwc_prep_f32(*sp, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), 0.1, 1,
+                                       rows, cin, tab.data_ptr(), am.data_ptr(), st), "prep")
+    t_ref = torch.relu((xd - mean[None, :, None, None]) * (gamma.double() * (var + eps).rsqrt())[None, :, None, None]
+                       + beta.double()[None, :, None, None])
+    # the bound is the maximum of the transformed tensor as the loaders compute it (fp32): never below it, and tight
+    t32 = torch.relu((x - stats[:cin][None, :, None, None]) * tab[cin:2 * cin][None, :, None, None] + tab[2 * cin:][None, :, None, None])
+    assert float(t32.max()) * (1 - 1e-6) <= float(am.max()) <= float(t32.max()) * (1 + 1e-5) + 1e-30
+    assert int(nbt) == 1
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * mean.float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), 0.9 + 0.1 * (var * rows / (rows - 1)).float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    y = _cl(torch.empty(n, cout, h, w, **f32))
+    G = lib.nw_conv2d_nhwc_moments_groups(n, h, w, cin, cout, k, k, 1, pad)
+    part = torch.empty(5 * G * cout, **f32) if moments else None
+    am_out = torch.empty(ops.AMAX_SLOTS, **f32)
+    _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(x.data_ptr(), tab.data_ptr(), am.data_ptr(), sw.split.data_ptr(), sw.scale.data_ptr(),
+                                               None, 0, y.data_ptr(), am_out.data_ptr(), n, h, w, cin, cout, k, k, 1, pad, ctot, 0,
+                                               None if part is None else part.data_ptr(), st), "conv bnrelu")
+    ref = F.conv2d(t_ref, wt.double(), None, 1, pad)
+    sc = ref.abs().max().item()
+    assert (y.double() - ref).abs().max().item() / sc < 2 * TOL
+    assert abs(float(am_out.max()) - float(y.abs().max())) <= 1e-6 * float(y.abs().max())
+    if moments:
+        st5 = torch.empty(5 * cout, **f32)
+        tab2, am2 = torch.empty(3 * cout, **f32), torch.empty(ops.AMAX_SLOTS, **f32)
+        g2, b2 = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+        _lib.check(lib.nw_bn_nhwc_prep_from_partials_f32(part.data_ptr(), G, cout, eps, *(st5.data_ptr() + 4 * cout * j for j in range(5)),
+                                                         g2.data_ptr(), b2.data_ptr(), None, None, None, 0.0, 1, tab2.data_ptr(),
+                                                         am2.data_ptr(), st), "merge + prep")
+        m_y, v_y = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False)
+        assert ((st5[:cout].double() - m_y).abs() / v_y.sqrt()).max().item() < 2e-5
+        assert ((st5[2 * cout:3 * cout].double() - v_y).abs() / v_y).max().item() < 2e-5
+        assert torch.equal(st5[3 * cout:4 * cout], y.amin((0, 2, 3))) and torch.equal(st5[4 * cout:], y.amax((0, 2, 3)))
+        t2 = torch.relu((y - st5[:cout][None, :, None, None]) * tab2[cout:2 * cout][None, :, None, None] + tab2[2 * cout:][None, :, None, None])
+        assert float(t2.max()) * (1 - 1e-6) <= float(am2.max()) <= float(t2.max()) * (1 + 1e-5) + 1e-30
+        np.testing.assert_allclose(tab2[cout:2 * cout].cpu().numpy(), (g2.double() * (v_y + eps).rsqrt()).float().cpu().numpy(), rtol=1e-4)
+    # the weight gradient with the same table on its x operand: dW = sum_pixels relu(bn(x)) (x) gy
+    if lib.nw_conv2d_nhwc_wgrad_supported(n, h, w, cin, cout, k, k, 1, pad):
+        gy = _cl((torch.randn(n, cout, h, w, generator=g) * 0.7).to(dev))
+        am_g = ops.absmax(gy)
+        dw = torch.empty((cout, k, k, cin), **f32)
+        job = _lib.WgradJob(x.data_ptr(), am.data_ptr(), gy.data_ptr(), am_g.data_ptr(), dw.data_ptr(), n, h, w, cin, cout, k, k, 1, pad,
+                            ctot, 0, 0, tab.data_ptr())
+        jobs = (_lib.WgradJob * 1)(job)
+        wb = lib.nw_conv2d_nhwc_wgrad_batch_workspace_bytes(jobs, 1)
+        wsw = torch.empty(max(wb, 16), dtype=torch.uint8, device=dev)
+        _lib.check(lib.nw_conv2d_nhwc_wgrad_batch_f16x2(jobs, 1, wsw.data_ptr(), wb, st), "wgrad")
+        dref = torch.nn.grad.conv2d_weight(t_ref, wt.shape, gy.double(), 1, pad).permute(0, 2, 3, 1)
+        assert (dw.double() - dref).abs().max().item() / dref.abs().max().item() < 2 * TOL
 
 
 def test_bn_forward_in_phases_equals_the_fused_call(dev):
