@@ -172,6 +172,7 @@ struct BnPrep {
 // bound of act((x - mean) a + beta) over x in [lo, hi]: the map is monotone in x, and computed exactly as the loaders compute it
 __device__ __forceinline__ float prep_bound(float lo, float hi, float mean, float a, float b, int relu) {
     const float u = __builtin_fmaf(lo - mean, a, b), v = __builtin_fmaf(hi - mean, a, b);
+    if (!(u == u) || !(v == v)) return INFINITY;   // a NaN in the statistics: the consumer turns a non-finite bound into NaN outputs
     return relu ? fmaxf(fmaxf(u, v), 0.f) : fmaxf(fabsf(u), fabsf(v));
 }
 __global__ __launch_bounds__(1024) void nw_bn_nhwc_merge_groups_kernel(const float* __restrict__ part, int G, int C, float eps,

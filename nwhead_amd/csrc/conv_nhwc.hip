@@ -69,19 +69,18 @@ template <int NA, int NB, int WM, int MODE, bool PRE = false>
 struct ConvCfg {
     static constexpr bool PATCH = MODE == CV_PATCH, ROWRUN = MODE == CV_ROWRUN || MODE == CV_ROWRUN4;
     static_assert(!(PRE && ROWRUN), "the few-channel stems have no BatchNorm in front");
-    static constexpr int NPRE = PRE ? 6 : 0;                      // factor loads per lane per chunk (mean, a, beta of 8 channels)
     static constexpr int WN = 4 / WM;
     static constexpr int BN = 16 * NA * WM, BM = 16 * NB * WN;
     static constexpr int NIW = BN / 32;                           // weight DMAs per loader wave per stage
     static constexpr int EMAX = PATCH ? BM + 192 : BM;            // activation entries (pixels) per buffer
     static constexpr int NPASS = EMAX / 64;
-    static constexpr int NACT = (MODE == CV_ROWRUN ? 8 : 2) * NPASS + NPRE;   // global loads per lane per chunk
+    static constexpr int NACT = (MODE == CV_ROWRUN ? 8 : 2) * NPASS;   // global loads per lane per chunk
     static constexpr int TI = PATCH ? 9 : 1;                      // stages per activation chunk
     // register sets of activation loads in flight: a one-stage chunk (GATHER) needs several to cover the memory latency
     static constexpr int NSET = PATCH ? 1 : (MODE == CV_ROWRUN ? 2 : 4);
     static constexpr int UNR = PATCH ? 9 : NSET;                  // the loaders' loop is unrolled over one period of their issue order
-    // weight ring depth (with the factor loads of PRE the loads in flight of the deepest ring would pass the 6-bit vmcnt)
-    static constexpr int NWR = MODE == CV_ROWRUN ? 4 : (BN == 128 ? (PATCH ? 4 : 6) : (PRE && !PATCH && NPASS >= 4 ? 6 : 8));
+    // weight ring depth (PRE: the BatchNorm table of the input channels -- 12 bytes per channel -- sits in LDS behind the rings)
+    static constexpr int NWR = MODE == CV_ROWRUN ? 4 : (BN == 128 ? (PATCH ? 4 : (PRE ? 5 : 6)) : 8);
     static constexpr int AH = NWR - 1;                            // weight stages issued ahead
     static constexpr int WST = BN * 128, PB = EMAX * 128;
     // activation buffers: a chunk is written two stages before its first stage; the first stage of a TILE is read at
@@ -150,6 +149,10 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wring = smem;
     char* const pbuf = smem + NWR * WST;
+    // PRE: [3][Cin] mean | a | beta of the input channels, copied once by the loader waves (first version: six global loads per
+    // lane and chunk beside the two of the activations -- 4x the vector-memory instructions of a 1x1 layer's loaders, +10 us
+    // on the 14 x 14 layers)
+    char* const ptab = smem + C::LDS + (NA == 4 && NB == 4 ? 4096 : 0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,6 +189,19 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     if (wave >= 4) {
         // ============================================================== loaders
         const int lw = wave - 4, lt = tid - 256, lj = lt & 3, le = lt >> 2;
+        typedef __attribute__((address_space(3))) char lds_char_;
+        if constexpr (PRE) {
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            const int n4 = 3 * p.Cin / 4;
+            for (int k = lt; k < n4; k += 256) {
+                const u32x4_ v = reinterpret_cast<const u32x4_*>(p.pre)[k];
+                const unsigned a_ = (unsigned)(uintptr_t)(lds_char_*)(ptab + 16 * k);
+                asm volatile("ds_write_b128 %0, %1" ::"v"(a_), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // (the consumers pass the same barrier at their start)
+        }
+        const unsigned ptab_lane = PRE ? (unsigned)(uintptr_t)(lds_char_*)(ptab + 32 * lj) : 0u;   // this lane's eight channels of chunk 0
         // ---- weight DMA: stage cursor
         unsigned woff[NIW];
 #pragma unroll
@@ -297,21 +313,13 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         auto ldg2 = [](float4& a, float4& b, const float4* src) { a = src[0]; b = src[1]; };
         auto ldg1 = [](float4& a, const float4* src) { a = src[0]; };
         float4 ld[NSET][NPASS][2];
-        float4 pf[NSET][PRE ? 6 : 1];                                  // PRE: mean, a, beta of the lane's eight channels of the chunk
         unsigned ldvalid[NSET];
-        auto issue_a = [&](float4 (&L)[NPASS][2], unsigned& valid, float4 (&F)[PRE ? 6 : 1]) {   // loads of the cursor's chunk
+        auto issue_a = [&](float4 (&L)[NPASS][2], unsigned& valid) {   // loads of the cursor's chunk
             const bool live = a_skip == 0 && a_g < QT;
             if (a_skip > 0) --a_skip;
             if (live && a_q == 0) setup_tile();
             valid = 0xffffffffu;
-            if (PRE) {   // the chunk's per-channel factors (always loaded: the issue order stays periodic); pixels that do not
-                         // exist must come out as ZERO behind the BatchNorm: bit q of `valid` = pass q holds a real pixel
-                const int cch = live ? (PATCH ? a_q : a_q % nc) : 0;
-                const float* fb = p.pre + 32 * cch + 8 * lj;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) ldg2(F[2 * k], F[2 * k + 1], reinterpret_cast<const float4*>(fb + (size_t)k * p.Cin));
-                valid = 0;
-            }
+            if (PRE) valid = 0;   // pixels that do not exist must come out as ZERO behind the BatchNorm: bit q = pass q holds a real pixel
             if (PATCH) {
                 const float* base = p.x + 32 * a_q;
 #pragma unroll
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         };
         // the tensor's scale: one power of two from the bound its producer left (read behind the first loads)
         float up = 1.f;
-        auto write_pass = [&](const float4& L0, const float4& L1, unsigned valid, int g, int q, const float4 (&F)[PRE ? 6 : 1]) {   // pass q of a loaded chunk -> split -> buffer g % NPB
+        auto write_pass = [&](const float4& L0, const float4& L1, unsigned valid, int g, int q, const f32x4 (&F)[PRE ? 6 : 1]) {   // pass q of a loaded chunk -> split -> buffer g % NPB
             char* pb = pbuf + (g % NPB) * PB;
 #ifdef NW_CABL_NOCVT
             if (L0.x != 12345.678f) return;
@@ -379,13 +387,19 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 for (int k = 0; k < 8; ++k) xv[k] = (MODE == CV_ROWRUN && !((valid >> (8 * q + k)) & 1)) ? 0.f : xs[k];
                 float upq = up;
                 if constexpr (PRE) {   // BatchNorm + ReLU in front of the split: bn_nhwc.hip's centred form, its NaN-keeping ReLU
-                    const float mu[8] = {F[0].x, F[0].y, F[0].z, F[0].w, F[1].x, F[1].y, F[1].z, F[1].w};
-                    const float sa[8] = {F[2].x, F[2].y, F[2].z, F[2].w, F[3].x, F[3].y, F[3].z, F[3].w};
-                    const float sb[8] = {F[4].x, F[4].y, F[4].z, F[4].w, F[5].x, F[5].y, F[5].z, F[5].w};
+                    const float mu[8] = {F[0][0], F[0][1], F[0][2], F[0][3], F[1][0], F[1][1], F[1][2], F[1][3]};
+                    const float sa[8] = {F[2][0], F[2][1], F[2][2], F[2][3], F[3][0], F[3][1], F[3][2], F[3][3]};
+                    const float sb[8] = {F[4][0], F[4][1], F[4][2], F[4][3], F[5][0], F[5][1], F[5][2], F[5][3]};
+                    // (packed fp32 subtract / FMA, v_max_f32: 16 instructions for the 8 elements.  v_max drops a NaN; a NaN anywhere
+                    //  in x makes its channel's mean NaN, the table's bound non-finite, and `up` -- the scale of EVERY element --
+                    //  NaN: the whole output is NaN, as the unfused passes would leave the loss)
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float t = __builtin_fmaf(xv[k] - mu[k], sa[k], sb[k]);
-                        xv[k] = t < 0.f ? 0.f : t;
+                    for (int k = 0; k < 8; k += 2) {
+                        const f32x2_ t = __builtin_elementwise_fma(f32x2_{xv[k], xv[k + 1]} - f32x2_{mu[k], mu[k + 1]}, f32x2_{sa[k], sa[k + 1]},
+                                                                   f32x2_{sb[k], sb[k + 1]});
+                        xv[k] = fmaxf(t.x, 0.f);
+                        xv[k + 1] = fmaxf(t.y, 0.f);
                     }
                     upq = ((valid >> q) & 1) ? up : 0.f;           // a pixel that does not exist: h = l = 0
                 }
@@ -419,9 +433,36 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %2, %3" ::"v"(ah_), "v"(hv), "v"(al_), "v"(lv) : "memory");
             }
         };
-        auto write_a = [&](const float4 (&L)[NPASS][2], unsigned valid, int g, const float4 (&F)[PRE ? 6 : 1]) {   // a loaded chunk -> split -> buffer g % NPB
+        // PRE: the factors of the chunk that is written NEXT are read from the LDS table one iteration ahead (hand-written reads:
+        // hipcc would wait vmcnt(0) in front of them); the iteration's own s_waitcnt lgkmcnt(0) in front of its barrier covers them
+        int w_q = 0;                                                   // chunk (of its tile) whose factors are read next
+        f32x4 Fn[PRE ? 6 : 1];
+        auto read_factors = [&]() {
+            if constexpr (PRE) {
+                const int cch = PATCH ? w_q : w_q % nc;
+                const unsigned a0 = ptab_lane + 128u * (unsigned)cch, rs = 4u * (unsigned)p.Cin;
+                const unsigned a1 = a0 + rs, a2 = a1 + rs;
+                asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
+                             "ds_read_b128 %4, %8\n\tds_read_b128 %5, %8 offset:16"
+                             : "=&v"(Fn[0]), "=&v"(Fn[1]), "=&v"(Fn[2]), "=&v"(Fn[3]), "=&v"(Fn[4]), "=&v"(Fn[5])
+                             : "v"(a0), "v"(a1), "v"(a2)
+                             : "memory");
+                if (++w_q == CH) w_q = 0;
+            }
+        };
+        if constexpr (PRE) {
+            read_factors();
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Fn[0]), "+v"(Fn[1]), "+v"(Fn[2]), "+v"(Fn[3]), "+v"(Fn[4]), "+v"(Fn[5])::"memory");
+        }
+        auto write_a = [&](const float4 (&L)[NPASS][2], unsigned valid, int g) {   // a loaded chunk -> split -> buffer g % NPB
+            f32x4 F[PRE ? 6 : 1];
+            if constexpr (PRE) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) F[k] = Fn[k];
+            }
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) write_pass(L[q][0], L[q][1], valid, g, q, F);
+            read_factors();                                            // (for the next chunk; waited for before this iteration's barrier)
         };
         // Iteration s (from -2; a barrier closes it from -1 on, the first one releases the consumers):
         //   A  the chunk whose first stage is s + 2 goes to LDS (its buffer was last read for a stage whose reads are
@@ -449,11 +490,14 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             for (int u = 0; u < UNR; ++u) {
                 const int si = s + u;
                 if (si >= S) break;
-                if (si == -2) up = __builtin_ldexpf(1.f, split_exponent(wave_max(fmaxf(fmaxf(am4.x, am4.y), fmaxf(am4.z, am4.w)))));
+                if (si == -2) {
+                    const float amx = wave_max(fmaxf(fmaxf(am4.x, am4.y), fmaxf(am4.z, am4.w)));
+                    up = __builtin_ldexpf(1.f, split_exponent(amx));
+                    if (PRE && !(amx < INFINITY)) up = __builtin_nanf("");   // the table saw a NaN / infinity (nw_bn_nhwc_prep_*)
+                }
                 if (!PATCH || u == 0) {
                     constexpr int SET_MASK = NSET - 1;
                     float4 (&L)[NPASS][2] = ld[PATCH ? 0 : (u & SET_MASK)];
-                    float4 (&F_)[PRE ? 6 : 1] = pf[PATCH ? 0 : (u & SET_MASK)];
                     unsigned& V_ = ldvalid[PATCH ? 0 : (u & SET_MASK)];
                     // the chunk's loads have landed: all but what was issued after them
                     NW_CSTAMP(0);                                                  // bookkeeping
@@ -461,11 +505,11 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     else wait_vmcnt<NSET * NIW + (NSET - 1) * NACT>();
                     NW_CSTAMP(1);                                                  // wait: the chunk's loads
                     if (si >= -2) {
-                        if (w_g < QT) write_a(L, V_, w_g, F_);
+                        if (w_g < QT) write_a(L, V_, w_g);
                         ++w_g;
                     }
                     NW_CSTAMP(2);                                                  // convert + LDS stores
-                    issue_a(L, V_, F_);
+                    issue_a(L, V_);
                     NW_CSTAMP(3);                                                  // issue of the next chunk's loads
                 }
                 issue_w();
@@ -476,7 +520,10 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                 } else {
                     wait_vmcnt<(AH - 2) * (NACT + NIW)>();
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (PRE)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Fn[0]), "+v"(Fn[1]), "+v"(Fn[2]), "+v"(Fn[3]), "+v"(Fn[4]), "+v"(Fn[5])::"memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 NW_CSTAMP(4);                                                      // wait: stage s + 2's weights
                 if (si >= -1) __builtin_amdgcn_s_barrier();
                 NW_CSTAMP(5);                                                      // barrier
@@ -569,6 +616,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             for (int e = 0; e < 4; ++e) { rmean[a][e] = m[e]; rm2[a][e] = q[e]; }
         }
     };
+    if constexpr (PRE) __builtin_amdgcn_s_barrier();               // (the loaders have staged the BatchNorm table)
     __builtin_amdgcn_s_barrier();                                  // the prologue's stages have landed
     NW_CSTAMP(0);                                                  // wait for the pipeline fill
     for (int tl = 0; tl < ntile; ++tl) {
@@ -993,15 +1041,17 @@ int launch_conv_cfg(ConvP p, hipStream_t st, int64_t* moments_groups = nullptr, 
     if (p.pre) {   // BatchNorm + ReLU in the loaders: training forward (statistics), inference (bias / ReLU behind it) or plain
         if constexpr (MODE == CV_GATHER || MODE == CV_PATCH) {
             using CP = ConvCfg<NA, NB, WM, MODE, true>;
-            constexpr size_t ldsp = CP::LDS + (NA == 4 && NB == 4 ? 4096 : 0);
-            static_assert(ldsp <= 160 * 1024, "LDS");
+            constexpr size_t ldsp0 = CP::LDS + (NA == 4 && NB == 4 ? 4096 : 0);
+            static_assert(ldsp0 <= 160 * 1024, "LDS");
+            const size_t ldsp = ldsp0 + (size_t)12 * p.Cin;        // + the BatchNorm table of the input channels
+            if (ldsp > 160 * 1024) return NW_ERR_UNSUPPORTED;
             auto kp0 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false, false, true>;
             auto kp1 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, true, false, true>;
             auto kp2 = nw_conv_nhwc_kernel<NA, NB, WM, MODE, false, true, true>;
             static const bool attrp = [&] {
                 bool ok = true;
                 for (const void* k : {reinterpret_cast<const void*>(kp0), reinterpret_cast<const void*>(kp1), reinterpret_cast<const void*>(kp2)})
-                    ok = ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp) == hipSuccess;
+                    ok = ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
                 return ok;
             }();
             if (!attrp) return NW_ERR_LAUNCH;
