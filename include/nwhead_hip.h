@@ -368,12 +368,17 @@ int nw_conv2d_nhwc_f16x2(const float *x, const float *amax_in, const float *w_sp
  * :86-90 likewise): y = conv(relu((x - mean) a + beta)), a = gamma / sqrt(var + eps).
  *   pre      3 Cin floats: mean | a | beta of the Cin channels the convolution reads (nw_bn_nhwc_prep_f32 /
  *            nw_bn_nhwc_prep_from_partials_f32 make it; an inference caller fills it from the running statistics)
- *   amax_in  bounds |relu((x - mean) a + beta)| (the same two entries leave the exact bound; any upper bound is legal)
+ *   amax_in  raw_records == 0: ONE amax record bounding |relu((x - mean) a + beta)| (the same two entries leave the exact
+ *            bound; any upper bound is legal).  raw_records = n > 0 (an inference caller without batch statistics): n
+ *            consecutive amax records of the RAW tensor x -- those of its producers: a dense block's input and every layer's
+ *            output so far -- and the kernel derives the bound itself, max_c |a_c| (A + |mean_c|) + max(beta_c, 0) with A the
+ *            records' maximum
  *   bias / relu: the inference epilogue (a folded BatchNorm behind the convolution); moments: as nw_conv2d_nhwc_f16x2.
  * `moments` of this and of nw_conv2d_nhwc_f16x2 hold FIVE rows per group since round 4: count, mean, M2, minimum,
  * maximum (5 G Cout floats). */
-int nw_conv2d_nhwc_bnrelu_f16x2(const float *x, const float *pre, const float *amax_in, const float *w_split,
-                                const float *w_scale, const float *bias, int relu, float *y, float *amax_out, int64_t n,
+int nw_conv2d_nhwc_bnrelu_f16x2(const float *x, const float *pre, const float *amax_in, int64_t raw_records,
+                                const float *w_split, const float *w_scale, const float *bias, int relu, float *y,
+                                float *amax_out, int64_t n,
                                 int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                                 int64_t pad, int64_t ldx, int64_t ldy, float *moments, void *stream);
 int64_t nw_conv2d_nhwc_moments_groups(int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,

@@ -70,7 +70,7 @@ SIGNATURES = {
     "nw_bn_nhwc_prep_window_from_partials_f32": (_int, [_p, _i64, _i64, _i64, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                                         _p, C.c_float, _int, _p, _p, _p]),
     "nw_bn_nhwc_prep_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_float, _int, _i64, _i64, _p, _p, _p]),
-    "nw_conv2d_nhwc_bnrelu_f16x2": (_int, [_p] * 6 + [_int, _p, _p] + [_i64] * 11 + [_p, _p]),
+    "nw_conv2d_nhwc_bnrelu_f16x2": (_int, [_p] * 3 + [_i64] + [_p] * 3 + [_int, _p, _p] + [_i64] * 11 + [_p, _p]),
     "nw_bn_relu_nhwc_apply_f32": (_int, [_p, _i64] + [_p] * 8 + [C.c_float, _p, _p, _i64, _i64, _int, _p]),
     "nw_split_conv_weights_f16x2": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "nw_conv2d_nhwc_wgrad_supported": (_int, [_i64] * 9),

@@ -46,6 +46,9 @@ struct ConvP {
     float* moments;          // nullable: per (tile row, wave row) group and output channel the count, mean, M2, minimum and
                              //   maximum of y (part[(k G + group) Cout + co], k = 0 .. 4, G = mtiles WN): BatchNorm's statistics
                              //   of y, and the bound on |relu(bn(y))| its consumer's split needs, without a pass over it
+    int pre_nrec;            // PRE: 0: amax_in bounds |x'| itself; n > 0: amax_in holds n amax records of the RAW tensor x (an
+                             //   inference caller: the producers' records) and the kernel derives the bound from the table,
+                             //   max_c |a_c| (A + |mean_c|) + max(beta_c, 0) with A = the records' maximum
     const float* pre;        // nullable: [3][Cin] = mean | a | beta -- the convolution reads x' = relu((x - mean) a + beta), a
                              //   BatchNorm + ReLU applied by the loaders on the way into LDS (round 4: model/densenet.py:36-45's
                              //   norm1-relu1-conv1 / norm2-relu2-conv2 without the tensors between them); amax_in bounds |x'|
@@ -80,7 +83,7 @@ struct ConvCfg {
     static constexpr int NSET = PATCH ? 1 : (MODE == CV_ROWRUN ? 2 : 4);
     static constexpr int UNR = PATCH ? 9 : NSET;                  // the loaders' loop is unrolled over one period of their issue order
     // weight ring depth (PRE: the BatchNorm table of the input channels -- 12 bytes per channel -- sits in LDS behind the rings)
-    static constexpr int NWR = MODE == CV_ROWRUN ? 4 : (BN == 128 ? (PATCH ? 4 : (PRE ? 5 : 6)) : 8);
+    static constexpr int NWR = MODE == CV_ROWRUN ? 4 : (BN == 128 ? (PATCH ? 4 : (PRE ? 5 : 6)) : (PATCH ? 8 : 6));
     static constexpr int AH = NWR - 1;                            // weight stages issued ahead
     static constexpr int WST = BN * 128, PB = EMAX * 128;
     // activation buffers: a chunk is written two stages before its first stage; the first stage of a TILE is read at
@@ -97,6 +100,21 @@ struct ConvCfg {
 __device__ __forceinline__ float amax_read(const float* rec, int lane) {
     const float4 v = reinterpret_cast<const float4*>(rec)[lane];
     return wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+}
+// PRE with raw records (ConvP::pre_nrec > 0): the bound on |relu((x - mean) a + beta)| from the table in LDS and the maximum A of
+// the n records; every wave computes the same value (no hand-over)
+__device__ __forceinline__ float pre_bound_from_table(const float* tab_lds, int Cin, const float* rec, int nrec, int lane) {
+    float A = 0.f;
+    for (int k = lane; k < 64 * nrec; k += 64) {
+        const float4 v = reinterpret_cast<const float4*>(rec)[k];
+        A = fmaxf(A, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    A = wave_max(A);
+    float b = 0.f;
+    for (int c = lane; c < Cin; c += 64)
+        b = fmaxf(b, __builtin_fmaf(fabsf(tab_lds[Cin + c]), A + fabsf(tab_lds[c]), fmaxf(tab_lds[2 * Cin + c], 0.f)));
+    b = wave_max(b);
+    return (A < INFINITY && b < INFINITY) ? b : INFINITY;
 }
 // 16-byte slot of piece s (0-3: the h halves of channels 8 s .. 8 s + 7, 4-7: the l halves) inside the 128-byte LDS row of
 // activation entry e.  ds_read_b128 serves a wave in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... --
@@ -264,6 +282,8 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         unsigned aoff[NPASS];                                      // PATCH: source offset (floats) of the entry at chunk 0
         unsigned avalid = 0;                                       // bit q: the entry of pass q is a real pixel
         int gy[NPASS], gx[NPASS], gn[NPASS];                       // GATHER: s yo - pad, s xo - pad, n H  (gn < 0: no pixel)
+        unsigned gbase[NPASS];                                     // GATHER: element offset of tap (0, 0), chunk 0 of the pass's pixel
+        int g_t = 0, g_c = 0, g_dy = 0, g_dx = 0;                  // GATHER: the cursor's (tap, channel chunk), kept incrementally
         auto setup_tile = [&]() {
             const int t_id = tbeg + a_tile * nslot;
             const int m0 = (t_id / p.ntiles) * BM;
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     gy[q] = p.stride * yo - p.pad;
                     gx[q] = p.stride * xo - p.pad;
                     gn[q] = m < p.M ? n * p.H : -1;
+                    gbase[q] = (unsigned)(((gn[q] + gy[q]) * p.W + gx[q]) * p.ldx + 8 * lj);   // (wraps for a pixel that does not exist: unused then)
                 }
             }
         };
@@ -358,12 +379,20 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
                     L[q][1] = make_float4(v[4], v[5], v[6], v[7]);
                 }
             } else {
-                const int t = a_q / nc, c = a_q - t * nc, dy = t / p.KW, dx = t - dy * p.KW;
+                // (tap, chunk) of the cursor without divisions, the tap's offset once per chunk on the scalar unit: the loaders'
+                // issue path is what bounds the 1x1 layers (bench_conv stamps, 42 x 14 x 14 x 512 -> 128: 850 of a stage's 2 500
+                // ticks went into issuing two loads)
+                if (a_q == 0) g_t = g_c = g_dy = g_dx = 0;
+                const int dy = g_dy, dx = g_dx;
+                const unsigned tapoff = (unsigned)((dy * p.W + dx) * p.ldx + 32 * g_c);
+                if (live) {
+                    if (++g_c == nc) { g_c = 0; ++g_t; if (++g_dx == p.KW) { g_dx = 0; ++g_dy; } }
+                }
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q) {
                     const int yi = gy[q] + dy, xi = gx[q] + dx;
                     const bool ok = live && gn[q] >= 0 && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
-                    const unsigned off = (unsigned)(((gn[q] + yi) * p.W + xi) * p.ldx + 32 * c + 8 * lj);
+                    const unsigned off = gbase[q] + tapoff;
                     if (PRE) valid |= ok ? (1u << q) : 0u;
                     ldg2(L[q][0], L[q][1], pick(ok, p.x + off));
                 }
@@ -479,7 +508,13 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
         constexpr int S_BEGIN = -2 - UNR * ((V + UNR - 1) / UNR);
         w_skip = -AH - S_BEGIN > 0 ? -AH - S_BEGIN : 0;
         a_skip = (!PATCH && (-2 - NSET) - S_BEGIN > 0) ? (-2 - NSET) - S_BEGIN : 0;
-        const float4 am4 = reinterpret_cast<const float4*>(p.amax_in)[lane];   // the tensor's amax record (used at iteration -2)
+        float4 am4 = reinterpret_cast<const float4*>(p.amax_in)[lane];   // the tensor's amax record (used at iteration -2)
+        if constexpr (PRE) {
+            if (p.pre_nrec > 0) {
+                const float b = pre_bound_from_table(reinterpret_cast<const float*>(ptab), p.Cin, p.amax_in, p.pre_nrec, lane);
+                am4 = make_float4(b, b, b, b);
+            }
+        }
         int w_g = 0;                                                   // next chunk to write
 #ifdef NW_CONV_DIAG
         unsigned long long cd_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cl_ = __builtin_amdgcn_s_memtime();
@@ -545,7 +580,8 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
     const int wco = (wave % WM) * (16 * NA), wpx = (wave / WM) * (16 * NB);
     const int asw = (i >> 1) & 7;
     const int aoff_h = (wco + i) * 128 + ((g ^ asw) << 4), aoff_l = (wco + i) * 128 + (((4 + g) ^ asw) << 4);
-    const float inv_up = __builtin_ldexpf(1.f, -split_exponent(amax_read(p.amax_in, lane)));
+    float inv_up = 1.f;
+    if (!(PRE && p.pre_nrec > 0)) inv_up = __builtin_ldexpf(1.f, -split_exponent(amax_read(p.amax_in, lane)));
     struct Frag {
         float4 ah[NA], al[NA], bh[NB], bl[NB];
     };
@@ -616,7 +652,12 @@ __global__ __launch_bounds__(512, 1) void nw_conv_nhwc_kernel(const ConvP p) {
             for (int e = 0; e < 4; ++e) { rmean[a][e] = m[e]; rm2[a][e] = q[e]; }
         }
     };
-    if constexpr (PRE) __builtin_amdgcn_s_barrier();               // (the loaders have staged the BatchNorm table)
+    if constexpr (PRE) {
+        __builtin_amdgcn_s_barrier();                              // (the loaders have staged the BatchNorm table)
+        if (p.pre_nrec > 0)
+            inv_up = __builtin_ldexpf(1.f, -split_exponent(pre_bound_from_table(reinterpret_cast<const float*>(ptab), p.Cin, p.amax_in,
+                                                                                 p.pre_nrec, lane)));
+    }
     __builtin_amdgcn_s_barrier();                                  // the prologue's stages have landed
     NW_CSTAMP(0);                                                  // wait for the pipeline fill
     for (int tl = 0; tl < ntile; ++tl) {
@@ -1118,7 +1159,8 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
                            const float* bias, const float* residual, int relu, float* y, float* amax_out,
                            int64_t n, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                            int64_t stride, int64_t pad, int64_t ldx, int64_t ldy, float* moments, int64_t* moments_groups,
-                           bool dry, void* stream, const nw_conv_bnstat* bnstat = nullptr, const float* pre = nullptr) {
+                           bool dry, void* stream, const nw_conv_bnstat* bnstat = nullptr, const float* pre = nullptr,
+                           int64_t pre_nrec = 0) {
     if (n < 0 || H < 0 || W < 0) return NW_ERR_INVALID_ARG;
     if (moments_groups) *moments_groups = 0;
     if (n == 0) return NW_OK;
@@ -1142,6 +1184,8 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
     p.x = x; p.amax_in = amax_in; p.ws = reinterpret_cast<const char*>(w_split); p.wscale = w_scale; p.bias = bias;
     p.res = residual; p.y = y; p.amax_out = amax_out; p.moments = moments;
     p.pre = pre;
+    p.pre_nrec = (int)pre_nrec;
+    if (pre_nrec < 0 || pre_nrec > 4096 || (!pre && pre_nrec)) return NW_ERR_INVALID_ARG;
     if (pre && (Cin % 32 || (reinterpret_cast<uintptr_t>(pre) & 15))) return NW_ERR_INVALID_ARG;
     p.bnb_x = p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_part = nullptr; p.bnb_ldx = 0;
     if (bnstat) {
@@ -1213,14 +1257,15 @@ extern "C" int nw_conv2d_nhwc_f16x2(const float* x, const float* amax_in, const 
                             pad, ldx, ldy, moments, moments ? &groups : nullptr, false, stream);
 }
 
-extern "C" int nw_conv2d_nhwc_bnrelu_f16x2(const float* x, const float* pre, const float* amax_in, const float* w_split,
-                                           const float* w_scale, const float* bias, int relu, float* y, float* amax_out, int64_t n,
+extern "C" int nw_conv2d_nhwc_bnrelu_f16x2(const float* x, const float* pre, const float* amax_in, int64_t raw_records,
+                                           const float* w_split, const float* w_scale, const float* bias, int relu, float* y,
+                                           float* amax_out, int64_t n,
                                            int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                                            int64_t pad, int64_t ldx, int64_t ldy, float* moments, void* stream) {
     if (!pre) return NW_ERR_INVALID_ARG;
     int64_t groups = 0;
     return conv2d_nhwc_impl(x, amax_in, w_split, w_scale, bias, nullptr, relu, y, amax_out, n, H, W, Cin, Cout, KH, KW, stride, pad,
-                            ldx, ldy, moments, moments ? &groups : nullptr, false, stream, nullptr, pre);
+                            ldx, ldy, moments, moments ? &groups : nullptr, false, stream, nullptr, pre, raw_records);
 }
 
 extern "C" int nw_conv2d_nhwc_bnstat_f16x2(const float* x, const float* amax_in, const float* w_split, const float* w_scale, float* y,

@@ -355,7 +355,92 @@ class DenseNet(nn.Module):
         if (NHWC_TRAINING and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and x.dim() == 4 and x.shape[1] == 3 and self._nhwc_servable()):
             return self._forward_nhwc_train(x)
+        if (NHWC_INFERENCE and not self.training and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and x.dim() == 4 and x.shape[1] == 3 and self._nhwc_servable() and self._nhwc_infer_servable(x)):
+            return self._forward_nhwc_infer(x)
         return torch.flatten(F.adaptive_avg_pool2d(F.relu(self.features(x)), (1, 1)), 1)
+
+    # ------------------------------------------------------------------ inference on the channels-last kernels (round 4)
+    def _nhwc_infer_servable(self, x):
+        """The module sequence the inference plan covers: the reference's (densenet.py:114-145), plain BatchNorm2d / Conv2d
+        modules with running statistics (a copy fold_batchnorm has rewritten runs its own modules), the reference's pools,
+        no dropout, maps that halve cleanly."""
+        f = self.features
+        mods = list(f.children())
+        if not (isinstance(f.conv0, nn.Conv2d) and type(f.norm0) is nn.BatchNorm2d and type(f.norm5) is nn.BatchNorm2d
+                and _is_pool(f.pool0, nn.MaxPool2d, 3, 2, 1) and f.conv0.stride == (2, 2) and f.conv0.padding == (3, 3)):
+            return False
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d) and (m.running_mean is None or not m.affine):
+                return False
+            if isinstance(m, _DenseLayer) and (m.drop_rate > 0 or type(m.norm1) is not nn.BatchNorm2d or type(m.norm2) is not nn.BatchNorm2d
+                                               or not isinstance(m.conv1, nn.Conv2d) or not isinstance(m.conv2, nn.Conv2d)
+                                               or m.conv2.kernel_size != (3, 3)):
+                return False
+            if isinstance(m, _Transition) and (type(m.norm) is not nn.BatchNorm2d or not isinstance(m.conv, nn.Conv2d)
+                                               or not _is_pool(m.pool, nn.AvgPool2d, 2, 2, 0)):
+                return False
+        hw = ((x.shape[2] + 6 - 7) // 2 + 1, (x.shape[3] + 6 - 7) // 2 + 1)
+        hw = ((hw[0] - 1) // 2 + 1, (hw[1] - 1) // 2 + 1)
+        for mod in mods:
+            if isinstance(mod, _Transition):
+                if hw[0] % 2 or hw[1] % 2:
+                    return False
+                hw = (hw[0] // 2, hw[1] // 2)
+        return min(hw) >= 1
+
+    def _infer_plan(self, dev):
+        """Per module what the inference kernels read: folded split-row weights, biases, BatchNorm tables.  Rebuilt when a
+        parameter or buffer has changed (address or in-place version)."""
+        from .. import ops
+        ts = list(self.parameters()) + list(self.buffers())
+        sig = (str(dev), len(ts), sum(0 if t.is_inference() else t._version for t in ts), sum(t.data_ptr() & 0xffffff for t in ts))
+        plan = getattr(self, "_nw_infer_plan", None)
+        if plan is not None and plan["sig"] == sig:
+            return plan
+        f = self.features
+
+        def fold(conv, bn):         # conv -> BatchNorm as one weight and bias
+            a = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+            wf = conv.weight.detach().float() * a.view(-1, 1, 1, 1)
+            b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(a)
+            return ops.SplitConvWeight(wf), (bn.bias.detach().float() + (b0 - bn.running_mean.detach().float()) * a).contiguous()
+        plan = {"sig": sig, "stem": fold(f.conv0, f.norm0), "mods": []}
+        for mod in f.children():
+            if isinstance(mod, _DenseBlock):
+                layers = []
+                for layer in mod.children():
+                    w1, b1 = fold(layer.conv1, layer.norm2)
+                    layers.append((ops.bn_table(layer.norm1), w1, b1, ops.SplitConvWeight(layer.conv2.weight.detach().float())))
+                plan["mods"].append(("block", layers))
+            elif isinstance(mod, _Transition):
+                plan["mods"].append(("transition", (ops.bn_table(mod.norm), ops.SplitConvWeight(mod.conv.weight.detach().float()))))
+        object.__setattr__(self, "_nw_infer_plan", plan)
+        return plan
+
+    @torch.no_grad()
+    def _forward_nhwc_infer(self, x):
+        """Eval-mode forward on the channels-last split-fp16 kernels (the copy of round 2 ran NCHW fp32-MFMA
+        kernels and MIOpen's stem): folded stem convolution + ReLU, max pool into the first block's slab, dense blocks as two
+        launches per layer with the BatchNorms in the convolutions (ops.dense_block_nhwc_infer), transitions in the
+        reference's order norm-relu-conv-pool with norm + relu in the convolution's loaders."""
+        from .. import ops
+        f = self.features
+        plan = self._infer_plan(x.device)
+        mods = [m for m in f.children() if isinstance(m, (_DenseBlock, _Transition))]
+        rooms = [m.slab_room() if isinstance(m, _DenseBlock) else 0 for m in mods] + [0]
+        w0, b0 = plan["stem"]
+        y = ops.conv2d_nhwc(x, w0, b0, None, True, 2, 3)
+        y = ops.maxpool3s2_nhwc(y, rooms[0])
+        for i, (mod, (kind, pl)) in enumerate(zip(mods, plan["mods"])):
+            if kind == "block":
+                y = ops.dense_block_nhwc_infer(y, pl)
+            else:
+                tab, wt = pl
+                y = ops.avgpool2_nhwc(ops.conv1x1_bnrelu_nhwc_infer(y, tab, wt), rooms[i + 1])
+        n5 = f.norm5
+        y = F.relu(F.batch_norm(y, n5.running_mean, n5.running_var, n5.weight, n5.bias, False, 0.0, n5.eps))
+        return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
 
     def _nhwc_servable(self):
         """Do the channels-last kernels serve every layer?  (convolutions: input and output channels in multiples of 32 --
@@ -415,6 +500,9 @@ class DenseNet(nn.Module):
                     y = ops.avgpool2_nhwc(z, room(i)) if _is_pool(mod.pool, nn.AvgPool2d, 2, 2, 0) else mod.pool(z)
         y = ops.bn_relu_train_nhwc(y, f.norm5)          # (norm5 + the relu of DenseNet.forward)
         return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
+
+
+NHWC_INFERENCE = True        # DenseNet.forward in eval mode on the device: the channels-last inference path above
 
 
 class ScaleShiftReLU(nn.Module):
@@ -730,7 +818,15 @@ def fold_batchnorm(model):
     the weights change."""
     import copy
     m = copy.deepcopy(model).eval()
+    # A DenseNet on the device that the channels-last inference path serves (DenseNet._forward_nhwc_infer: it folds for itself,
+    # from the plain modules) stays as it is; its eval forward on other tensors is the reference's module sequence.
+    keep = set()
+    for mod in m.modules():
+        if isinstance(mod, DenseNet) and NHWC_INFERENCE and mod._nhwc_servable() and next(mod.parameters()).is_cuda:
+            keep.update(id(x) for x in mod.modules())
     for mod in list(m.modules()):                # (the featurizer may sit inside a Sequential: proj_dim > 0)
+        if id(mod) in keep:
+            continue
         if isinstance(mod, DenseNet):
             f = mod.features
             f.conv0, f.norm0 = _fold_pair(f.conv0, f.norm0), nn.Identity()

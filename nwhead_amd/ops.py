@@ -1423,14 +1423,14 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                 G1 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, c, mid, 1, 1, 1, 0)
                 G2 = lib.nw_conv2d_nhwc_moments_groups(n, h, w, mid, growth, kh, kh, 1, kh // 2)
                 part = _workspace(4 * 5 * max(G1 * mid, G2 * growth), dev)
-                _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(_ptr(slab), _ptr(tab1), _ptr(am1), _ptr(o1[0].split), _ptr(o1[0].scale), None, 0,
+                _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(_ptr(slab), _ptr(tab1), _ptr(am1), 0, _ptr(o1[0].split), _ptr(o1[0].scale), None, 0,
                                                            _ptr(u), None, n, h, w, c, mid, 1, 1, 1, 0, ctot, 0, _ptr(part), st),
                            "nw_conv2d_nhwc_bnrelu_f16x2")
                 rm, rv, mom, nbt = _bn_tracking(layer.norm2)
                 _lib.check(lib.nw_bn_nhwc_prep_from_partials_f32(_ptr(part), G1, mid, eps, _ptr(m2), _ptr(i2), _ptr(v2), _ptr(lo2),
                                                                  _ptr(hi2), _ptr(g2), _ptr(b2), _ptr(rm), _ptr(rv), _ptr(nbt), mom, 1,
                                                                  _ptr(tab2), _ptr(am2), st), "nw_bn_nhwc_prep_from_partials_f32")
-                _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(_ptr(u), _ptr(tab2), _ptr(am2), _ptr(o2[0].split), _ptr(o2[0].scale), None, 0,
+                _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(_ptr(u), _ptr(tab2), _ptr(am2), 0, _ptr(o2[0].split), _ptr(o2[0].scale), None, 0,
                                                            slab.data_ptr() + 4 * c, None, n, h, w, mid, growth, kh, kh, 1, kh // 2, 0,
                                                            ctot, _ptr(part), st), "nw_conv2d_nhwc_bnrelu_f16x2")
                 saved += [u, stats, tab1, am1, tab2, am2, g1, b1, g2, b2]
@@ -1566,6 +1566,76 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
             dx = G[:, :c0]                  # a channel prefix of the gradient slab (the pools' backward reads strided rows)
             dx.nw_amax = am_g
         return (dx, None, None, *grads)
+
+
+def bn_table(bn):
+    """mean | a | beta (3 c floats) of an eval-mode BatchNorm2d for nw_conv2d_nhwc_bnrelu_f16x2: y = (x - mean) a + beta."""
+    a = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    return torch.cat((bn.running_mean.detach().float(), a, bn.bias.detach().float())).contiguous()
+
+
+@torch.no_grad()
+def dense_block_nhwc_infer(x, plan):
+    """A dense block (model/densenet.py:62-80) at inference over ONE channels-last slab, two launches per layer:
+    conv1 = nw_conv2d_nhwc_bnrelu_f16x2 (norm1 + relu1 in its loaders, norm2 folded into its weight and bias, relu2 in its
+    store) and conv2 = nw_conv2d_nhwc_f16x2 writing its `growth` channels into the slab.  plan: per layer (table of norm1,
+    SplitConvWeight of the folded conv1, its bias, SplitConvWeight of conv2).  The bound conv1's loaders need is derived in the
+    kernel from the amax records of everything in the slab so far (the input's and every conv2's: `raw_records`).  Returns the
+    slab (n, C0 + L growth, h, w) with `.nw_records` (L + 1 records)."""
+    lib = _lib.load()
+    xv, ldx0 = _nhwc_rows(x)
+    n, c0, h, w = xv.shape
+    dev, L = xv.device, len(plan)
+    growth, mid = plan[0][3].shape[0], plan[0][1].shape[0]
+    ctot = c0 + L * growth
+    slab = getattr(x, "nw_slab", None)
+    if not (slab is not None and tuple(slab.shape) == (n, ctot, h, w) and slab.data_ptr() == xv.data_ptr() and ldx0 == ctot
+            and slab.dtype == torch.float32 and slab.is_contiguous(memory_format=torch.channels_last)):
+        slab = torch.empty((n, ctot, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        slab[:, :c0] = xv
+    f32 = dict(dtype=torch.float32, device=dev)
+    recs = torch.empty((L + 1) * AMAX_SLOTS, **f32)
+    am0 = getattr(x, "nw_amax", None)
+    recs[:AMAX_SLOTS].copy_(am0 if am0 is not None else absmax(xv if ldx0 == c0 else xv.contiguous(memory_format=torch.channels_last)))
+    u = torch.empty((n * h * w, mid), **f32)
+    am_u = torch.empty(AMAX_SLOTS, **f32)
+    st = _stream(xv)
+    with _OnDevice(dev):
+        for k, (tab1, w1, b1, w2) in enumerate(plan):
+            c = c0 + k * growth
+            kh = w2.shape[2]
+            _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(_ptr(slab), _ptr(tab1), _ptr(recs), k + 1, _ptr(w1.split), _ptr(w1.scale), _ptr(b1),
+                                                       1, _ptr(u), _ptr(am_u), n, h, w, c, mid, 1, 1, 1, 0, ctot, 0, None, st),
+                       "nw_conv2d_nhwc_bnrelu_f16x2")
+            _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(u), _ptr(am_u), _ptr(w2.split), _ptr(w2.scale), None, None, 0,
+                                                slab.data_ptr() + 4 * c, recs.data_ptr() + 4 * AMAX_SLOTS * (k + 1), n, h, w, mid, growth,
+                                                kh, kh, 1, kh // 2, 0, ctot, None, st), "nw_conv2d_nhwc_f16x2")
+    slab.nw_records = recs
+    return slab
+
+
+@torch.no_grad()
+def conv1x1_bnrelu_nhwc_infer(x, tab, weight, records=None, room=0):
+    """conv1x1(relu(bn(x))) of a DenseNet transition at inference (model/densenet.py:86-90; nw_conv2d_nhwc_bnrelu_f16x2)
+    over a channels-last activation; records: the amax records of x's producers (default: x.nw_records / x.nw_amax)."""
+    lib = _lib.load()
+    xv, ldx = _nhwc_rows(x)
+    n, c, h, w = xv.shape
+    cout = weight.shape[0]
+    if records is None:
+        records = getattr(x, "nw_records", None)
+        if records is None:
+            records = getattr(x, "nw_amax", None)
+        if records is None:
+            records = absmax(xv if ldx == c else xv.contiguous(memory_format=torch.channels_last))
+    y, ldy = _with_room(n, cout, h, w, room, xv.device)
+    am = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=xv.device)
+    with _OnDevice(xv.device):
+        _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(_ptr(xv), _ptr(tab), _ptr(records), records.numel() // AMAX_SLOTS, _ptr(weight.split),
+                                                   _ptr(weight.scale), None, 0, _ptr(y), _ptr(am), n, h, w, c, cout, 1, 1, 1, 0, ldx,
+                                                   ldy if room > 0 else 0, None, _stream(xv)), "nw_conv2d_nhwc_bnrelu_f16x2")
+    y.nw_amax = am
+    return y
 
 
 def dense_block_nhwc_supported(x, layers, bank):

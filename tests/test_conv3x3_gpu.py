@@ -67,15 +67,16 @@ def test_folded_densenets_with_fused_3x3():
             net(torch.randn(4, 3, side, side, device=dev))
         net.eval()
         x = torch.randn(batch, 3, side, side, device=dev)
-        was = bb.FUSED_CONV3X3
+        was, was_nhwc = bb.FUSED_CONV3X3, bb.NHWC_INFERENCE
         bb.FUSED_CONV3X3 = True                      # (the default; NW_OWN_CONV3X3=0 in the environment turns it off)
+        bb.NHWC_INFERENCE = False                    # (round 4: DenseNet-121 itself runs the channels-last path; see test_conv1x1_gpu)
         try:
             folded = fold_batchnorm(net)
+            assert sum(isinstance(m, bb.Conv3x3Fused) for m in folded.modules()) == 58
+            with torch.no_grad():
+                want, got = net(x), folded(x)
         finally:
-            bb.FUSED_CONV3X3 = was
-        assert sum(isinstance(m, bb.Conv3x3Fused) for m in folded.modules()) == 58
-        with torch.no_grad():
-            want, got = net(x), folded(x)
+            bb.FUSED_CONV3X3, bb.NHWC_INFERENCE = was, was_nhwc
         scale = float(want.abs().max())
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
 

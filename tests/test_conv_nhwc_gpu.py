@@ -530,7 +530,7 @@ def test_conv_with_batchnorm_relu_in_the_loaders(dev, n, cin, h, w, cout, k, wid
     G = lib.nw_conv2d_nhwc_moments_groups(n, h, w, cin, cout, k, k, 1, pad)
     part = torch.empty(5 * G * cout, **f32) if moments else None
     am_out = torch.empty(ops.AMAX_SLOTS, **f32)
-    _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(x.data_ptr(), tab.data_ptr(), am.data_ptr(), sw.split.data_ptr(), sw.scale.data_ptr(),
+    _lib.check(lib.nw_conv2d_nhwc_bnrelu_f16x2(x.data_ptr(), tab.data_ptr(), am.data_ptr(), 0, sw.split.data_ptr(), sw.scale.data_ptr(),
                                                None, 0, y.data_ptr(), am_out.data_ptr(), n, h, w, cin, cout, k, k, 1, pad, ctot, 0,
                                                None if part is None else part.data_ptr(), st), "conv bnrelu")
     ref = F.conv2d(t_ref, wt.double(), None, 1, pad)
@@ -741,3 +741,36 @@ def test_k2_resnet18_plus_head_end_to_end(dev, folding):
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 2e-3, err
     assert (out.argmax(-1).cpu() == ref.argmax(-1)).float().mean().item() > 0.98
+
+
+def test_densenet121_inference_on_the_channels_last_kernels(dev):
+    """DenseNet.forward in eval mode on the device (round 4: stem, pools, two launches per dense layer with the BatchNorms
+    inside the convolutions, transitions) against the fp64 network on the host, with trained-looking BatchNorm statistics
+    (channel scales over two decades, offsets); the folded copy NWNet builds is the same path; a weight update rebuilds the plan."""
+    from nwhead_amd.model import load_model, fold_batchnorm
+    torch.manual_seed(3)
+    net = load_model("densenet121").eval()
+    g = torch.Generator().manual_seed(5)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            c = m.num_features
+            m.running_mean.copy_(torch.randn(c, generator=g) * 0.3)
+            m.running_var.copy_(torch.exp(torch.randn(c, generator=g) * 1.0))
+            m.weight.data.copy_(torch.rand(c, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(c, generator=g) * 0.2)
+    x = torch.randn(5, 3, 96, 96, generator=g)
+    with torch.no_grad():
+        ref = net.double()(x.double())
+    net = net.float().to(dev)
+    with torch.no_grad():
+        y = net(x.to(dev))
+        assert getattr(net, "_nw_infer_plan", None) is not None          # the channels-last path ran
+        yf = fold_batchnorm(net)(x.to(dev))
+        sc = ref.abs().max().item()
+        assert (y.cpu().double() - ref).abs().max().item() < 2e-5 * sc
+        assert torch.equal(y, yf)
+        net.features.denseblock2.denselayer3.conv1.weight.mul_(0.5)       # in place: the plan follows
+        y2 = net(x.to(dev))
+        ref2 = net.cpu().double()(x.double())
+    assert (y2.cpu().double() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
+    assert not torch.allclose(y2, y)

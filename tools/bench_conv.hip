@@ -37,8 +37,17 @@ int main(int argc, char** argv) {
     hipMalloc(&am, 1024); hipMalloc(&amo, 1024);
     hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice); hipMemcpy(ws, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(sc, hs.data(), cout * 4, hipMemcpyHostToDevice); hipMemcpy(am, ham.data(), 1024, hipMemcpyHostToDevice);
+    // NW_BC_MOMENTS=1: with the moments epilogue; NW_BC_PRE=1: BatchNorm + ReLU in the loaders (identity table)
+    float* mom = nullptr; float* tab = nullptr;
+    if (getenv("NW_BC_MOMENTS")) hipMalloc(&mom, (size_t)5 * 4 * nw_conv2d_nhwc_moments_groups(n, h, w, cin, cout, k, k, 1, pad) * cout + 64);
+    if (getenv("NW_BC_PRE")) {
+        std::vector<float> ht(3 * cin, 0.f);
+        for (int64_t c = 0; c < cin; ++c) ht[cin + c] = 1.f;
+        hipMalloc(&tab, ht.size() * 4); hipMemcpy(tab, ht.data(), ht.size() * 4, hipMemcpyHostToDevice);
+    }
     auto launch = [&] {
-        return nw_conv2d_nhwc_f16x2(x, am, ws, sc, nullptr, nullptr, 0, y, amo, n, h, w, cin, cout, k, k, 1, pad, 0, 0, nullptr, nullptr);
+        if (tab) return nw_conv2d_nhwc_bnrelu_f16x2(x, tab, am, 0, ws, sc, nullptr, 0, y, amo, n, h, w, cin, cout, k, k, 1, pad, 0, 0, mom, nullptr);
+        return nw_conv2d_nhwc_f16x2(x, am, ws, sc, nullptr, nullptr, 0, y, amo, n, h, w, cin, cout, k, k, 1, pad, 0, 0, mom, nullptr);
     };
     int rc = launch();
     if (rc) { std::printf("launch failed: %d\n", rc); return 1; }

@@ -30,10 +30,10 @@ for c in (256, 512, 992):
         lib.nw_conv2d_nhwc_f16x2(slab.data_ptr(), am_s.data_ptr(), sw.split.data_ptr(), sw.scale.data_ptr(), None, None, 0, u.data_ptr(), None,
                                  n, h, w, c, cout, 1, 1, 1, 0, ctot, 0, part.data_ptr(), st)
     def pre():
-        lib.nw_conv2d_nhwc_bnrelu_f16x2(slab.data_ptr(), tab.data_ptr(), am_s.data_ptr(), sw.split.data_ptr(), sw.scale.data_ptr(), None, 0,
+        lib.nw_conv2d_nhwc_bnrelu_f16x2(slab.data_ptr(), tab.data_ptr(), am_s.data_ptr(), 0, sw.split.data_ptr(), sw.scale.data_ptr(), None, 0,
                                         u.data_ptr(), None, n, h, w, c, cout, 1, 1, 1, 0, ctot, 0, part.data_ptr(), st)
     def nostat():
-        lib.nw_conv2d_nhwc_bnrelu_f16x2(slab.data_ptr(), tab.data_ptr(), am_s.data_ptr(), sw.split.data_ptr(), sw.scale.data_ptr(), None, 0,
+        lib.nw_conv2d_nhwc_bnrelu_f16x2(slab.data_ptr(), tab.data_ptr(), am_s.data_ptr(), 0, sw.split.data_ptr(), sw.scale.data_ptr(), None, 0,
                                         u.data_ptr(), None, n, h, w, c, cout, 1, 1, 1, 0, ctot, 0, None, st)
     ts = [bench.time_kernel_events(f, 50) * 1e6 for f in (dense, prefix, pre, nostat)]
     print(f"c={c}: dense t1 {ts[0]:.1f} us | slab prefix {ts[1]:.1f} | bnrelu on the prefix {ts[2]:.1f} | ... without moments {ts[3]:.1f}", flush=True)
