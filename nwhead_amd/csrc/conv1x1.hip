@@ -254,15 +254,15 @@ __global__ __launch_bounds__(512, 2) void nw_conv1x1_dma_kernel(
 #pragma unroll
         for (int s = 0; s < DNBUF - 1; ++s)
             if (s < nst) issue(s);
-        if (nst >= DNBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nst >= DNBUF - 1) wait_vmcnt<2 * PER>();   // (tile_dma.h: the count is checked against the 6-bit field at compile time)
+        else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's share of `pre`)
         __builtin_amdgcn_s_barrier();
         for (int s = 0; s < nst; ++s) {
             if (s + DNBUF - 1 < nst) issue(s + DNBUF - 1);   // into the buffer the consumers left at the last barrier
             // stage s + 1 of this wave has landed once at most the two youngest stages are in flight
-            if (s + DNBUF - 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s + DNBUF - 1 < nst) wait_vmcnt<2 * PER>();
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
         return;

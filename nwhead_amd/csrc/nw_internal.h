@@ -121,6 +121,14 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int w = 0; w < nw_; ++w) r += red[w];
     return r;
 }
+// counted wait for all but the wave's N youngest vector-memory operations; every counted wait of the library goes through
+// here so that the 6-bit field is checked at compile time (an overflow once hung the test suite: DESIGN.md 4.7h)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
     __syncthreads();

@@ -73,11 +73,7 @@ __device__ __forceinline__ int split_exponent(float rowmax) {
     return e;
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+// (wait_vmcnt<N>: nw_internal.h)
 
 // The loader role (waves 4-7), shared by the fp32 and the split-fp16 consumers: the stage image in
 // LDS is byte-identical in both (128 B per row per stage).

@@ -29,10 +29,13 @@ class _ChannelsLast(nn.Module):
 class NWHead(nn.Module):
     """forward(x:(B,d), sx:(N,d)|(B,N,d), sy:(N,)|(B,N)) -> (B, n_classes) log-probabilities."""
 
-    def __init__(self, kernel, n_classes):
+    def __init__(self, kernel, n_classes, validate_labels=False):
         super().__init__()
         self.kernel = kernel
         self.n_classes = n_classes
+        # not in the reference: its F.one_hot (nw.py:276) refuses support labels >= n_classes; here that check costs a device
+        # round trip per call, so it is an option (on under NWNet(debug_mode=True)); without it such supports are skipped
+        self.validate_labels = bool(validate_labels)
 
     def forward(self, x, sx, sy, return_weights=False, support_norm2=None, support_cache=None):
         if not isinstance(self.kernel, _ScoreModule):
@@ -46,7 +49,7 @@ class NWHead(nn.Module):
             return ops.nw_aggregate(scores, sy, self.n_classes)
         return ops.nw_head(x, sx, sy, self.n_classes, self.kernel.kind, self.kernel._logit_scale(),
                            return_weights=return_weights, support_norm2=support_norm2,
-                           support_cache=support_cache)
+                           support_cache=support_cache, validate_labels=self.validate_labels)
 
 
 class NWNet(nn.Module):
@@ -54,8 +57,9 @@ class NWNet(nn.Module):
                  kernel_type='euclidean', train_type='random', n_way=None, n_shot=1,
                  n_shot_random=1, n_shot_full=100, n_shot_cluster=1, n_neighbors=10,
                  env_array=None, debug_mode=False, device='cuda:0', return_mask=False, cluster_backend='auto',
-                 loader_workers=0, pin_memory=False):
+                 loader_workers=0, pin_memory=False, knn_per_query=False):
         super().__init__()
+        self.knn_per_query = bool(knn_per_query)  # not in the reference: 'knn' / 'hnsw' modes give every query ITS OWN neighbours
         self.cluster_backend = cluster_backend   # not in the reference: where 'cluster' mode's k-means runs (utils.compute_clusters)
         # not in the reference either (its bank loaders are single-process, support.py:164-165): DataLoader workers and
         # pinned staging for the loaders precompute() featurises the bank from; same row order whatever they are
@@ -73,7 +77,7 @@ class NWNet(nn.Module):
         self.device, self.return_mask = device, return_mask
         # registered twice on purpose: reference state_dicts carry both kernel.* and nwhead.kernel.*
         self.kernel = get_kernel(kernel_type)
-        self.nwhead = NWHead(self.kernel, n_classes)
+        self.nwhead = NWHead(self.kernel, n_classes, validate_labels=bool(debug_mode))
         if support_dataset is not None:
             self.support_train = SupportSetTrain(support_dataset, n_classes, train_type, n_shot,
                                                  n_way=n_way, env_array=env_array)
@@ -129,6 +133,7 @@ class NWNet(nn.Module):
         self.support_eval = SupportSetEval(support_dataset, self.n_classes, self.n_shot_random,
                                            self.n_shot_full, n_shot_cluster=self.n_shot_cluster,
                                            n_neighbors=self.n_neighbors, env_array=self.env_array,
+                                           knn_per_query=self.knn_per_query,
                                            cluster_backend=self.cluster_backend, loader_workers=self.loader_workers,
                                            pin_memory=self.pin_memory)
 

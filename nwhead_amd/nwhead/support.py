@@ -72,8 +72,10 @@ class SupportSetEval(SupportSet):
     MODES = ('random', 'full', 'cluster', 'ensemble', 'knn', 'hnsw')
 
     def __init__(self, support_set, n_classes, n_shot_random, n_shot_full, n_shot_cluster=3,
-                 n_neighbors=20, env_array=None, cluster_backend="auto", loader_workers=0, pin_memory=False):
+                 n_neighbors=20, env_array=None, cluster_backend="auto", loader_workers=0, pin_memory=False,
+                 knn_per_query=False):
         super().__init__(support_set, n_classes, env_array)
+        self.knn_per_query = bool(knn_per_query)      # utils.KNN(per_query=): each query its own neighbours (not in the reference)
         self.cluster_backend = cluster_backend        # utils.compute_clusters: 'auto' | 'sklearn' | 'device'
         self.n_shot_random, self.n_shot_full = n_shot_random, n_shot_full
         self.n_shot_cluster, self.n_neighbors = n_shot_cluster, n_neighbors
@@ -92,8 +94,8 @@ class SupportSetEval(SupportSet):
         cf, cy = compute_clusters(sfeat, sy, self.n_shot_cluster, backend=self.cluster_backend)
         self.cluster_feat, self.cluster_y = cf.to(dev), cy.to(dev)
         self.random_iter = InfiniteUniformClassLoader(FeatureDataset(sfeat, sy, smeta), self.n_shot_random)
-        self.knn = KNN(sfeat, sy, n_neighbors=self.n_neighbors)
-        self.hnsw = HNSW(sfeat, sy, n_neighbors=self.n_neighbors)
+        self.knn = KNN(sfeat, sy, n_neighbors=self.n_neighbors, per_query=self.knn_per_query)
+        self.hnsw = HNSW(sfeat, sy, n_neighbors=self.n_neighbors, per_query=self.knn_per_query)
 
     def get_support(self, mode, x=None):
         if mode not in self.MODES:

@@ -401,10 +401,20 @@ class _NWHeadFn(torch.autograd.Function):
 
 
 def nw_head(q, s, sy, n_classes, kind="euclidean", logit_scale=None, return_weights=False,
-            support_norm2=None, support_cache=None):
+            support_norm2=None, support_cache=None, validate_labels=False):
     """NWHead.forward(x, sx, sy) -> (B,C) log-probs (and the (B,N) softmax weights on request).
     support_norm2: optional cached ``row_norm2(s)`` for a shared (N,d) support.
-    support_cache: optional ``SplitBank(s)`` (norms + split-fp16 rows: the fast 'full' inference path)."""
+    support_cache: optional ``SplitBank(s)`` (norms + split-fp16 rows: the fast 'full' inference path).
+    validate_labels: the reference's F.one_hot (nw.py:276) REFUSES labels outside [0, n_classes); the kernels skip such
+    supports silently (banks with labels check once, when they are built).  True: check here and raise F.one_hot's
+    RuntimeError -- one device round trip per call, which is why it is opt-in (NWHead.validate_labels; NWNet's debug_mode
+    turns it on)."""
+    if validate_labels and sy.numel():
+        lo, hi = (int(v) for v in torch.aminmax(sy.detach()))
+        if lo < 0:
+            raise RuntimeError("Class values must be non-negative.")                  # F.one_hot's own messages
+        if hi >= int(n_classes):
+            raise RuntimeError("Class values must be smaller than num_classes.")
     kid = _kind_id(kind)
     if kid == SCORE_KINDS["clip"] and logit_scale is None:
         raise ValueError("clip kernel needs logit_scale")

@@ -286,6 +286,35 @@ def g6():
     npz("g6_backbones.npz", **out)
 
 
+def g6b():
+    """G6b: WELL-CONDITIONED train-mode outputs of the reference backbones -- 16 images, so that every
+    BatchNorm sees at least 64 samples per channel (G6's 2-3 images end on 8-12 samples: three of its four train-mode
+    outputs are ill-conditioned and only pin the device loosely).  Procedural weights (fill_procedural_hash: G6's sine-wave weights leave
+    near-constant channels, ill-conditioned whatever the batch) AND procedural inputs (tests/procedural.py): only the outputs and one updated running mean are stored."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from procedural import fill_procedural_hash as fill_procedural, procedural_input
+    from model.resnet import resnet18, CIFAR_ResNet18
+    from model.densenet import DenseNet
+    out = {}
+    cases = {
+        "resnet18": (lambda: resnet18(), (16, 3, 64, 64)),                     # last maps 2 x 2: 64 samples per channel
+        "CIFAR_ResNet18": (lambda: CIFAR_ResNet18(), (16, 3, 32, 32)),
+        "densenet121": (lambda: DenseNet(32, (6, 12, 24, 16), 64), (16, 3, 64, 64)),
+    }
+    for key, (name, (ctor, shape)) in enumerate(cases.items()):
+        net = fill_procedural(ctor()).train()
+        x = procedural_input(*shape, key=key)
+        with torch.no_grad():
+            out[f"{name}_shape"] = np.array(shape)
+            out[f"{name}_key"] = np.array(key)
+            out[f"{name}_train"] = net(x)
+            bn_name = [k for k in net.state_dict() if k.endswith("running_mean")][-1]
+            out[f"{name}_rm_name"] = np.array(bn_name)
+            out[f"{name}_rm_after"] = net.state_dict()[bn_name].clone()
+            out[f"{name}_train_f64"] = fill_procedural(ctor()).double().train()(x.double())   # how far fp32 itself is from exact
+    npz("g6b_backbones_train.npz", **out)
+
+
 def g9():
     """A11 projection (nw.py:74-79) and the CLIP kernel's doubly registered parameter (nw.py:82,85): state_dict
     key lists and shapes of the reference's NWNet, and what forward() returns with those weights."""
@@ -322,6 +351,6 @@ def g9():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g6b, g7, g8, g9):
         if not only or fn.__name__ in only:
             fn()

@@ -76,3 +76,21 @@ def test_fold_batchnorm_matches_eval_mode():
         with torch.no_grad():
             a, b = net(x32), folded(x32)
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * a.abs().max().item())
+
+
+def test_g6b_well_conditioned_training_mode_on_host():
+    """Fixture G6b (reference modules run by make_goldens.py; hash-procedural weights and inputs, 16 images: >= 64 samples per
+    channel in every BatchNorm): our definitions' train-mode features and the last BatchNorm's running mean, on the host."""
+    from conftest import load_golden
+    from procedural import fill_procedural_hash, procedural_input
+    from nwhead_amd.model import load_model
+    g = load_golden("g6b_backbones_train.npz")
+    for name in ("resnet18", "CIFAR_ResNet18", "densenet121"):
+        net = fill_procedural_hash(load_model(name)).train()
+        x = procedural_input(*(int(v) for v in g[f"{name}_shape"]), key=int(g[f"{name}_key"]))
+        with torch.no_grad():
+            out = net(x).numpy()
+        scale = float(np.abs(g[f"{name}_train"]).max())
+        np.testing.assert_allclose(out, g[f"{name}_train"], rtol=0, atol=1e-4 * scale)
+        rm = net.state_dict()[str(g[f"{name}_rm_name"])].numpy()
+        np.testing.assert_allclose(rm, g[f"{name}_rm_after"], rtol=1e-4, atol=1e-6)

@@ -153,9 +153,13 @@ def test_k4_head_shape_forward_backward(dev, ops, O, kind, n_shot):
 
 def test_k4_densenet121_train_step_vs_cpu_autograd(dev, O):
     """BASELINE configs[3]: DenseNet-121 @224 + NW head, n_way = 10, B = 32 queries, one support image per class
-    (through forward(x, y, support_data=...)).  The device step (MIOpen convolutions, the hand-written
-    BatchNorm+ReLU kernels, the HIP head forward and backward) against the same network on the host with the
-    oracle head: loss, log-probabilities and the gradients at both ends of the network."""
+    (through forward(x, y, support_data=...)).  The device step (channels-last path: own split-fp16 convolutions
+    forward / data / weight gradient with the BatchNorms of the dense blocks applied in their loaders, own BatchNorm backward,
+    pools, the HIP head forward and backward) against the same network IN FP32 ON THE HOST with the oracle head: loss,
+    log-probabilities and the gradients at both ends of the network.  The bars below (5e-3, cosine 0.995) are the fp32 host
+    run's own distance from exact arithmetic over 120 layers at this size, not the device's: the device step is held to an
+    fp64 reference at 1e-4 / cosine 0.9999 in test_nwnet_training_step_against_fp64 below (96 x 96 inputs: the fp64
+    network over 42 images @224 takes minutes on the host)."""
     from nwhead_amd.model import load_model
     from nwhead_amd.nwhead.nw import NWNet
     torch.manual_seed(0)
@@ -194,6 +198,61 @@ def test_k4_densenet121_train_step_vs_cpu_autograd(dev, O):
     assert int(net.featurizer.features.norm0.num_batches_tracked) == 1
     np.testing.assert_allclose(net.featurizer.features.norm0.running_mean.cpu().numpy(),
                                ref_feat.features.norm0.running_mean.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["resnet18", "CIFAR_ResNet18", "densenet121"])
+def test_g6b_training_mode_on_device(dev, name):
+    """Fixture G6b: the reference's train-mode features on a WELL-CONDITIONED batch (16 images, hash-
+    procedural weights and inputs; the reference's own fp32 run is within 1e-5 of its fp64 run) against the device's training
+    forward -- channels-last kernels with the BatchNorms in the convolutions' loaders for DenseNet-121, the fused NCHW BatchNorm
+    kernels around MIOpen's convolutions for the ResNets -- at 1e-4 of the feature scale, and the running statistics."""
+    from conftest import load_golden
+    from procedural import fill_procedural_hash, procedural_input
+    from nwhead_amd.model import load_model
+    g = load_golden("g6b_backbones_train.npz")
+    net = fill_procedural_hash(load_model(name)).to(dev).train()
+    x = procedural_input(*(int(v) for v in g[f"{name}_shape"]), key=int(g[f"{name}_key"])).to(dev)
+    out = net(x.requires_grad_(True)).detach().cpu().numpy()
+    scale = float(np.abs(g[f"{name}_train"]).max())
+    np.testing.assert_allclose(out, g[f"{name}_train"], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(out, g[f"{name}_train_f64"], rtol=0, atol=1e-4 * scale)
+    rm = net.state_dict()[str(g[f"{name}_rm_name"])].cpu().numpy()
+    np.testing.assert_allclose(rm, g[f"{name}_rm_after"], rtol=1e-4, atol=1e-6)
+
+
+def test_nwnet_training_step_against_fp64(dev, O):
+    """the WHOLE NWNet training step -- DenseNet-121 over 6 queries + 10 supports @96 (joint BatchNorm
+    statistics, nw.py:182-184), the head, NLL, and back through head and backbone -- against the same step in fp64 on the host
+    (fp64 network, the oracle's fp64 head and its closed-form backward): log-probabilities within 1e-4, the gradient of ALL
+    parameters at cosine > 0.9999 and norm within 0.1 %."""
+    import copy
+    from nwhead_amd.model import load_model
+    from nwhead_amd.nwhead.nw import NWNet
+    torch.manual_seed(0)
+    net = NWNet(load_model("densenet121"), 10, device="cuda:0")
+    ref = copy.deepcopy(net.featurizer).double().train()
+    net = net.to(dev).train()
+    g = torch.Generator().manual_seed(1)
+    protos = torch.randn(10, 3, 96, 96, generator=g)
+    sy = torch.arange(10)
+    sx = protos + 0.3 * torch.randn(10, 3, 96, 96, generator=g)
+    y = torch.randint(0, 10, (6,), generator=g)
+    x = protos[y] + 0.3 * torch.randn(6, 3, 96, 96, generator=g)
+    out = net(x.to(dev), y.to(dev), support_data=(sx, sy, None))
+    F.nll_loss(out, y.to(dev)).backward()
+    feats = ref(torch.cat((x, sx), 0).double())
+    fq, fs = feats[:6].detach(), feats[6:].detach()
+    out64 = O.nw_head_f64(fq, fs, sy, 10)
+    gout = torch.zeros(6, 10, dtype=torch.float64)
+    gout[torch.arange(6), y] = -1.0 / 6
+    gx, gs = O.nw_head_bwd_f64(fq, fs, sy, 10, gout)
+    feats.backward(torch.cat((gx, gs), 0))
+    assert (out.detach().cpu().double() - out64).abs().max().item() < 1e-4
+    g_dev = torch.cat([p.grad.detach().cpu().double().flatten() for p in net.featurizer.parameters()])
+    g_ref = torch.cat([p.grad.flatten() for p in ref.parameters()])
+    cos = float((g_dev * g_ref).sum() / (g_dev.norm() * g_ref.norm()))
+    assert cos > 0.9999, cos
+    assert abs(float(g_dev.norm() / g_ref.norm()) - 1.0) < 1e-3
 
 
 # ------------------------------------------------------------------ G6 on the device

@@ -363,3 +363,36 @@ def test_run_tables_of_another_label_array_are_not_used(dev):
     assert torch.equal(call(other, sy.data_ptr(), N), want_other)             # another array: ignored, own tables built
     assert torch.equal(call(other, other.data_ptr(), N - 1), want_other)      # another row count: ignored
     assert torch.equal(call(other, None, -1), want_other)                     # identity not given: ignored
+
+
+def test_labels_outside_the_class_range_on_the_unbanked_path(dev):
+    """the reference's F.one_hot (nw.py:276) raises for a support label >= n_classes; nw_head without a
+    bank skips such supports unless validate_labels is set (NWHead.validate_labels, on under NWNet(debug_mode=True)), in which
+    case it raises F.one_hot's RuntimeError."""
+    import torch.nn.functional as F
+    from nwhead_amd import ops
+    from nwhead_amd.nwhead.kernel import get_kernel
+    from nwhead_amd.nwhead.nw import NWHead
+    g = torch.Generator().manual_seed(9)
+    q, s = torch.randn(6, 32, generator=g).to(dev), torch.randn(40, 32, generator=g).to(dev)
+    sy = (torch.arange(40) % 5).to(dev)
+    bad = sy.clone()
+    bad[7] = 5
+    with pytest.raises(RuntimeError, match="smaller than num_classes"):
+        F.one_hot(bad.cpu(), 5)                                           # what the reference does with it
+    with pytest.raises(RuntimeError, match="smaller than num_classes"):
+        ops.nw_head(q, s, bad, 5, validate_labels=True)
+    with pytest.raises(RuntimeError, match="non-negative"):
+        ops.nw_head(q, s, bad - 6, 5, validate_labels=True)
+    head = NWHead(get_kernel("euclidean"), 5, validate_labels=True)
+    with pytest.raises(RuntimeError, match="smaller than num_classes"):
+        head(q, s, bad)
+    assert torch.equal(head(q, s, sy), ops.nw_head(q, s, sy, 5))
+    # without the check: support 7 is skipped (its weight reaches no class), everything else as if it were absent
+    keep = torch.ones(40, dtype=torch.bool, device=dev)
+    keep[7] = False
+    out = ops.nw_head(q, s, bad, 5)
+    assert torch.isfinite(out).all()
+    w = torch.softmax(-torch.cdist(q, s), -1)
+    want = torch.log(torch.stack([(w * ((bad == c) & keep)).sum(-1) for c in range(5)], -1) + 1e-12)
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5)
