@@ -467,6 +467,12 @@ typedef struct nw_wgrad_job {
     int64_t out_oihw;   /* != 0: dw in torch's contiguous (Cout, Cin, KH, KW) layout instead of (Cout, KH, KW, Cin) */
     const float *pre_x; /* nullable: 3 Cin floats mean | a | beta -- the x operand is relu((x - mean) a + beta), as the forward
                            convolution read it (nw_conv2d_nhwc_bnrelu_f16x2); amax_x then bounds THAT tensor */
+    /* rowrun_stride = s > 0 (round 4: the strided few-channel stems, model/densenet.py:114-116, model/resnet.py:147): the weight
+     * gradient of a KH x KW convolution over a 4-channel NHWC input x (in_H x in_W pixels; RGB zero-padded to four channels) as
+     * ONE 1x1 problem over gy's grid (H, W = output size, KH = KW = 1, stride 1, pad 0) with Cin = 32 KH "channels": channel
+     * 32 ky + 4 kx + ci of output pixel (yo, xo) is x[s yo + row0 + ky][s xo + col0 + kx][ci] (zero outside the image; row0 =
+     * col0 = -padding).  dw (Cout, 32 KH): [co][32 ky + 4 kx + ci]; the columns with kx >= KW or ci = 3 are not part of dW. */
+    int64_t rowrun_stride, in_H, in_W, row0, col0;
 } nw_wgrad_job;
 size_t nw_conv2d_nhwc_wgrad_batch_workspace_bytes(const nw_wgrad_job *jobs, int64_t njobs);
 int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job *jobs, int64_t njobs, void *workspace, size_t workspace_bytes,

@@ -128,7 +128,7 @@ class WgradJob(C.Structure):
     """nw_wgrad_job (include/nwhead_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("amax_x", C.c_void_p), ("gy", C.c_void_p), ("amax_g", C.c_void_p), ("dw", C.c_void_p)] + \
                [(k, C.c_int64) for k in ("n", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "ldx", "ldg", "out_oihw")] + \
-               [("pre_x", C.c_void_p)]
+               [("pre_x", C.c_void_p)] + [(k, C.c_int64) for k in ("rowrun_stride", "in_H", "in_W", "row0", "col0")]
 
 
 class SgdParam(C.Structure):

@@ -31,6 +31,11 @@ struct WgradP {
                              //   (a convolution whose forward read x that way: conv_nhwc.hip's ConvP::pre); amax_x bounds that tensor
     const float* gy;
     const float* amax_g;
+    // ROW RUNS (rr_s > 0; 1x1 plan only): the x operand of output pixel (n, yo, xo) is not a pixel's channels but the 32
+    // consecutive floats of a 4-channel NHWC input that one kernel ROW of a few-channel convolution reads there (conv_nhwc.hip's
+    // ROWRUN mode: the 7x7 / 2 stem over the zero-padded RGB input): input row rr_s yo + rr_row0, pixels rr_s xo + rr_col0 .. + 7.
+    // With "channel" 32 ky + 4 kx + ci the whole dW is ONE 1x1 weight gradient between gy and KH x 32 such channels.
+    int rr_s, rr_H, rr_W, rr_row0, rr_col0;
     float* part;             // [ks][Cout][T][Cin]
     const float4* zeros;
     int N, H, W, Cin, Cout, T, KW, pad;
@@ -151,6 +156,20 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int bx) {
 #else
                 const bool ok = px >= 0 && ch < p.Cin;
 #endif
+                if (p.rr_s > 0) {   // a row run: two 4-channel pixels per lane, each inside or outside the input row on its own
+                    const Pos& o = px_[q];
+                    // "channel" ch = 32 ky + 4 kx + ci: kernel row ky's run, pixel kx of it (all kernel rows in ONE problem: gy is
+                    // read once per 128 of them, not once per kernel row)
+                    const int yi = p.rr_s * o.y + p.rr_row0 + (ch >> 5), xa = p.rr_s * o.x + p.rr_col0 + ((ch & 31) >> 2);
+                    const bool okr = ok && yi >= 0 && yi < p.rr_H;
+                    const float* rowp = p.x + ((size_t)(o.n * p.rr_H + yi) * p.rr_W) * 4;
+                    const bool oka = okr && xa >= 0 && xa < p.rr_W, okb = okr && xa + 1 >= 0 && xa + 1 < p.rr_W;
+                    L.x[q][0] = *reinterpret_cast<const float4*>(oka ? reinterpret_cast<uintptr_t>(rowp + 4 * xa) : zpage);
+                    L.x[q][1] = *reinterpret_cast<const float4*>(okb ? reinterpret_cast<uintptr_t>(rowp + 4 * xa + 4) : zpage);
+                    L.xok |= okr ? (1u << q) : 0u;
+                    advance(px_[q]);
+                    continue;
+                }
                 const float4* src = reinterpret_cast<const float4*>(ok ? reinterpret_cast<uintptr_t>(p.x + (size_t)px * p.ldx + ch) : zpage);
                 L.x[q][0] = src[0];
                 L.x[q][1] = src[1];
@@ -525,6 +544,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     WgradP p;
     p.x = x; p.amax_x = amax_x; p.gy = gy; p.amax_g = amax_g; p.pre_x = nullptr;
+    p.rr_s = p.rr_H = p.rr_W = p.rr_row0 = p.rr_col0 = 0;
     p.part = pl.ks == 1 ? dw : static_cast<float*>(workspace);
     p.zeros = static_cast<const float4*>(nw_conv_zero_page());
     if (!p.zeros) return NW_ERR_LAUNCH;
@@ -601,6 +621,11 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
         if ((reinterpret_cast<uintptr_t>(j.x) | reinterpret_cast<uintptr_t>(j.gy) | reinterpret_cast<uintptr_t>(j.dw) |
              reinterpret_cast<uintptr_t>(j.amax_x) | reinterpret_cast<uintptr_t>(j.amax_g) | reinterpret_cast<uintptr_t>(j.pre_x)) & 15)
             return NW_ERR_INVALID_ARG;
+        if (j.rowrun_stride) {   // row runs: the plan of a 1x1 problem over gy's grid with 32 "channels" (8 pixels x 4)
+            if (j.rowrun_stride < 0 || j.KH != 1 || j.Cin % 32 || j.pre_x || j.in_H <= 0 || j.in_W <= 0 ||
+                j.n * j.in_H * j.in_W * 4 >= (1LL << 31))
+                return NW_ERR_INVALID_ARG;
+        }
     }
     char* wsp = static_cast<char*>(workspace);
     for (int pass = 0; pass < 2; ++pass) {                   // 3x3 problems, then 1x1 problems: two kernels
@@ -628,6 +653,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
             if (pl.taps9 != want9) continue;
             WgradP& q = bt.p[bt.n];
             q.x = j.x; q.amax_x = j.amax_x; q.gy = j.gy; q.amax_g = j.amax_g; q.pre_x = j.pre_x;
+            q.rr_s = (int)j.rowrun_stride; q.rr_H = (int)j.in_H; q.rr_W = (int)j.in_W; q.rr_row0 = (int)j.row0; q.rr_col0 = (int)j.col0;
             const bool oihw = j.out_oihw != 0 && j.KH * j.KW > 1;   // torch's weight layout: written by the reduce kernel
             q.part = (pl.ks == 1 && !oihw) ? j.dw : reinterpret_cast<float*>(jws);
             q.zeros = zeros;

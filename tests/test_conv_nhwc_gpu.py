@@ -152,6 +152,29 @@ def test_conv_weight_gradient_against_torch_fp64(dev, n, cin, h, w, cout, k):
     assert torch.equal(dw, dw2)                            # chunk sums added in a fixed order
 
 
+STEM_WGRAD_CASES = [(3, 64, 64, 64, 7, 2, 3), (4, 37, 53, 32, 7, 2, 3), (5, 32, 32, 64, 3, 1, 1), (2, 28, 30, 16, 5, 1, 2),
+                    (2, 40, 40, 64, 7, 2, 0), (42, 224, 224, 64, 7, 2, 3)]
+
+
+@pytest.mark.parametrize("n,h,w,cout,k,stride,pad", STEM_WGRAD_CASES)
+def test_stem_weight_gradient_against_torch_fp64(dev, n, h, w, cout, k, stride, pad):
+    """Round 4: the weight gradient of the few-channel stems -- 7x7 / 2 over RGB (model/densenet.py:114-116,
+    model/resnet.py:147; the last shape is K4's), CIFAR's 3x3 -- as one row-run job per kernel row (nw_wgrad_job.rowrun_stride)
+    instead of MIOpen's kernel: against fp64, odd image sizes (ragged right / bottom borders), no padding, repeatable."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(n + h + k)
+    x = (torch.randn(n, 3, h, w, generator=g) * 1.5 + 0.3).to(dev)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    gy = _cl(torch.randn(n, cout, ho, wo, generator=g).to(dev))
+    dw = ops.conv2d_nhwc_wgrad(_cl(x), gy, (cout, 3, k, k), stride, pad)
+    assert dw.shape == (cout, 3, k, k)
+    ref = torch.ops.aten.convolution_backward(gy.double().contiguous(), x.double().contiguous(),
+                                              torch.empty(cout, 3, k, k, dtype=torch.float64, device=dev), None, [stride, stride],
+                                              [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert (dw.double() - ref).abs().max().item() / ref.abs().max().item() < TOL
+    assert torch.equal(dw, ops.conv2d_nhwc_wgrad(x, gy, (cout, 3, k, k), stride, pad))      # (NCHW input: the padding pass takes either)
+
+
 def test_batched_weight_gradients_equal_the_single_calls(dev):
     """nw_conv2d_nhwc_wgrad_batch_f16x2: 3x3 and 1x1 problems of different sizes in one call -- operands that are channel
     windows of wider tensors (ldx / ldg), both output layouts (out_oihw) -- against fp64; repeatable bit for bit; a batch
