@@ -595,7 +595,7 @@ int nw_debug_tile_timing(int enable);
 /* Diagnostic knobs (timing experiments; process-wide; never needed in normal use).  Names: pvar, qg, tile_rs, merge_mq,
  * merge_per_query, merge_no_global_tables, persistent_any_rs, no_persistent, split_queries, bwd_no_mfma, bwd_split,
  * coeff_threads, xgemm_wgs, xgemm_nbuf, split_lbits, conv_gather, conv_max_wgs, wgrad_min_stages, conv_skip_cfgs,
- * wgrad_batch_wgs, bn_inline_fin.  The Python layer forwards
+ * wgrad_batch_wgs, bn_inline_fin, conv_moments_per_tile, conv_force_cfg.  The Python layer forwards
  * the NW_<NAME> environment variables once, when it loads the library; the library itself never reads the environment. */
 int nw_debug_set(const char *name, int value);
 int nw_debug_tile_timing_read(double *total_us, int64_t *launches);

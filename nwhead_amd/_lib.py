@@ -153,7 +153,8 @@ class FwdOpts(C.Structure):
 # forward call's nw_fwd_opts; the others are diagnostic knobs, forwarded once at load time (and again by sync_knobs()).
 KNOBS = ("pvar", "qg", "tile_rs", "merge_mq", "merge_per_query", "merge_no_global_tables", "persistent_any_rs", "no_persistent",
          "split_queries", "bwd_no_mfma", "bwd_split", "coeff_threads", "xgemm_wgs", "xgemm_nbuf", "split_lbits", "conv_gather",
-         "conv_max_wgs", "wgrad_min_stages", "conv_skip_cfgs", "wgrad_batch_wgs", "bn_inline_fin", "conv_moments_per_tile")
+         "conv_max_wgs", "wgrad_min_stages", "conv_skip_cfgs", "wgrad_batch_wgs", "bn_inline_fin", "conv_moments_per_tile",
+         "conv_force_cfg")
 _KNOB_UNSET = -2 ** 31
 _knob_state = {}
 

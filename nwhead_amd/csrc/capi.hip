@@ -24,7 +24,8 @@ bool g_knobs_init = [] { for (int& k : g_knobs) k = KNOB_UNSET; return true; }()
 const char* const knob_names[KNOB_COUNT] = {
     "pvar", "qg", "tile_rs", "merge_mq", "merge_per_query", "merge_no_global_tables", "persistent_any_rs", "no_persistent",
     "split_queries", "bwd_no_mfma", "bwd_split", "coeff_threads", "xgemm_wgs", "xgemm_nbuf", "split_lbits", "conv_gather",
-    "conv_max_wgs", "wgrad_min_stages", "conv_skip_cfgs", "wgrad_batch_wgs", "bn_inline_fin", "conv_moments_per_tile"};
+    "conv_max_wgs", "wgrad_min_stages", "conv_skip_cfgs", "wgrad_batch_wgs", "bn_inline_fin", "conv_moments_per_tile",
+    "conv_force_cfg"};
 }  // namespace
 const FwdOpts& fwd_opts() { return tl_fwd_opts; }
 int knob(int id) { return (id >= 0 && id < KNOB_COUNT) ? __atomic_load_n(&g_knobs[id], __ATOMIC_RELAXED) : KNOB_UNSET; }

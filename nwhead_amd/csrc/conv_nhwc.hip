@@ -1231,18 +1231,25 @@ static int conv2d_nhwc_impl(const float* x, const float* amax_in, const float* w
     const int64_t want = (int64_t)nw::num_cus() * 3 / 4;
     auto tiles = [&](int bm, int bn) { return ((int64_t)p.M + bm - 1) / bm * (Cout / bn); };
     const int skip = nw::knob(nw::KNOB_CONV_SKIP_CFGS) > 0 ? nw::knob(nw::KNOB_CONV_SKIP_CFGS) : 0;   // timing experiments: pass over the first n fitting shapes
-    int seen = 0;
-#define NW_CONV_TRY(NA_, NB_, WM_, BM_, BN_, LAST_)                                                            \
-    if (Cout % BN_ == 0 && (LAST_ || (tiles(BM_, BN_) >= want && seen++ >= skip))) {                           \
+    const int force = nw::knob(nw::KNOB_CONV_FORCE_CFG) > 0 ? nw::knob(nw::KNOB_CONV_FORCE_CFG) : 0;   // ... or run shape number n of the list below
+    int seen = 0, idx = 0;
+#define NW_CONV_TRY(NA_, NB_, WM_, BM_, BN_, COND_)                                                            \
+    ++idx;                                                                                                      \
+    if (Cout % BN_ == 0 && (force ? idx == force : ((COND_) && seen++ >= skip))) {                              \
         if (k33 && patch_fits(BM_) && !force_gather)                                                            \
             return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_PATCH>(p, st, moments_groups, dry);                \
         return nw::launch_conv_cfg<NA_, NB_, WM_, nw::CV_GATHER>(p, st, moments_groups, dry);                   \
     }
-    NW_CONV_TRY(4, 4, 2, 128, 128, false)
-    NW_CONV_TRY(4, 2, 1, 128, 64, false)
-    if (Cout % 64 == 0) { NW_CONV_TRY(4, 1, 1, 64, 64, true) }
-    NW_CONV_TRY(2, 4, 1, 256, 32, false)
-    NW_CONV_TRY(2, 2, 1, 128, 32, false)
+    const int64_t G = nw::num_cus();
+    // 64 pixels x 128 channels: where the 64 x 64 tiles just miss one round of the grid (42 x 14 x 14 pixels x 128 channels:
+    // 258 tiles on 256 workgroups -- two of them run twice as long as the rest) and this shape fits in one
+    const bool wide = nw::knob(nw::KNOB_CONV_FORCE_CFG) != -1 && tiles(64, 64) > G && tiles(64, 64) <= G + G / 4 && tiles(64, 128) >= G / 4;
+    NW_CONV_TRY(4, 4, 2, 128, 128, tiles(128, 128) >= want)
+    NW_CONV_TRY(4, 2, 1, 128, 64, tiles(128, 64) >= want)
+    NW_CONV_TRY(4, 2, 2, 64, 128, wide)
+    if (Cout % 64 == 0) { NW_CONV_TRY(4, 1, 1, 64, 64, true) } else { ++idx; }
+    NW_CONV_TRY(2, 4, 1, 256, 32, tiles(256, 32) >= want)
+    NW_CONV_TRY(2, 2, 1, 128, 32, tiles(128, 32) >= want)
     NW_CONV_TRY(2, 1, 1, 64, 32, true)
 #undef NW_CONV_TRY
     return NW_ERR_UNSUPPORTED;

@@ -80,7 +80,8 @@ constexpr int KNOB_UNSET = -2147483647 - 1;
 enum Knob { KNOB_PVAR, KNOB_QG, KNOB_TILE_RS, KNOB_MERGE_MQ, KNOB_MERGE_PER_QUERY, KNOB_MERGE_NO_GLOBAL_TABLES,
             KNOB_PERSISTENT_ANY_RS, KNOB_NO_PERSISTENT, KNOB_SPLIT_QUERIES, KNOB_BWD_NO_MFMA, KNOB_BWD_SPLIT,
             KNOB_COEFF_THREADS, KNOB_XGEMM_WGS, KNOB_XGEMM_NBUF, KNOB_SPLIT_LBITS, KNOB_CONV_GATHER, KNOB_CONV_MAX_WGS,
-            KNOB_WGRAD_MIN_STAGES, KNOB_CONV_SKIP_CFGS, KNOB_WGRAD_BATCH_WGS, KNOB_BN_INLINE_FIN, KNOB_CONV_MOMENTS_PER_TILE, KNOB_COUNT };
+            KNOB_WGRAD_MIN_STAGES, KNOB_CONV_SKIP_CFGS, KNOB_WGRAD_BATCH_WGS, KNOB_BN_INLINE_FIN, KNOB_CONV_MOMENTS_PER_TILE,
+            KNOB_CONV_FORCE_CFG, KNOB_COUNT };
 int knob(int id);
 
 // fused forward (fused.hip)

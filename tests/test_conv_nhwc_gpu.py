@@ -46,6 +46,8 @@ CONV_CASES = [
     (3, 3, 64, 64, 64, 7, 2, 3, True, False, True),        # ROWRUN: the 7x7 / 2 stem over RGB (4-channel padded input)
     (5, 3, 32, 32, 64, 3, 1, 1, True, False, True),        # CIFAR stem
     (2, 1, 28, 28, 32, 5, 1, 2, True, False, True),        # one input channel: the scalar ROWRUN path
+    (42, 64, 14, 14, 128, 1, 1, 0, True, True, True),      # 64 pixels x 128 channels: 129 tiles instead of 258 of 64 x 64 (GATHER)
+    (42, 32, 14, 14, 128, 3, 1, 1, True, True, True),      # ... and PATCH (the data gradient of a DenseNet conv2 at 14 x 14)
 ]
 
 
@@ -503,6 +505,8 @@ BNRELU_CASES = [
     (3, 128, 9, 7, 32, 3, 0, True),          # PATCH, tiles crossing rows and images
     (3, 128, 56, 56, 32, 3, 0, False),       # DenseNet conv2 at 56 x 56 (256-pixel tiles)
     (5, 128, 7, 7, 32, 3, 0, True),
+    (42, 96, 14, 14, 128, 1, 128, True),     # 64 pixels x 128 channels (one round of 129 tiles), moments merged per workgroup
+    (42, 32, 14, 14, 128, 3, 0, True),       # ... in PATCH mode
 ]
 
 

@@ -9,7 +9,7 @@
 #include "nw_internal.h"
 namespace nw {   // the library's knobs from the environment here: NW_CONV_SKIP_CFGS=n passes over the first n fitting tile shapes
 int knob(int id) {
-    const char* e = id == KNOB_CONV_SKIP_CFGS ? getenv("NW_CONV_SKIP_CFGS") : nullptr;
+    const char* e = id == KNOB_CONV_SKIP_CFGS ? getenv("NW_CONV_SKIP_CFGS") : id == KNOB_CONV_FORCE_CFG ? getenv("NW_CONV_FORCE_CFG") : nullptr;
     return e ? atoi(e) : KNOB_UNSET;
 }
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools/prof_backbone_pmc.sh TAG k2|k4 [steps]
+# usage (GPU box, repo root): bash tools/prof_backbone_pmc.sh TAG k2|k4|k5 [steps]
 # rocprofv3 kernel trace + stats, then PMC passes (never combined with a trace) of the K2 predict calls (folded channels_last
 # ResNet-18 + head) or of DenseNet-121 training steps (K4); condense with tools/pmc_by_kernel.py
 set -e
@@ -10,7 +10,8 @@ export TMPDIR=/tmp
 cd /tmp
 if [ "$WHAT" = k4 ]; then
   SCRIPT=$GRAFT_REPO_ROOT/tools/k4_step.py
-  python3 $SCRIPT 1 > $OUT/warm.log 2>&1 || true     # (MIOpen's solver search for the strided stem, outside the traces)
+elif [ "$WHAT" = k5 ]; then
+  SCRIPT=$GRAFT_REPO_ROOT/tools/k5_time.py
 else
   SCRIPT=$GRAFT_REPO_ROOT/tools/k2_step.py
 fi
