@@ -535,6 +535,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, c
     if (ldx == 0) ldx = Cin;
     if (ldg == 0) ldg = Cout;
     if (ldx < Cin || ldg < Cout || ldx % 4 || ldg % 4) return NW_ERR_INVALID_ARG;
+    if (n * H * W * ldx >= (1LL << 31) || n * H * W * ldg >= (1LL << 31)) return NW_ERR_UNSUPPORTED;   // 32-bit element offsets with the row strides
     if (!x || !amax_x || !gy || !amax_g || !dw) return NW_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dw) |
          reinterpret_cast<uintptr_t>(amax_x) | reinterpret_cast<uintptr_t>(amax_g) | reinterpret_cast<uintptr_t>(workspace)) & 15)
@@ -575,7 +576,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_f16x2(const float* x, const float* amax_x, c
 // ---- a batch of weight gradients (nw_wgrad_job, include/nwhead_hip.h)
 static int batch_target_wgs(int64_t njobs) {
     const int k = nw::knob(nw::KNOB_WGRAD_BATCH_WGS);
-    if (k > 0) return k;
+    if (k > 0) return k > 256 ? 256 : k;   // (the jobs' workspace slices are sized for at most 256 workgroups per job: wgrad_job_ws)
     // the jobs share the chip: ~1024 workgroups in all, 64..256 per job (K4: 17.36-17.42 ms at 64 per job, 17.66-17.70 at 256:
     // fewer chunks = smaller partial tiles and a shorter reduce)
     const int64_t t = 1024 / (njobs > 0 ? njobs : 1);
@@ -618,6 +619,7 @@ extern "C" int nw_conv2d_nhwc_wgrad_batch_f16x2(const nw_wgrad_job* jobs, int64_
         if (!wgrad_plan(j.n, j.H, j.W, j.Cin, j.Cout, j.KH, j.KW, j.stride, j.pad, &pl, tgt)) return NW_ERR_UNSUPPORTED;
         const int64_t ldx = j.ldx ? j.ldx : j.Cin, ldg = j.ldg ? j.ldg : j.Cout;
         if (!j.x || !j.amax_x || !j.gy || !j.amax_g || !j.dw || ldx < j.Cin || ldg < j.Cout || ldx % 4 || ldg % 4) return NW_ERR_INVALID_ARG;
+        if (j.n * j.H * j.W * ldg >= (1LL << 31) || (!j.rowrun_stride && j.n * j.H * j.W * ldx >= (1LL << 31))) return NW_ERR_UNSUPPORTED;
         if ((reinterpret_cast<uintptr_t>(j.x) | reinterpret_cast<uintptr_t>(j.gy) | reinterpret_cast<uintptr_t>(j.dw) |
              reinterpret_cast<uintptr_t>(j.amax_x) | reinterpret_cast<uintptr_t>(j.amax_g) | reinterpret_cast<uintptr_t>(j.pre_x)) & 15)
             return NW_ERR_INVALID_ARG;

@@ -502,7 +502,7 @@ class DenseNet(nn.Module):
         return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
 
 
-NHWC_INFERENCE = True        # DenseNet.forward in eval mode on the device: the channels-last inference path above
+NHWC_INFERENCE = _os.environ.get("NW_NHWC_INFERENCE", "1") != "0"   # DenseNet.forward in eval mode on the device: the channels-last inference path above
 
 
 class ScaleShiftReLU(nn.Module):

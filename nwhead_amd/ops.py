@@ -1033,10 +1033,13 @@ def bn_relu_train_nhwc(x, bn, relu=True, passthrough=False):
     if x.shape[1] % 4:
         raise ValueError("bn_relu_train_nhwc needs a channel count that is a multiple of 4")
     if x.shape[1] > BN_NHWC_MAX_C:           # wider than the kernels' per-channel tables: torch's BatchNorm on the same layout
-        y = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True,
-                                           0.0 if bn.momentum is None else bn.momentum, bn.eps)
+        # (torch's own order: count first; momentum None = cumulative average with factor 1 / count, nn/modules/batchnorm.py)
         if bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
+        factor = bn.momentum
+        if factor is None:
+            factor = 1.0 / float(bn.num_batches_tracked) if (bn.track_running_stats and bn.num_batches_tracked is not None) else 0.0
+        y = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, factor, bn.eps)
         y = torch.relu(y) if relu else y
         return (y, x) if passthrough else y
     return _BNReLUNhwcFn.apply(x, bn.weight, bn.bias, bn, bool(relu), bool(passthrough))

@@ -312,6 +312,23 @@ def test_bn_relu_nhwc_train_against_fp64(dev, n, c, h, w, prefix, relu):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("c", [64, 2592])
+def test_bn_relu_nhwc_cumulative_average(dev, c):
+    """BatchNorm2d(momentum=None): running statistics are the cumulative average (factor 1 / num_batches_tracked, counted
+    first) on the kernels' path and on the wider-than-2560-channels fallback (it used factor 0)."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(c)
+    bn = torch.nn.BatchNorm2d(c, momentum=None).to(dev).train()
+    ref = torch.nn.BatchNorm2d(c, momentum=None).to(dev).double().train()
+    for step in range(3):
+        x = _cl((torch.randn(3, c, 5, 5, generator=g) * (1.0 + step) + 0.5 * step).to(dev))
+        ops.bn_relu_train_nhwc(x, bn, True)
+        ref(x.double())
+    assert int(bn.num_batches_tracked) == 3
+    assert (bn.running_mean.double() - ref.running_mean).abs().max().item() < 1e-5
+    assert (bn.running_var.double() - ref.running_var).abs().max().item() < 1e-5 * float(ref.running_var.max())
+
+
 @pytest.mark.parametrize("n,c,h,w,prefix", [(2, 8, 9, 11, 0), (3, 64, 56, 56, 0), (2, 128, 28, 28, 32), (1, 4, 2, 2, 0),
                                             (2, 12, 7, 1, 0), (42, 64, 112, 112, 0)])
 def test_pools_nhwc_against_torch(dev, n, c, h, w, prefix):
