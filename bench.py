@@ -44,8 +44,8 @@ def make_inputs(B, N, d, C, dev, seed=0):
     return q.to(dev), s.to(dev), sy.to(dev)
 
 
-PMC_FILE = "profiles/r03_bench_pmc.json"   # rocprofv3 --pmc passes of `bench.py --skip-extras` (tools/prof_bench.sh)
-PMC_FILE_T = "profiles/r03_T_forward_pmc.json"   # ... of the T-shape forward (tools/prof.sh)
+PMC_FILE = "profiles/r04_bench_pmc.json"   # rocprofv3 --pmc passes of `bench.py --skip-extras` (tools/prof_bench.sh)
+PMC_FILE_T = "profiles/r04_T_forward_pmc.json"   # ... of the T-shape forward (tools/prof.sh)
 
 
 def pmc_entry(kernel, pmc_file=None):
