@@ -544,6 +544,22 @@ int nw_bn_relu_nhwc_train_bwd_from_partials_f32(const float *x, int64_t ldx, con
                                                 float *dbeta, const float *acc, int64_t ldacc, int64_t lddx,
                                                 float *amax_out, void *workspace, size_t workspace_bytes, int64_t rows,
                                                 int64_t c, void *stream);
+/* Backward of `norm1 -> relu1 -> conv1` of a dense layer (model/densenet.py:36-40; the 1x1 bottleneck convolution) in two
+ * streaming passes, without the convolution's data gradient ever reaching memory (csrc/bn_dgrad.hip, round 4):
+ *   du (rows, k) fp32, dense: dL/d(conv1 output), k = conv1's output channels (multiple of 32, <= 128); amax_du: its amax record;
+ *   w_split / w_scale: conv1's DATA-GRADIENT operand (the (c, k) matrix W^T in nw_split_rows_f16x2 form: what
+ *     nw_conv2d_nhwc_f16x2 takes to compute the data gradient of a 1x1 convolution);
+ *   x (rows, >= c) with row stride ldx: the tensor norm1 read; tab: norm1's table mean | a | beta (rows tab_stride floats apart,
+ *     a = gamma invstd: nw_bn_nhwc_prep_*); invstd (c,);
+ *   g (rows, >= c) with row stride ldg: dL/dx is ADDED into g[:, :c] in place; amax_out (nullable): amax record of the result;
+ *   dgamma, dbeta (c,): written.  workspace: nw_bn_dgrad1x1_workspace_bytes(rows, c).
+ * Equals nw_conv2d_nhwc_f16x2 (data gradient) + nw_bn_relu_nhwc_train_bwd_f32(acc = dx = g) up to fp32 summation order.
+ * NW_ERR_UNSUPPORTED for c % 32 != 0 or k outside {32, 64, 96, 128} (callers keep the two-step path for those). */
+size_t nw_bn_dgrad1x1_workspace_bytes(int64_t rows, int64_t c);
+int nw_bn_dgrad1x1_bwd_f16x2(const float *du, const float *amax_du, const float *w_split, const float *w_scale,
+                             const float *x, int64_t ldx, const float *tab, int64_t tab_stride, const float *invstd,
+                             float *g, int64_t ldg, float *amax_out, float *dgamma, float *dbeta, void *workspace,
+                             size_t workspace_bytes, int64_t rows, int64_t c, int64_t k, void *stream);
 int nw_bn_relu_nhwc_train_bwd_f32(const float *x, int64_t ldx, const float *dy, const float *gamma, const float *beta,
                                   const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
                                   float *dbeta, const float *acc, int64_t ldacc, int64_t lddx, float *amax_out,

@@ -668,6 +668,17 @@ inline bool bad_align(const void* a, const void* b = nullptr, const void* c = nu
 }  // namespace
 }  // namespace nw
 
+namespace nw {
+// bn_dgrad.hip: dgamma, dbeta and the two means from G groups of (sum g, sum g xhat) rows -- part[(k * G + g) * C + c]
+int bn_bwd_finalize_groups(const float* part, int G, int C, float inv_m, float* dgamma, float* dbeta, float* k, hipStream_t st) {
+    if (!part || G <= 0 || C <= 0 || !dgamma || !dbeta || !k) return NW_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(nw_bn_nhwc_bwd_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, st, part, G, C, inv_m, dgamma,
+                       dbeta, k);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+}  // namespace nw
+
 extern "C" size_t nw_bn_nhwc_workspace_bytes(int64_t rows, int64_t c) {
     if (rows <= 0 || c <= 0) return 0;
     int G; int64_t rpc;

@@ -100,6 +100,9 @@ int launch_fused(const float* q, const float* s, const int64_t* sy, const float*
                  void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t d, int64_t C,
                  int kind, hipStream_t st);
 
+// bn_nhwc.hip, for bn_dgrad.hip: the BatchNorm backward finalize over G groups of partial sums
+int bn_bwd_finalize_groups(const float* part, int G, int C, float inv_m, float* dgamma, float* dbeta, float* k, hipStream_t st);
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -1388,6 +1388,11 @@ def _bn_tracking(bn):
 # pass: one launch and one read of (x, dy) less per BatchNorm, paid for by the x loads of the epilogue.  Measured on K4, three
 # alternations on one box: 18.93-18.97 ms with, 18.79-18.83 without -- left OFF
 DENSE_BWD_STATS_IN_DGRAD = os.environ.get("NW_DENSE_BWD_STATS", "0") == "1"
+# norm1 -> relu1 -> conv1 backward as nw_bn_dgrad1x1_bwd_f16x2 (two streaming passes, no (rows, c) gradient tensor) instead of the
+# data-gradient convolution + the two BatchNorm backward passes.  Half the HBM bytes, but measured SLOWER on K4 (15.3 vs 14.5 ms,
+# alternated on one box): its first pass is instruction-bound (the per-channel sums) and the 14 x 14 / 7 x 7 layers pay three
+# launch-latency floors either way -- left OFF (DESIGN.md 4.7h')
+DENSE_FUSED_NORM1_BWD = os.environ.get("NW_DENSE_FUSED_NORM1_BWD", "0") == "1"
 
 
 class _DenseBlockNhwcFn(torch.autograd.Function):
@@ -1577,16 +1582,26 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
                     wjobs.append(_lib.WgradJob(_ptr(slab), _ptr(am1), _ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(dw1),
                                                n, h, w, c, mid, 1, 1, 1, 0, ctot, 0, 0, _ptr(tab1)))
                     wkeep += [du, am_d]
-                    dt1 = torch.empty((rows, c), **f32)
-                    _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,
-                                                        None, 0, _ptr(dt1), am_d.data_ptr() + 8 * AMAX_SLOTS, n, h, w, mid, c, 1, 1, 1, 0,
-                                                        0, 0, None, st), "nw_conv2d_nhwc_f16x2")
-                    # norm1 + relu over the slab's prefix: dx is ADDED into the gradient slab's prefix, in place
                     dg1, db1 = torch.empty(c, **f32), torch.empty(c, **f32)
                     am_g = torch.empty(AMAX_SLOTS, **f32)
-                    _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(slab), ctot, _ptr(dt1), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(i1),
-                                                                 _ptr(G), _ptr(dg1), _ptr(db1), _ptr(G), ctot, ctot, _ptr(am_g),
-                                                                 _ptr(wsn), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
+                    if DENSE_FUSED_NORM1_BWD and mid % 32 == 0 and mid <= 128 and c % 32 == 0:
+                        # conv1's data gradient, norm1's statistics and dx in two streaming passes: the (rows, c) gradient never
+                        # reaches memory (csrc/bn_dgrad.hip); dx is ADDED into the gradient slab's prefix, in place
+                        fb = lib.nw_bn_dgrad1x1_workspace_bytes(rows, c)
+                        wsf = _workspace(fb, dev)
+                        _lib.check(lib.nw_bn_dgrad1x1_bwd_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale),
+                                                                _ptr(slab), ctot, _ptr(tab1), c, _ptr(i1), _ptr(G), ctot, _ptr(am_g),
+                                                                _ptr(dg1), _ptr(db1), _ptr(wsf), fb, rows, c, mid, st),
+                                   "nw_bn_dgrad1x1_bwd_f16x2")
+                    else:
+                        dt1 = torch.empty((rows, c), **f32)
+                        _lib.check(lib.nw_conv2d_nhwc_f16x2(_ptr(du), am_d.data_ptr() + 4 * AMAX_SLOTS, _ptr(d1.split), _ptr(d1.scale), None,
+                                                            None, 0, _ptr(dt1), am_d.data_ptr() + 8 * AMAX_SLOTS, n, h, w, mid, c, 1, 1, 1, 0,
+                                                            0, 0, None, st), "nw_conv2d_nhwc_f16x2")
+                        # norm1 + relu over the slab's prefix: dx is ADDED into the gradient slab's prefix, in place
+                        _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(_ptr(slab), ctot, _ptr(dt1), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(i1),
+                                                                     _ptr(G), _ptr(dg1), _ptr(db1), _ptr(G), ctot, ctot, _ptr(am_g),
+                                                                     _ptr(wsn), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
                 grads[6 * k:6 * k + 6] = [dg1, db1, dw1, dg2, db2, dw2]
             if wjobs:
                 jobs = (_lib.WgradJob * len(wjobs))(*wjobs)

@@ -92,7 +92,7 @@ def test_conv2d_nhwc_many_tiles_per_workgroup():
             "    assert err < t.TOL, (case, err)\n"
             "for args in t.MOMENT_CASES:\n"          # a workgroup's tiles merged into one moments group each (Chan, in registers)
             "    t.test_conv_channel_windows_and_moments(dev, *args)\n"
-            "for flag in (False, True):\n"            # ... and the backward sums of the data gradients' epilogues
+            "for flag in (False, True, 'fused_norm1'):\n"            # ... and the backward sums of the data gradients' epilogues
             "    t.test_dense_block_slab_node_against_layer_by_layer(dev, flag)\n"
             "print('OK')\n" % (ROOT, ROOT))
     env = dict(os.environ, NW_CONV_MAX_WGS="8")
@@ -310,6 +310,76 @@ def test_bn_relu_nhwc_train_against_fp64(dev, n, c, h, w, prefix, relu):
     assert (bn.running_mean.double() - ref.running_mean).abs().max().item() < 1e-6 * sc(ref.running_mean)
     assert (bn.running_var.double() - ref.running_var).abs().max().item() < 1e-5 * sc(ref.running_var)
     assert int(bn.num_batches_tracked) == 1
+
+
+FUSED_NORM1_CASES = [(2, 14, 14, 96, 160, 128), (3, 7, 7, 992, 1024, 128), (1, 5, 3, 32, 32, 32), (2, 28, 28, 288, 320, 128),
+                     (4, 9, 11, 64, 64, 64), (2, 12, 12, 544, 576, 96), (42, 14, 14, 256, 288, 128)]
+
+
+@pytest.mark.parametrize("n,h,w,c,ctot,mid", FUSED_NORM1_CASES)
+def test_fused_norm1_backward_against_fp64(dev, n, h, w, c, ctot, mid):
+    """nw_bn_dgrad1x1_bwd_f16x2 (round 4; backward of model/densenet.py:36-40 norm1 -> relu1 -> conv1): the gradient slab's
+    prefix, dgamma, dbeta and the amax record against fp64, and against the two-step path (data-gradient convolution +
+    nw_bn_relu_nhwc_train_bwd_f32) it replaces -- channel prefix of a wider slab, channels with an offset, negative gamma,
+    channel groups of unequal size (c = 288: 192 + 96), fewer than 16 pixels, a ragged last strip."""
+    from nwhead_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(c + mid + h)
+    rows = n * h * w
+    slab = (torch.randn(rows, ctot, generator=g) * (0.3 + 1.5 * torch.rand(1, ctot, generator=g)) + 2.0 * torch.randn(1, ctot, generator=g)).to(dev)
+    gamma = ((torch.rand(c, generator=g) + 0.5) * torch.where(torch.rand(c, generator=g) < 0.2, -1.0, 1.0)).to(dev)
+    beta = (torch.randn(c, generator=g) * 0.5).to(dev)
+    wt = (torch.randn(mid, c, generator=g) / c ** 0.5).to(dev)                 # conv1's weight (Cout = mid, Cin = c)
+    du = (torch.randn(rows, mid, generator=g) * 0.7).to(dev)
+    G0 = torch.randn(rows, ctot, generator=g).to(dev)
+    x = slab[:, :c]
+    mean = x.double().mean(0)
+    var = x.double().var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    tab = torch.cat([mean, gamma.double() * invstd, beta.double()]).float().contiguous()
+    inv32 = invstd.float().contiguous()
+    m32 = mean.float().contiguous()
+    # fp64 reference from the fp32 table (what the forward used)
+    a64, b64, m64, i64 = tab[c:2 * c].double(), tab[2 * c:].double(), m32.double(), inv32.double()
+    g64 = du.double() @ wt.double()
+    xm = x.double() - m64
+    gd = torch.where(xm * a64 + b64 > 0, g64, torch.zeros_like(g64))
+    dbeta, dgamma = gd.sum(0), (gd * xm * i64).sum(0)
+    dx = a64 * (gd - dbeta / rows - xm * i64 * dgamma / rows)
+    want = G0.double().clone()
+    want[:, :c] += dx
+    # the fused call
+    d1 = ops.SplitConvWeight(wt.t().reshape(c, mid, 1, 1).contiguous())
+    am_du = ops.absmax(du)
+    G = G0.clone()
+    am_g = torch.empty(ops.AMAX_SLOTS, device=dev)
+    dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    fb = lib.nw_bn_dgrad1x1_workspace_bytes(rows, c)
+    ws = torch.empty(fb // 4, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    _lib.check(lib.nw_bn_dgrad1x1_bwd_f16x2(P(du), P(am_du), P(d1.split), P(d1.scale), P(slab), ctot, P(tab), c, P(inv32), P(G), ctot,
+                                            P(am_g), P(dg), P(db), P(ws), fb, rows, c, mid, st), "nw_bn_dgrad1x1_bwd_f16x2")
+    sc = lambda t: max(float(t.abs().max()), 1e-12)
+    assert (G[:, :c].double() - want[:, :c]).abs().max().item() < 2e-5 * sc(want[:, :c])
+    assert torch.equal(G[:, c:], G0[:, c:])                                  # nothing outside the prefix is touched
+    assert (dg.double() - dgamma).abs().max().item() < 2e-5 * sc(dgamma)
+    assert (db.double() - dbeta).abs().max().item() < 2e-5 * sc(dbeta)
+    assert float(am_g.max()) == float(G[:, :c].abs().max())
+    # the two-step path on the same operands
+    dt1 = torch.empty(rows, c, device=dev)
+    am_t = torch.empty(ops.AMAX_SLOTS, device=dev)
+    _lib.check(lib.nw_conv2d_nhwc_f16x2(P(du), P(am_du), P(d1.split), P(d1.scale), None, None, 0, P(dt1), P(am_t), n, h, w, mid, c, 1, 1,
+                                        1, 0, 0, 0, None, st), "nw_conv2d_nhwc_f16x2")
+    G2 = G0.clone()
+    dg2, db2 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    bnb = lib.nw_bn_nhwc_workspace_bytes(rows, c)
+    ws2 = torch.empty(bnb // 4 + 4, device=dev)
+    am2 = torch.empty(ops.AMAX_SLOTS, device=dev)
+    _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(P(slab), ctot, P(dt1), P(gamma), P(beta), P(m32), P(inv32), P(G2), P(dg2), P(db2), P(G2),
+                                                 ctot, ctot, P(am2), P(ws2), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
+    assert (G[:, :c] - G2[:, :c]).abs().max().item() < 2e-5 * sc(want[:, :c])
+    assert (dg - dg2).abs().max().item() < 2e-5 * sc(dgamma) and (db - db2).abs().max().item() < 2e-5 * sc(dbeta)
 
 
 @pytest.mark.parametrize("c", [64, 2592])
@@ -645,7 +715,7 @@ def test_bn_forward_in_phases_equals_the_fused_call(dev):
     assert int(bn_b.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("bwd_stats_in_dgrad", [False, True])
+@pytest.mark.parametrize("bwd_stats_in_dgrad", [False, True, "fused_norm1"])
 def test_dense_block_slab_node_against_layer_by_layer(dev, bwd_stats_in_dgrad):
     """ops.dense_block_nhwc_train (one autograd node over one slab, statistics shared between the layers, moments from the
     convolutions' epilogues, the gradient slab accumulated in place) against the layer-by-layer channels-last path and
@@ -668,9 +738,10 @@ def test_dense_block_slab_node_against_layer_by_layer(dev, bwd_stats_in_dgrad):
         blk = copy.deepcopy(block)
         bank = ops.ConvWeightBank([(m.weight, True) for m in blk.modules() if isinstance(m, torch.nn.Conv2d)])
         bank.refresh()
-        old, old_f = BB.DENSE_SLAB, ops.DENSE_BWD_STATS_IN_DGRAD
+        old, old_f, old_n = BB.DENSE_SLAB, ops.DENSE_BWD_STATS_IN_DGRAD, ops.DENSE_FUSED_NORM1_BWD
         BB.DENSE_SLAB = slab
-        ops.DENSE_BWD_STATS_IN_DGRAD = bwd_stats_in_dgrad      # (BatchNorm's backward sums from the data gradients' epilogues)
+        ops.DENSE_BWD_STATS_IN_DGRAD = bwd_stats_in_dgrad is True      # (BatchNorm's backward sums from the data gradients' epilogues)
+        ops.DENSE_FUSED_NORM1_BWD = bwd_stats_in_dgrad == "fused_norm1"   # (norm1 -> relu1 -> conv1 backward in nw_bn_dgrad1x1_bwd_f16x2)
         try:
             x = x0.clone().requires_grad_(True)
             if slab:
@@ -678,7 +749,7 @@ def test_dense_block_slab_node_against_layer_by_layer(dev, bwd_stats_in_dgrad):
             y = blk.forward_nhwc_train(x, bank)
             (y * t).sum().backward()
         finally:
-            BB.DENSE_SLAB, ops.DENSE_BWD_STATS_IN_DGRAD = old, old_f
+            BB.DENSE_SLAB, ops.DENSE_BWD_STATS_IN_DGRAD, ops.DENSE_FUSED_NORM1_BWD = old, old_f, old_n
         return y.detach().double(), x.grad.double(), {k: p.grad.double() for k, p in blk.named_parameters()}, \
             {k: b.double() for k, b in blk.named_buffers() if "running" in k}
 
