@@ -32,6 +32,39 @@ def _no_pretrained(pretrained):
 
 
 # ----------------------------------------------------------------------------- ImageNet-style ResNet
+def _conv_nhwc_train(conv, x, bank):
+    """A bias-free nn.Conv2d on the channels-last training kernels (ops.conv2d_nhwc_train; model/resnet.py:15-28)."""
+    from .. import ops
+    return ops.conv2d_nhwc_train(x, conv.weight, conv.stride[0], conv.padding[0], operands=bank.operands(conv.weight))
+
+
+def _add_relu_nhwc(z, identity):
+    """relu(z + identity) at the end of a residual block (model/resnet.py:60-66, :100-108), with the amax record the next
+    convolution scales its operand by."""
+    from .. import ops
+    out = torch.relu(z + identity)
+    out.nw_amax = ops.absmax(out.detach())
+    return out
+
+
+def _convs_nhwc_servable(model, stem):
+    """Do csrc/conv_nhwc.hip / conv_wgrad.hip serve every convolution (and bn_nhwc.hip every BatchNorm) of the network?"""
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            cout, cin, kh, kw = m.weight.shape
+            ok = (m.bias is None and m.groups == 1 and m.dilation == (1, 1) and kh == kw and m.stride[0] == m.stride[1]
+                  and m.padding[0] == m.padding[1] and cout % 32 == 0)
+            if m is stem:
+                ok = ok and cin == 3 and 4 * kw <= 32
+            else:
+                ok = ok and cin % 32 == 0 and kh in (1, 3) and m.padding[0] == (kh - 1) // 2 and m.stride[0] in (1, 2)
+            if not ok:
+                return False
+        elif isinstance(m, nn.BatchNorm2d) and not (m.affine and m.num_features % 4 == 0):
+            return False
+    return True
+
+
 class BasicBlock(nn.Module):
     """conv3x3-bn-relu-conv3x3-bn (+ identity or 1x1 projection) - relu; model/resnet.py:31-66."""
     expansion = 1
@@ -52,6 +85,15 @@ class BasicBlock(nn.Module):
             return self.conv2(self.conv1(x, relu=True), residual=x if self.downsample is None else self.downsample(x), relu=True)
         y = self.conv2(_bn_relu(self.bn1, self.conv1(x)))
         return _bn_relu(self.bn2, y, x if self.downsample is None else self.downsample(x))
+
+    def forward_nhwc_train(self, x, bank):
+        """The block in channels-last layout on the own kernels (ResNet._forward_nhwc_train)."""
+        from .. import ops
+        y = ops.bn_relu_train_nhwc(_conv_nhwc_train(self.conv1, x, bank), self.bn1)
+        z = ops.bn_relu_train_nhwc(_conv_nhwc_train(self.conv2, y, bank), self.bn2, relu=False)
+        idt = x if self.downsample is None else ops.bn_relu_train_nhwc(_conv_nhwc_train(self.downsample[0], x, bank),
+                                                                         self.downsample[1], relu=False)
+        return _add_relu_nhwc(z, idt)
 
 
 class Bottleneck(nn.Module):
@@ -74,6 +116,15 @@ class Bottleneck(nn.Module):
         y = _bn_relu(self.bn1, self.conv1(x))
         y = _bn_relu(self.bn2, self.conv2(y))
         return _bn_relu(self.bn3, self.conv3(y), x if self.downsample is None else self.downsample(x))
+
+    def forward_nhwc_train(self, x, bank):
+        from .. import ops
+        y = ops.bn_relu_train_nhwc(_conv_nhwc_train(self.conv1, x, bank), self.bn1)
+        y = ops.bn_relu_train_nhwc(_conv_nhwc_train(self.conv2, y, bank), self.bn2)
+        z = ops.bn_relu_train_nhwc(_conv_nhwc_train(self.conv3, y, bank), self.bn3, relu=False)
+        idt = x if self.downsample is None else ops.bn_relu_train_nhwc(_conv_nhwc_train(self.downsample[0], x, bank),
+                                                                         self.downsample[1], relu=False)
+        return _add_relu_nhwc(z, idt)
 
 
 class ResNet(nn.Module):
@@ -111,7 +162,37 @@ class ResNet(nn.Module):
         blocks += [block(out, planes) for _ in range(1, n)]
         return nn.Sequential(*blocks)
 
+    def _nhwc_train_servable(self):
+        ok = getattr(self, "_nw_nhwc_ok", None)
+        if ok is None:
+            ok = self._nw_nhwc_ok = (_convs_nhwc_servable(self, self.conv1) and _is_pool(self.maxpool, nn.MaxPool2d, 3, 2, 1)
+                                     and all(type(d) is nn.Sequential and len(d) == 2 for d in
+                                             (b.downsample for st in (self.layer1, self.layer2, self.layer3, self.layer4) for b in st)
+                                             if d is not None))
+        return ok
+
+    def _forward_nhwc_train(self, x):
+        """The training forward in channels-last layout on the MI355X (round 4; same module sequence as
+        model/resnet.py:192-207): every convolution -- forward, data and weight gradient, the strided ones included -- in
+        csrc/conv_nhwc.hip / conv_wgrad.hip, BatchNorm (+ ReLU) in csrc/bn_nhwc.hip, the max pool in pool_nhwc.hip."""
+        from .. import ops
+        bank = getattr(self, "_nw_bank", None)
+        if bank is None or bank.weights[0] is not self.conv1.weight:
+            convs = [(m.weight, m is not self.conv1) for m in self.modules() if isinstance(m, nn.Conv2d)]
+            bank = self._nw_bank = ops.ConvWeightBank(convs)
+        bank.refresh(force=True)        # one launch; a fused optimizer's step leaves no trace in the version counters
+        y = ops.bn_relu_train_nhwc(_conv_nhwc_train(self.conv1, x, bank), self.bn1)
+        y = ops.maxpool3s2_nhwc(y)
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in stage:
+                y = blk.forward_nhwc_train(y, bank)
+        return torch.flatten(self.avgpool(y), 1)
+
     def forward(self, x):
+        if (NHWC_TRAINING and RESNET_NHWC_TRAINING and self.training and x.is_cuda and x.dtype == torch.float32
+                and torch.is_grad_enabled() and x.dim() == 4 and x.shape[1] == 3 and not isinstance(self.conv1, ConvBiasAct)
+                and self._nhwc_train_servable()):
+            return self._forward_nhwc_train(x)
         if isinstance(self.conv1, ConvBiasAct):      # folded inference copy
             y = self.conv1(x, relu=True)
             if (y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and _is_pool(self.maxpool, nn.MaxPool2d, 3, 2, 1)
@@ -151,6 +232,8 @@ FUSED_BN_RELU_TRAINING = True   # training-mode BatchNorm2d + ReLU through ops.b
 # cores with split-fp16 operands (ops.conv2d_nhwc_train, csrc/conv_nhwc.hip + conv_wgrad.hip) and BatchNorm + ReLU through
 # csrc/bn_nhwc.hip; the DenseNets take this path.  NW_NHWC_TRAINING=0: the NCHW path (MIOpen convolutions).
 NHWC_TRAINING = _os.environ.get("NW_NHWC_TRAINING", "1") != "0"
+# ... and the ImageNet-style ResNets (round 4): NW_RESNET_NHWC_TRAINING=0 keeps them on the NCHW path (MIOpen convolutions + bnrelu.hip)
+RESNET_NHWC_TRAINING = _os.environ.get("NW_RESNET_NHWC_TRAINING", "1") != "0"
 # a dense block of the channels-last training path as one autograd node over one slab (ops._DenseBlockNhwcFn)
 DENSE_SLAB = _os.environ.get("NW_DENSE_SLAB", "1") != "0"
 # a transition of that path as BatchNorm-ReLU -> 2x2 average pool -> 1x1 convolution (pool and convolution commute)

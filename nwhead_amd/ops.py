@@ -1253,6 +1253,10 @@ def _amax_of(t):
 # DenseNet-121 step takes 24.9-26.5 ms against 20.8-22.0 (same box, alternated): the two cross-stream dependencies per
 # node (event + barrier packet each way) cost more than the overlap of two kernels that both want every CU returns.
 WGRAD_SIDE_STREAM = os.environ.get("NW_WGRAD_STREAM", "0") == "1"
+# Data and weight gradients of STRIDED many-channel convolutions (the ResNets' 3x3 / 2 and 1x1 / 2) on the own kernels: the data
+# gradient as the stride-1 one over gy with zeros between its pixels, the weight gradient as one 1x1 problem per tap
+# (round 4).  0: torch / MIOpen.
+OWN_STRIDED_GRADS = os.environ.get("NW_OWN_STRIDED_GRADS", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -1314,6 +1318,17 @@ class _ConvNhwcFn(torch.autograd.Function):
                 if dg is None:
                     dg = SplitConvWeight(weight.detach().flip(2, 3).transpose(0, 1))     # (cin, cout, kh, kw)
                 dx = conv2d_nhwc(g, dg, None, None, False, 1, kh - 1 - pad, amax=gam)
+            elif (OWN_STRIDED_GRADS and stride > 1 and kh == kw and kh - 1 - pad >= 0 and cout % 32 == 0 and cin % 32 == 0
+                  and xv.shape[2] + 2 * pad - kh + 1 >= (g.shape[2] - 1) * stride + 1):
+                # strided: the stride-1 data gradient of gy with zeros between its pixels (model/resnet.py's 3x3 / 2 and 1x1 / 2
+                # convolutions; three quarters of the products are with zeros -- six small layers of a ResNet)
+                dg = ctx.dgrad_operand
+                if dg is None:
+                    dg = SplitConvWeight(weight.detach().flip(2, 3).transpose(0, 1))
+                hd, wd = xv.shape[2] + 2 * pad - kh + 1, xv.shape[3] + 2 * pad - kw + 1
+                gd = torch.zeros((g.shape[0], cout, hd, wd), dtype=torch.float32, device=g.device).contiguous(memory_format=torch.channels_last)
+                gd[:, :, 0:(g.shape[2] - 1) * stride + 1:stride, 0:(g.shape[3] - 1) * stride + 1:stride] = g
+                dx = conv2d_nhwc(gd, dg, None, None, False, 1, kh - 1 - pad, amax=gam)
             else:
                 dx = torch.ops.aten.convolution_backward(g, xv, weight, None, [stride, stride], [pad, pad], [1, 1], False,
                                                          [0, 0], 1, [True, False, False])[0]
@@ -1365,6 +1380,29 @@ def conv2d_nhwc_wgrad(x, gy, wshape, stride, pad, amax_x=None, amax_g=None):
             _lib.check(lib.nw_conv2d_nhwc_wgrad_batch_f16x2(jobs, 1, _ptr(ws), wsb, _stream(x)), "nw_conv2d_nhwc_wgrad_batch_f16x2")
         # rows[co, 32 ky + 4 kx + ci] -> (cout, cin, kh, kw)
         return rows.view(cout, kh, 8, 4)[:, :, :kw, :3].permute(0, 3, 1, 2)
+    if OWN_STRIDED_GRADS and stride > 1 and cin % 8 == 0 and cout % 8 == 0 and x.is_cuda and \
+            lib.nw_conv2d_nhwc_wgrad_supported(n, gy.shape[2], gy.shape[3], cin, cout, 1, 1, 1, 0):
+        # strided convolutions with many channels (model/resnet.py:31-66: 3x3 / 2, 1x1 / 2): one 1x1 problem per tap between gy
+        # and the input pixels that tap reads (a strided slice of the padded input, copied densely), batched into one launch
+        ho, wo = gy.shape[2], gy.shape[3]
+        if amax_x is None:
+            amax_x = _amax_of(x)
+        if amax_g is None:
+            amax_g = _amax_of(gy)
+        gyc = gy if gy.is_contiguous(memory_format=torch.channels_last) else gy.contiguous(memory_format=torch.channels_last)
+        xp = torch.nn.functional.pad(x, (pad, pad, pad, pad)) if pad else x
+        taps = [xp[:, :, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride].contiguous(memory_format=torch.channels_last)
+                for ky in range(kh) for kx in range(kw)]
+        dwt = torch.empty((kh * kw, cout, cin), dtype=torch.float32, device=x.device)
+        jl = [_lib.WgradJob(_ptr(t), _ptr(amax_x), _ptr(gyc), _ptr(amax_g), dwt.data_ptr() + 4 * k * cout * cin, n, ho, wo, cin, cout,
+                            1, 1, 1, 0, 0, 0, 0, None) for k, t in enumerate(taps)]
+        jobs = (_lib.WgradJob * len(jl))(*jl)
+        wsb = lib.nw_conv2d_nhwc_wgrad_batch_workspace_bytes(jobs, len(jl))
+        ws = _workspace(wsb, x.device)
+        with _OnDevice(x.device):
+            _lib.check(lib.nw_conv2d_nhwc_wgrad_batch_f16x2(jobs, len(jl), _ptr(ws), wsb, _stream(x)), "nw_conv2d_nhwc_wgrad_batch_f16x2")
+        del taps
+        return dwt.permute(1, 2, 0).reshape(cout, cin, kh, kw) if kh * kw > 1 else dwt.view(cout, cin, 1, 1)
     # other strided shapes: MIOpen's channels-last weight-gradient kernel on channels-last operands (as NCHW tensors it copies
     # gy and transposes it back)
     return torch.ops.aten.convolution_backward(gy.contiguous(memory_format=torch.channels_last),

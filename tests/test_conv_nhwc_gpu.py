@@ -228,10 +228,15 @@ def test_batched_weight_gradients_equal_the_single_calls(dev):
 
 @pytest.mark.parametrize("n,cin,h,w,cout,k,stride,pad", [(3, 64, 14, 14, 128, 1, 1, 0), (2, 128, 28, 28, 32, 3, 1, 1),
                                                          (2, 160, 14, 14, 128, 1, 1, 0), (2, 64, 28, 28, 128, 3, 2, 1),
-                                                         (2, 3, 32, 32, 64, 7, 2, 3)])
+                                                         (2, 3, 32, 32, 64, 7, 2, 3),
+                                                         # the ResNets' strided layers on the own kernels (round 4): 3x3 / 2, 1x1 / 2, odd maps
+                                                         (3, 64, 56, 56, 128, 3, 2, 1), (3, 64, 56, 56, 128, 1, 2, 0),
+                                                         (2, 128, 15, 13, 256, 3, 2, 1), (2, 256, 7, 9, 512, 1, 2, 0),
+                                                         (6, 512, 3, 3, 512, 3, 1, 1), (6, 256, 6, 6, 512, 3, 2, 1)])   # ResNet-18 layer4 at 96 x 96 inputs
 def test_conv_autograd_node(dev, n, cin, h, w, cout, k, stride, pad):
-    """ops.conv2d_nhwc_train: forward, data gradient (the same kernel on the flipped, transposed weight; torch for the
-    strided shapes) and weight gradient against fp64 autograd, with and without a ConvWeightBank."""
+    """ops.conv2d_nhwc_train: forward, data gradient (the same kernel on the flipped, transposed weight; for the strided
+    many-channel shapes over gy with zeros between its pixels) and weight gradient (strided: one 1x1 problem per tap) against
+    fp64 autograd, with and without a ConvWeightBank."""
     from nwhead_amd import ops
     g = torch.Generator().manual_seed(cin + k)
     x0 = _cl(torch.randn(n, cin, h, w, generator=g).to(dev))
@@ -497,6 +502,63 @@ def test_densenet_training_step_nhwc_against_fp64(dev):
     assert e1 < 1e-4 and e1 < 3 * e0 + 1e-6, (e0, e1)
     c0, c1 = cos(g0, g64), cos(g1, g64)
     assert c1 > 0.9999 and (1 - c1) < 3 * (1 - c0) + 1e-7, (c0, c1)
+
+
+@pytest.mark.parametrize("arch,size,batch", [("resnet18", 96, 6), ("resnet50", 96, 6)])
+def test_resnet_training_step_nhwc_against_fp64(dev, arch, size, batch):
+    """The ImageNet-style ResNets' training forward + backward on the channels-last path (round 4: own convolutions incl. the
+    strided 3x3 / 2 and 1x1 / 2 data and weight gradients and the 7x7 / 2 stem, own NHWC BatchNorm, own max pool;
+    model/resnet.py:31-108, :136-207) against the same network in fp64 -- and at least as close to it as the NCHW path
+    (MIOpen convolutions + bnrelu.hip) is.  The parameter gradients include every BatchNorm's and every projection's."""
+    import copy
+    import nwhead_amd.model.backbones as BB
+    from nwhead_amd.model import load_model
+    from tests.procedural import fill_procedural_hash
+    torch.manual_seed(0)
+    net = load_model(arch)
+    fill_procedural_hash(net)
+    net = net.to(dev).train()
+    x = torch.randn(batch, 3, size, size, device=dev)
+    out_dim = net(x[:2]).shape[1]
+    t = torch.randn(batch, out_dim, device=dev)
+
+    def run(model, xx, tt, nhwc):
+        old = BB.RESNET_NHWC_TRAINING
+        BB.RESNET_NHWC_TRAINING = nhwc
+        try:
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.reset_running_stats()
+            model.zero_grad(set_to_none=True)
+            out = model(xx)
+            (out * tt).sum().backward()
+        finally:
+            BB.RESNET_NHWC_TRAINING = old
+        stats = torch.cat([b.detach().double().flatten() for k, b in model.named_buffers() if "running" in k])
+        return out.detach().double(), torch.cat([p.grad.detach().double().flatten() for p in model.parameters()]), stats
+
+    net64 = copy.deepcopy(net).double()
+    old = BB.FUSED_BN_RELU_TRAINING
+    BB.FUSED_BN_RELU_TRAINING = False
+    try:
+        o64, g64, s64 = run(net64, x.double(), t.double(), False)
+    finally:
+        BB.FUSED_BN_RELU_TRAINING = old
+    o0, g0, s0 = run(net, x, t, False)
+    o1, g1, s1 = run(net, x, t, True)
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))
+    e0 = ((o0 - o64).abs().max() / o64.abs().max()).item()
+    e1 = ((o1 - o64).abs().max() / o64.abs().max()).item()
+    assert e1 < 1e-4 and e1 < 3 * e0 + 1e-6, (e0, e1)
+    # Gradients: a SINGLE ReLU whose pre-activation is zero to fp32 rounding and falls the other way than in fp64 moves every
+    # gradient upstream of it by ~2e-3 of its norm (measured on this input: one flip among layer4.1.bn1's 27 648 activations,
+    # tools/bn_bwd_diag.py; every kernel of the path agrees with fp64 of its OWN inputs to 1e-6, tools/dgrad_diag.py) -- which
+    # path catches such a flip is chance, so the bar is absolute, not relative to the NCHW path.
+    c0, c1 = cos(g0, g64), cos(g1, g64)
+    assert c1 > 0.9999, (c0, c1)
+    m0, m1 = ((g0 - g64).abs().max() / g64.abs().max()).item(), ((g1 - g64).abs().max() / g64.abs().max()).item()
+    assert m1 < max(1e-2, 5 * m0), (m0, m1)
+    assert ((s1 - s64).abs().max() / s64.abs().max()).item() < 1e-4
 
 
 def test_training_forward_sees_a_fused_optimizer_step(dev):

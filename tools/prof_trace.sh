@@ -1,10 +1,13 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/prof_trace.sh TAG B N d C what
+# usage (GPU box, repo root): bash tools/prof_trace.sh TAG script.py [args] -> kernel trace + per-kernel totals of a python script
 set -e
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+S=$GRAFT_REPO_ROOT/$1; shift
 cd /tmp
-rm -rf $OUT/trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/prof_driver.py "$@" 30 > $OUT/trace.log 2>&1
-cat $OUT/trace/*/*_kernel_stats.csv | cut -d, -f1-4,6,7 | cut -c1-220
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $S "$@" > $OUT/trace.log 2>&1
+python3 $GRAFT_REPO_ROOT/tools/pmc_by_kernel.py $OUT $OUT/by_kernel.json > $OUT/by_kernel.txt 2>&1 || true
+grep -v Warn $OUT/trace.log | grep "ms per" || true
+head -30 $OUT/by_kernel.txt
