@@ -544,6 +544,12 @@ int nw_bn_relu_nhwc_train_bwd_from_partials_f32(const float *x, int64_t ldx, con
                                                 float *dbeta, const float *acc, int64_t ldacc, int64_t lddx,
                                                 float *amax_out, void *workspace, size_t workspace_bytes, int64_t rows,
                                                 int64_t c, void *stream);
+/* The end of a residual block in training (model/resnet.py:60-66, :100-108: out = relu(bn(.) + identity)) over two tensors of
+ * equal layout, `count` floats each (a multiple of 4), 16-byte aligned: nw_add_relu_f32 writes out = relu(a + b) (x < 0 ? 0 : x:
+ * keeps a NaN) and out's amax record; nw_relu_bwd_f32 writes dx = g where out > 0, else 0 -- the gradient of BOTH summands --
+ * and dx's amax record.  amax_out nullable. */
+int nw_add_relu_f32(const float *a, const float *b, float *out, float *amax_out, int64_t count, void *stream);
+int nw_relu_bwd_f32(const float *out, const float *g, float *dx, float *amax_out, int64_t count, void *stream);
 /* Backward of `norm1 -> relu1 -> conv1` of a dense layer (model/densenet.py:36-40; the 1x1 bottleneck convolution) in two
  * streaming passes, without the convolution's data gradient ever reaching memory (csrc/bn_dgrad.hip, round 4):
  *   du (rows, k) fp32, dense: dL/d(conv1 output), k = conv1's output channels (multiple of 32, <= 128); amax_du: its amax record;

@@ -128,6 +128,39 @@ inline bool bad_dims(int64_t n, int64_t h, int64_t w, int64_t c) {
            n >= (1LL << 31) || n * h * w >= (1LL << 40);
 }
 
+
+// out = relu(a + b) at the end of a residual block (model/resnet.py:60-66, :100-108), x < 0 ? 0 : x (keeps a NaN, like torch's
+// relu), with the amax record of out: slots b, b + n, ... of the record belong to workgroup b of n
+__global__ __launch_bounds__(1024) void nw_add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                         float* __restrict__ amax, int64_t n4) {
+    __shared__ float red[16];
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        float4 o = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+        o.x = o.x < 0.f ? 0.f : o.x; o.y = o.y < 0.f ? 0.f : o.y; o.z = o.z < 0.f ? 0.f : o.z; o.w = o.w < 0.f ? 0.f : o.w;
+        mx = fmaxf(mx, fmaxf(fmaxf(o.x, o.y), fmaxf(o.z, o.w)));
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+    mx = nw::block_max(mx, red);
+    if (amax && threadIdx.x < 256 && (int)threadIdx.x % (int)gridDim.x == (int)blockIdx.x) amax[threadIdx.x] = threadIdx.x == blockIdx.x ? mx : 0.f;
+}
+
+// dx = g where out > 0 (the backward of the ReLU above; both summands of the block receive dx), with dx's amax record
+__global__ __launch_bounds__(1024) void nw_relu_bwd_kernel(const float* __restrict__ out, const float* __restrict__ g, float* __restrict__ dx,
+                                                         float* __restrict__ amax, int64_t n4) {
+    __shared__ float red[16];
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 y = reinterpret_cast<const float4*>(out)[i], v = reinterpret_cast<const float4*>(g)[i];
+        const float4 o = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+    mx = nw::block_max(mx, red);
+    if (amax && threadIdx.x < 256 && (int)threadIdx.x % (int)gridDim.x == (int)blockIdx.x) amax[threadIdx.x] = threadIdx.x == blockIdx.x ? mx : 0.f;
+}
+
 }  // namespace
 
 extern "C" int nw_avgpool2x2_nhwc_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n, int64_t h, int64_t w, int64_t c,
@@ -190,6 +223,34 @@ extern "C" int nw_maxpool3x3s2_nhwc_bwd_f32(const float* gy, int64_t ldgy, const
     const int64_t total = n * h * w * q4;
     hipLaunchKernelGGL(nw_maxpool3s2_nhwc_bwd_kernel, dim3(pool_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), gy, ldgy,
                        tap, gx, ldgx, (int)h, (int)w, Ho, Wo, (int)c, q4, total);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+static int ew_args(const void* a, const void* b, const void* c, const void* amax, int64_t count) {
+    if (count < 0 || count % 4) return NW_ERR_INVALID_ARG;
+    if (count > 0 && (!a || !b || !c)) return NW_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(amax)) & 15)
+        return NW_ERR_INVALID_ARG;
+    return NW_OK;
+}
+static unsigned ew_grid(int64_t n4) {
+    const int64_t g = (n4 + 1023) / 1024;
+    return (unsigned)(g < 1 ? 1 : (g > 256 ? 256 : g));           // (<= the record's 256 slots: one per workgroup of 1024 threads)
+}
+
+extern "C" int nw_add_relu_f32(const float* a, const float* b, float* out, float* amax_out, int64_t count, void* stream) {
+    const int rc = ew_args(a, b, out, amax_out, count);
+    if (rc != NW_OK) return rc;
+    hipLaunchKernelGGL(nw_add_relu_kernel, dim3(ew_grid(count / 4)), dim3(1024), 0, static_cast<hipStream_t>(stream), a, b, out, amax_out, count / 4);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_relu_bwd_f32(const float* out, const float* g, float* dx, float* amax_out, int64_t count, void* stream) {
+    const int rc = ew_args(out, g, dx, amax_out, count);
+    if (rc != NW_OK) return rc;
+    hipLaunchKernelGGL(nw_relu_bwd_kernel, dim3(ew_grid(count / 4)), dim3(1024), 0, static_cast<hipStream_t>(stream), out, g, dx, amax_out, count / 4);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

@@ -42,9 +42,7 @@ def _add_relu_nhwc(z, identity):
     """relu(z + identity) at the end of a residual block (model/resnet.py:60-66, :100-108), with the amax record the next
     convolution scales its operand by."""
     from .. import ops
-    out = torch.relu(z + identity)
-    out.nw_amax = ops.absmax(out.detach())
-    return out
+    return ops.add_relu_nhwc(z, identity)
 
 
 def _convs_nhwc_servable(model, stem):
@@ -276,6 +274,13 @@ class PreActBlock(nn.Module):
         y = self.conv2(_bn_relu(self.bn2, self.conv1(a)))
         return y + self.shortcut(a)
 
+    def forward_nhwc_train(self, x, bank):
+        """The block in channels-last layout on the own kernels (CIFAR_ResNet._forward_nhwc_train)."""
+        from .. import ops
+        a = ops.bn_relu_train_nhwc(x, self.bn1)
+        y = _conv_nhwc_train(self.conv2, ops.bn_relu_train_nhwc(_conv_nhwc_train(self.conv1, a, bank), self.bn2), bank)
+        return y + (a if len(self.shortcut) == 0 else _conv_nhwc_train(self.shortcut[0], a, bank))
+
 
 class CIFAR_ResNet(nn.Module):
     """3x3 stem, four stages, 4x4 average pool: 32x32 inputs only (model/resnet.py:209-239)."""
@@ -291,7 +296,35 @@ class CIFAR_ResNet(nn.Module):
                 self.in_planes = planes * block.expansion
             setattr(self, f"layer{idx}", nn.Sequential(*blocks))
 
+    def _nhwc_train_servable(self):
+        ok = getattr(self, "_nw_nhwc_ok", None)
+        if ok is None:
+            ok = self._nw_nhwc_ok = (_convs_nhwc_servable(self, self.conv1)
+                                     and all(isinstance(b, PreActBlock) and len(b.shortcut) <= 1
+                                             for st in (self.layer1, self.layer2, self.layer3, self.layer4) for b in st))
+        return ok
+
+    def _forward_nhwc_train(self, x):
+        """The training forward in channels-last layout on the MI355X (round 4; model/resnet.py:209-239, the reference's default
+        CIFAR backbone): every convolution incl. the strided ones and the 1x1 shortcuts in csrc/conv_nhwc.hip / conv_wgrad.hip,
+        BatchNorm + ReLU in csrc/bn_nhwc.hip."""
+        from .. import ops
+        bank = getattr(self, "_nw_bank", None)
+        if bank is None or bank.weights[0] is not self.conv1.weight:
+            convs = [(m.weight, m is not self.conv1) for m in self.modules() if isinstance(m, nn.Conv2d)]
+            bank = self._nw_bank = ops.ConvWeightBank(convs)
+        bank.refresh(force=True)
+        y = ops.bn_relu_train_nhwc(_conv_nhwc_train(self.conv1, x, bank), self.bn1)
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in stage:
+                y = blk.forward_nhwc_train(y, bank)
+        return torch.flatten(F.avg_pool2d(y, 4), 1)
+
     def forward(self, x, lin=0, lout=5):
+        if (NHWC_TRAINING and RESNET_NHWC_TRAINING and self.training and x.is_cuda and x.dtype == torch.float32
+                and torch.is_grad_enabled() and x.dim() == 4 and x.shape[1] == 3 and isinstance(self.conv1, nn.Conv2d)
+                and self._nhwc_train_servable()):
+            return self._forward_nhwc_train(x)
         x = _bn_relu(self.bn1, self.conv1(x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return torch.flatten(F.avg_pool2d(x, 4), 1)

@@ -1045,6 +1045,49 @@ def bn_relu_train_nhwc(x, bn, relu=True, passthrough=False):
     return _BNReLUNhwcFn.apply(x, bn.weight, bn.bias, bn, bool(relu), bool(passthrough))
 
 
+class _AddReluNhwcFn(torch.autograd.Function):
+    """relu(a + b) over two channels-last tensors (the end of a residual block, model/resnet.py:60-66) with the amax record of the
+    result; backward: ONE masked gradient for both summands (nw_add_relu_f32 / nw_relu_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        av, bv = a.detach(), b.detach()
+        if not (av.is_contiguous(memory_format=torch.channels_last) and bv.is_contiguous(memory_format=torch.channels_last)):
+            av, bv = av.contiguous(memory_format=torch.channels_last), bv.contiguous(memory_format=torch.channels_last)
+        out = torch.empty_like(av, memory_format=torch.channels_last)
+        amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=av.device)
+        with _OnDevice(av.device):
+            _lib.check(lib.nw_add_relu_f32(_ptr(av), _ptr(bv), _ptr(out), _ptr(amax), av.numel(), _stream(av)), "nw_add_relu_f32")
+        ctx.save_for_backward(out)
+        out.nw_amax = amax
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        out, = ctx.saved_tensors
+        if g.dtype != torch.float32 or not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.float().contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(out, memory_format=torch.channels_last)
+        amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=out.device)
+        with _OnDevice(out.device):
+            _lib.check(lib.nw_relu_bwd_f32(_ptr(out), _ptr(g), _ptr(dx), _ptr(amax), out.numel(), _stream(out)), "nw_relu_bwd_f32")
+        dx.nw_amax = amax
+        return dx, dx
+
+
+def add_relu_nhwc(a, b):
+    """relu(a + b) for two channels-last fp32 activations of one shape on the MI355X; the result carries `.nw_amax`."""
+    _need_hip(a, b)
+    if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32 or a.numel() % 4:
+        out = torch.relu(a + b)
+        out.nw_amax = absmax(out.detach())
+        return out
+    return _AddReluNhwcFn.apply(a, b)
+
+
 def _with_room(n, c, h, w, room, dev):
     """A channels-last (n, c, h, w) result tensor, alone or -- room > 0 -- as the first c channels of a fresh (n, c + room, h, w)
     allocation it carries as `.nw_slab`: a dense block that follows adopts that allocation as its slab instead of copying its

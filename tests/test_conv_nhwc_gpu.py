@@ -387,6 +387,29 @@ def test_fused_norm1_backward_against_fp64(dev, n, h, w, c, ctot, mid):
     assert (dg - dg2).abs().max().item() < 2e-5 * sc(dgamma) and (db - db2).abs().max().item() < 2e-5 * sc(dbeta)
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 7, 5), (2, 128, 28, 28), (1, 4, 1, 1), (5, 36, 9, 3)])
+def test_add_relu_nhwc_against_torch(dev, shape):
+    """ops.add_relu_nhwc (nw_add_relu_f32 / nw_relu_bwd_f32: the end of a residual block, model/resnet.py:60-66): values bit-equal
+    to torch's relu(a + b) incl. a NaN, the amax records of the result and of the gradient, one masked gradient for both summands."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    a = _cl(torch.randn(*shape, generator=g).to(dev)).requires_grad_(True)
+    b = _cl(torch.randn(*shape, generator=g).to(dev)).requires_grad_(True)
+    t = _cl(torch.randn(*shape, generator=g).to(dev))
+    out = ops.add_relu_nhwc(a, b)
+    ref = torch.relu(a.detach() + b.detach())
+    assert torch.equal(out.detach(), ref) and out.is_contiguous(memory_format=torch.channels_last)
+    assert float(out.nw_amax.max()) == float(ref.abs().max()) and out.nw_amax.shape == (ops.AMAX_SLOTS,)
+    (out * t).sum().backward()
+    want = torch.where(ref > 0, t, torch.zeros_like(t))
+    assert torch.equal(a.grad, want) and torch.equal(b.grad, want)
+    with torch.no_grad():
+        a2 = a.detach().clone()
+        a2[0, 0, 0, 0] = float("nan")
+        o2 = ops.add_relu_nhwc(a2, b.detach())
+        assert torch.isnan(o2[0, 0, 0, 0]) and torch.equal(o2.reshape(-1)[1:], ref.reshape(-1)[1:])
+
+
 @pytest.mark.parametrize("c", [64, 2592])
 def test_bn_relu_nhwc_cumulative_average(dev, c):
     """BatchNorm2d(momentum=None): running statistics are the cumulative average (factor 1 / num_batches_tracked, counted
@@ -504,9 +527,9 @@ def test_densenet_training_step_nhwc_against_fp64(dev):
     assert c1 > 0.9999 and (1 - c1) < 3 * (1 - c0) + 1e-7, (c0, c1)
 
 
-@pytest.mark.parametrize("arch,size,batch", [("resnet18", 96, 6), ("resnet50", 96, 6)])
+@pytest.mark.parametrize("arch,size,batch", [("resnet18", 96, 6), ("resnet50", 96, 6), ("CIFAR_ResNet18", 32, 16)])
 def test_resnet_training_step_nhwc_against_fp64(dev, arch, size, batch):
-    """The ImageNet-style ResNets' training forward + backward on the channels-last path (round 4: own convolutions incl. the
+    """The ResNets' (ImageNet-style and the CIFAR pre-activation one) training forward + backward on the channels-last path (round 4: own convolutions incl. the
     strided 3x3 / 2 and 1x1 / 2 data and weight gradients and the 7x7 / 2 stem, own NHWC BatchNorm, own max pool;
     model/resnet.py:31-108, :136-207) against the same network in fp64 -- and at least as close to it as the NCHW path
     (MIOpen convolutions + bnrelu.hip) is.  The parameter gradients include every BatchNorm's and every projection's."""
