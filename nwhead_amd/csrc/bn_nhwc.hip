@@ -844,7 +844,7 @@ extern "C" int nw_bn_relu_nhwc_apply_f32(const float* x, int64_t ldx, const floa
                                          int64_t c, int relu, void* stream) {
     using namespace nw;
     if (rows <= 0 || c <= 0 || c % 4 || ldx < c || ldx % 4) return NW_ERR_INVALID_ARG;
-    if (!x || !mean || !invstd || !var || !gamma || !beta || !y) return NW_ERR_INVALID_ARG;
+    if (!x || !mean || !invstd || (!var && running_var) || !gamma || !beta || !y) return NW_ERR_INVALID_ARG;   // (var: only for the running variance)
     if (bad_align(x, y, amax_out) || bad_align(gamma, beta, mean, invstd)) return NW_ERR_INVALID_ARG;
     if (c > BN_MAX_C) return NW_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -531,6 +531,10 @@ class DenseNet(nn.Module):
                 plan["mods"].append(("block", layers))
             elif isinstance(mod, _Transition):
                 plan["mods"].append(("transition", (ops.bn_table(mod.norm), ops.SplitConvWeight(mod.conv.weight.detach().float()))))
+        n5 = f.norm5
+        plan["norm5"] = (n5.running_mean.detach().float().contiguous(),
+                         torch.rsqrt(n5.running_var.detach().float() + n5.eps).contiguous(),
+                         n5.weight.detach().float().contiguous(), n5.bias.detach().float().contiguous())
         object.__setattr__(self, "_nw_infer_plan", plan)
         return plan
 
@@ -554,8 +558,7 @@ class DenseNet(nn.Module):
             else:
                 tab, wt = pl
                 y = ops.avgpool2_nhwc(ops.conv1x1_bnrelu_nhwc_infer(y, tab, wt), rooms[i + 1])
-        n5 = f.norm5
-        y = F.relu(F.batch_norm(y, n5.running_mean, n5.running_var, n5.weight, n5.bias, False, 0.0, n5.eps))
+        y = ops.bn_relu_nhwc_apply(y, *plan["norm5"])           # norm5 + the relu of DenseNet.forward (densenet.py:139, :160)
         return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
 
     def _nhwc_servable(self):

@@ -1698,6 +1698,23 @@ class _DenseBlockNhwcFn(torch.autograd.Function):
         return (dx, None, None, *grads)
 
 
+@torch.no_grad()
+def bn_relu_nhwc_apply(x, mean, invstd, gamma, beta, relu=True):
+    """relu((x - mean) gamma invstd + beta) over a channels-last fp32 activation with GIVEN statistics (an eval-mode BatchNorm2d
+    + ReLU that no convolution follows: DenseNet's norm5) in nw_bn_relu_nhwc_apply_f32; (n, c, h, w), c % 4 == 0."""
+    _need_hip(x)
+    lib = _lib.load()
+    xv, ldx = _nhwc_rows(x)
+    n, c, h, w = xv.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=xv.device, memory_format=torch.channels_last)
+    amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=xv.device)
+    with _OnDevice(xv.device):
+        _lib.check(lib.nw_bn_relu_nhwc_apply_f32(_ptr(xv), ldx, _ptr(mean), _ptr(invstd), None, _ptr(gamma), _ptr(beta), None, None, None,
+                                                 0.0, _ptr(y), _ptr(amax), n * h * w, c, int(relu), _stream(xv)), "nw_bn_relu_nhwc_apply_f32")
+    y.nw_amax = amax
+    return y
+
+
 def bn_table(bn):
     """mean | a | beta (3 c floats) of an eval-mode BatchNorm2d for nw_conv2d_nhwc_bnrelu_f16x2: y = (x - mean) a + beta."""
     a = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
