@@ -221,10 +221,11 @@ def measure_influence(B, N, C, dev, iters=100):
     try:
         e = json.load(open(os.path.join(ROOT, "profiles/r04_K5_pmc_by_kernel.json")))
         for k, v in e.items():
-            if k.startswith("nw_influence_kernel") and "hbm_read_MB_per_call_x2_corrected" in v:
+            if k.startswith("nw_influence_kernel<false>") and "hbm_read_MB_per_call_x2_corrected" in v:
                 roof["traffic"] = (v["hbm_read_MB_per_call_x2_corrected"] + v["hbm_write_MB_per_call"]) * 1e6
-                roof["traffic_source"] = "profiles/r04_K5_pmc_by_kernel.json (all calls of tools/k5_time.py: both batch sizes; FETCH_SIZE x 2 + WRITE_SIZE)"
-                roof["kernel_us_in_trace"] = v.get("avg_us")
+                roof["traffic_source"] = ("profiles/r04_K5_pmc_by_kernel.json: FETCH_SIZE x 2 + WRITE_SIZE averaged over ALL stand-alone calls of "
+                                          "tools/k5_time.py (~6 700 at B=256 = 20.6 MB algorithmic each, ~50 at B=4096 = 328 MB: 22.8 MB "
+                                          "algorithmic on average)")
     except Exception:
         pass
     return {"B": B, "N": N, "C": C, "alg_bytes_per_call": nbytes, "roofline": roof if B == 256 else None,
