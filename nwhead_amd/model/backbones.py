@@ -38,6 +38,21 @@ def _conv_nhwc_train(conv, x, bank):
     return ops.conv2d_nhwc_train(x, conv.weight, conv.stride[0], conv.padding[0], operands=bank.operands(conv.weight))
 
 
+def _fold_conv_bn_split(conv, bn):
+    """conv -> eval-mode BatchNorm as ONE split-row weight and a bias (what ops.conv2d_nhwc takes)."""
+    from .. import ops
+    a = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    wf = conv.weight.detach().float() * a.view(-1, 1, 1, 1)
+    b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(a)
+    return ops.SplitConvWeight(wf), (bn.bias.detach().float() + (b0 - bn.running_mean.detach().float()) * a).contiguous()
+
+
+def _bn_apply_args(bn):
+    """(mean, invstd, gamma, beta) of an eval-mode BatchNorm2d for ops.bn_relu_nhwc_apply."""
+    return (bn.running_mean.detach().float().contiguous(), torch.rsqrt(bn.running_var.detach().float() + bn.eps).contiguous(),
+            bn.weight.detach().float().contiguous(), bn.bias.detach().float().contiguous())
+
+
 def _add_relu_nhwc(z, identity):
     """relu(z + identity) at the end of a residual block (model/resnet.py:60-66, :100-108), with the amax record the next
     convolution scales its operand by."""
@@ -304,6 +319,14 @@ class CIFAR_ResNet(nn.Module):
                                              for st in (self.layer1, self.layer2, self.layer3, self.layer4) for b in st))
         return ok
 
+    def _nhwc_infer_servable(self):
+        """Plain modules with running statistics (a copy fold_batchnorm has rewritten runs its own modules)."""
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d) and (type(m) is not nn.BatchNorm2d or m.running_mean is None or not m.affine):
+                return False
+        return all(type(b.bn1) is nn.BatchNorm2d and type(b.bn2) is nn.BatchNorm2d and isinstance(b.conv1, nn.Conv2d)
+                   and isinstance(b.conv2, nn.Conv2d) for st in (self.layer1, self.layer2, self.layer3, self.layer4) for b in st)
+
     def _forward_nhwc_train(self, x):
         """The training forward in channels-last layout on the MI355X (round 4; model/resnet.py:209-239, the reference's default
         CIFAR backbone): every convolution incl. the strided ones and the 1x1 shortcuts in csrc/conv_nhwc.hip / conv_wgrad.hip,
@@ -320,11 +343,49 @@ class CIFAR_ResNet(nn.Module):
                 y = blk.forward_nhwc_train(y, bank)
         return torch.flatten(F.avg_pool2d(y, 4), 1)
 
+    def _infer_plan(self, dev):
+        """What the inference kernels read: split-row weights (conv -> BatchNorm pairs folded), biases, BatchNorm factors.
+        Rebuilt when a parameter or buffer has changed (address or in-place version)."""
+        from .. import ops
+        ts = list(self.parameters()) + list(self.buffers())
+        sig = (str(dev), len(ts), sum(0 if t.is_inference() else t._version for t in ts), sum(t.data_ptr() & 0xffffff for t in ts))
+        plan = getattr(self, "_nw_infer_plan", None)
+        if plan is not None and plan["sig"] == sig:
+            return plan
+        plan = {"sig": sig, "stem": _fold_conv_bn_split(self.conv1, self.bn1), "blocks": []}
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for b in stage:
+                sc = ops.SplitConvWeight(b.shortcut[0].weight.detach().float()) if len(b.shortcut) else None
+                plan["blocks"].append((_bn_apply_args(b.bn1), _fold_conv_bn_split(b.conv1, b.bn2), b.conv1.stride[0],
+                                       ops.SplitConvWeight(b.conv2.weight.detach().float()), sc))
+        object.__setattr__(self, "_nw_infer_plan", plan)
+        return plan
+
+    @torch.no_grad()
+    def _forward_nhwc_infer(self, x):
+        """Eval-mode forward on the channels-last split-fp16 kernels (round 4; model/resnet.py:111-134, :209-239): the stem with bn1
+        folded in and ReLU in its store; per block relu(bn1(x)) in one pass (nw_bn_relu_nhwc_apply_f32: the shortcut needs it too),
+        conv1 with bn2 folded in + ReLU, conv2 with the shortcut added in its store."""
+        from .. import ops
+        plan = self._infer_plan(x.device)
+        w0, b0 = plan["stem"]
+        y = ops.conv2d_nhwc(x, w0, b0, None, True, 1, 1)
+        for bn1, (w1, b1), stride, w2, wsc in plan["blocks"]:
+            a = ops.bn_relu_nhwc_apply(y, *bn1)
+            sc = a if wsc is None else ops.conv2d_nhwc(a, wsc, None, None, False, stride, 0, want_amax=False)
+            t = ops.conv2d_nhwc(a, w1, b1, None, True, stride, 1)
+            y = ops.conv2d_nhwc(t, w2, None, sc, False, 1, 1, want_amax=False)
+        return torch.flatten(F.avg_pool2d(y, 4), 1)
+
     def forward(self, x, lin=0, lout=5):
         if (NHWC_TRAINING and RESNET_NHWC_TRAINING and self.training and x.is_cuda and x.dtype == torch.float32
                 and torch.is_grad_enabled() and x.dim() == 4 and x.shape[1] == 3 and isinstance(self.conv1, nn.Conv2d)
                 and self._nhwc_train_servable()):
             return self._forward_nhwc_train(x)
+        if (NHWC_INFERENCE and not self.training and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and x.dim() == 4 and x.shape[1] == 3 and isinstance(self.conv1, nn.Conv2d) and type(self.bn1) is nn.BatchNorm2d
+                and self._nhwc_train_servable() and self._nhwc_infer_servable()):
+            return self._forward_nhwc_infer(x)
         x = _bn_relu(self.bn1, self.conv1(x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return torch.flatten(F.avg_pool2d(x, 4), 1)
@@ -943,6 +1004,9 @@ def fold_batchnorm(model):
     for mod in m.modules():
         if isinstance(mod, DenseNet) and NHWC_INFERENCE and mod._nhwc_servable() and next(mod.parameters()).is_cuda:
             keep.update(id(x) for x in mod.modules())
+        if (isinstance(mod, CIFAR_ResNet) and NHWC_INFERENCE and next(mod.parameters()).is_cuda and mod._nhwc_train_servable()
+                and mod._nhwc_infer_servable()):
+            keep.update(id(x) for x in mod.modules())      # (likewise: CIFAR_ResNet._forward_nhwc_infer)
     for mod in list(m.modules()):                # (the featurizer may sit inside a Sequential: proj_dim > 0)
         if id(mod) in keep:
             continue
@@ -980,6 +1044,8 @@ def fold_batchnorm(model):
         elif isinstance(mod, (CifarTransition, CIFAR_DenseNet)):
             mod.bn = ScaleShiftReLU(mod.bn)
     for mod in m.modules():
+        if id(mod) in keep:
+            continue
         if isinstance(mod, BasicBlock) and FUSED_RESNET_CONV3X3 and isinstance(mod.conv2, nn.Conv2d) and mod.conv2.out_channels % 32 == 0:
             if mod.conv1.stride == (1, 1):
                 mod.conv1, mod.bn1 = Conv3x3Fused(mod.conv1, mod.bn1, post_relu=True), nn.Identity()

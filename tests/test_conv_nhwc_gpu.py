@@ -974,3 +974,32 @@ def test_densenet121_inference_on_the_channels_last_kernels(dev):
         ref2 = net.cpu().double()(x.double())
     assert (y2.cpu().double() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
     assert not torch.allclose(y2, y)
+
+
+@pytest.mark.parametrize("arch,batch", [("CIFAR_ResNet18", 16), ("CIFAR_ResNet10", 5)])
+def test_cifar_resnet_inference_on_the_channels_last_kernels(dev, arch, batch):
+    """CIFAR_ResNet._forward_nhwc_infer (round 4; model/resnet.py:111-134, :209-239): the eval-mode pre-activation ResNet on the split-fp16
+    kernels -- stem with bn1 folded, relu(bn1(.)) per block in one pass, conv1 with bn2 folded, conv2 with the shortcut in its
+    store -- against the fp32 CPU network with the same parameters and running statistics; no torch convolution is called."""
+    import copy
+    from nwhead_amd.model import load_model
+    from tests.procedural import fill_procedural_hash
+    net = load_model(arch)
+    fill_procedural_hash(net)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        net.train()
+        net(torch.randn(8, 3, 32, 32, generator=g))            # running statistics off their init
+        net.eval()
+        x = torch.randn(batch, 3, 32, 32, generator=g)
+        want = net(x)
+        dnet = copy.deepcopy(net).to(dev).eval()
+        calls = []
+        orig = F.conv2d
+        F.conv2d = lambda *a, **k: calls.append(1) or orig(*a, **k)
+        try:
+            got = dnet(x.to(dev))
+        finally:
+            F.conv2d = orig
+    assert getattr(dnet, "_nw_infer_plan", None) is not None and not calls
+    assert (got.cpu() - want).abs().max().item() < 1e-4 * want.abs().max().item()

@@ -113,10 +113,13 @@ def test_bn_folding_through_nwnet(arch):
         net.enable_bn_folding()
         net.precompute()
         assert net._folded is not None
-        # the ResNet family's copy is kept in channels_last; the pre-activation copy (HIP BatchNorm+ReLU) stays NCHW
-        assert hasattr(net._folded, "inner") == (arch == "resnet18")
-        assert not any(isinstance(m, nn.BatchNorm2d) for m in net._folded.modules())
+        # the copies are kept in channels_last (a copy with NCHW HIP kernels inside -- ScaleShiftReLU, Conv1x1Fused -- would not be)
+        assert hasattr(net._folded, "inner")
+        if arch == "resnet18":
+            assert not any(isinstance(m, nn.BatchNorm2d) for m in net._folded.modules())
         out = net.predict(x, "full")
+        if arch != "resnet18":   # round 4: CIFAR_ResNet._forward_nhwc_infer folds for itself from the plain modules (as the DenseNets' path does)
+            assert getattr(net._folded.inner, "_nw_infer_plan", None) is not None
     assert torch.allclose(out, ref, rtol=1e-3, atol=1e-3), (out - ref).abs().max()
     assert list(net.state_dict().keys()) == keys
     net.train()
@@ -157,7 +160,7 @@ def test_preactivation_folded_copy_on_the_device(arch, size):
         folded = fold_batchnorm(net)
         x = torch.randn(3, 3, size, size, generator=g).cuda()
         a, b = net(x), folded(x)
-    if arch == "densenet121":     # round 4: served by DenseNet._forward_nhwc_infer, which folds for itself from the plain modules
+    if arch in ("densenet121", "CIFAR_ResNet18"):     # round 4: served by _forward_nhwc_infer, which folds for itself from the plain modules
         assert getattr(folded, "_nw_infer_plan", None) is not None
     else:
         assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules())
