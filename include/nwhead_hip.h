@@ -544,6 +544,18 @@ int nw_bn_relu_nhwc_train_bwd_from_partials_f32(const float *x, int64_t ldx, con
                                                 float *dbeta, const float *acc, int64_t ldacc, int64_t lddx,
                                                 float *amax_out, void *workspace, size_t workspace_bytes, int64_t rows,
                                                 int64_t c, void *stream);
+/* The ImageNet stems at inference in one kernel (csrc/stem_pool.hip; model/resnet.py:147, :200-203, model/densenet.py:114-120 with
+ * the BatchNorm folded into weight and bias): y = maxpool3x3/2/1(relu(conv7x7/2/3(x) + bias)), 64 output channels; the
+ * 112 x 112 map between the two never reaches memory.
+ *   x4 (n, H, W, 4) fp32: the 4-channel padded input of nw_to_nhwc_pad_f32, amax_in its amax record;
+ *   w_split / w_scale: the (64, 7 x 32) few-channel operand of nw_split_rows_f16x2 (k = 32 ky + 4 kx + ci, as nw_conv2d_nhwc_f16x2
+ *     takes it for a 4-channel input); bias (64,);
+ *   y (n, Hp, Wp, >= 64) with row stride ldy floats (0: 64), Hp = ((H - 1) / 2 + 1 - 1) / 2 + 1; amax_out (nullable): its record.
+ * Same values as nw_conv2d_nhwc_f16x2(bias, relu) + nw_maxpool3x3s2_nhwc_f32 up to fp32 summation order. */
+int nw_stem7x7s2_relu_maxpool_supported(int64_t n, int64_t H, int64_t W, int64_t cout);
+int nw_stem7x7s2_relu_maxpool_f16x2(const float *x4, const float *amax_in, const float *w_split, const float *w_scale,
+                                    const float *bias, float *y, float *amax_out, int64_t n, int64_t H, int64_t W, int64_t ldy,
+                                    void *stream);
 /* The end of a residual block in training (model/resnet.py:60-66, :100-108: out = relu(bn(.) + identity)) over two tensors of
  * equal layout, `count` floats each (a multiple of 4), 16-byte aligned: nw_add_relu_f32 writes out = relu(a + b) (x < 0 ? 0 : x:
  * keeps a NaN) and out's amax record; nw_relu_bwd_f32 writes dx = g where out > 0, else 0 -- the gradient of BOTH summands --

@@ -207,6 +207,14 @@ class ResNet(nn.Module):
                 and self._nhwc_train_servable()):
             return self._forward_nhwc_train(x)
         if isinstance(self.conv1, ConvBiasAct):      # folded inference copy
+            c1 = self.conv1
+            if (FUSED_CONV_NHWC and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and not torch.is_grad_enabled()
+                    and c1.kernel_size == (7, 7) and c1.stride == (2, 2) and c1.padding == (3, 3) and c1.out_channels == 64
+                    and c1.groups == 1 and c1.dilation == (1, 1) and c1.bias is not None and _is_pool(self.maxpool, nn.MaxPool2d, 3, 2, 1)):
+                from .. import ops       # stem convolution + ReLU + max pool in one kernel: the 112 x 112 map stays on the CU
+                y = ops.stem_conv_relu_maxpool_nhwc(x, c1._split_weight(), c1.bias)
+                y = self.layer4(self.layer3(self.layer2(self.layer1(y))))
+                return torch.flatten(self.avgpool(y), 1)
             y = self.conv1(x, relu=True)
             if (y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and _is_pool(self.maxpool, nn.MaxPool2d, 3, 2, 1)
                     and y.is_contiguous(memory_format=torch.channels_last) and not torch.is_grad_enabled()):
@@ -611,8 +619,7 @@ class DenseNet(nn.Module):
         mods = [m for m in f.children() if isinstance(m, (_DenseBlock, _Transition))]
         rooms = [m.slab_room() if isinstance(m, _DenseBlock) else 0 for m in mods] + [0]
         w0, b0 = plan["stem"]
-        y = ops.conv2d_nhwc(x, w0, b0, None, True, 2, 3)
-        y = ops.maxpool3s2_nhwc(y, rooms[0])
+        y = ops.stem_conv_relu_maxpool_nhwc(x, w0, b0, rooms[0])        # (one kernel where it serves the shape)
         for i, (mod, (kind, pl)) in enumerate(zip(mods, plan["mods"])):
             if kind == "block":
                 y = ops.dense_block_nhwc_infer(y, pl)

@@ -934,6 +934,35 @@ def conv2d_nhwc(x, weight, bias=None, residual=None, relu=False, stride=1, pad=0
     return y
 
 
+STEM_POOL_FUSED = os.environ.get("NW_STEM_POOL_FUSED", "1") != "0"
+
+
+@torch.no_grad()
+def stem_conv_relu_maxpool_nhwc(x, weight, bias, room=0):
+    """maxpool3x3/2/1(relu(conv7x7/2/3(x) + bias)) of an ImageNet stem at inference (model/resnet.py:147, :200-203,
+    model/densenet.py:114-120; BatchNorm folded into `weight`, a SplitConvWeight of shape (64, 4, 7, 7), and `bias`) as ONE kernel
+    (nw_stem7x7s2_relu_maxpool_f16x2) when it serves the shape, else the convolution and the pool; x: (n, 3, H, W) fp32 on the
+    device.  The result is channels_last with `.nw_amax`; room: see conv2d_nhwc."""
+    _need_hip(x, bias)
+    lib = _lib.load()
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    if not (STEM_POOL_FUSED and cin == 3 and tuple(weight.shape[1:]) == (4, 7, 7) and bias is not None
+            and lib.nw_stem7x7s2_relu_maxpool_supported(n, h, w, cout)):
+        return maxpool3s2_nhwc(conv2d_nhwc(x, weight, bias, None, True, 2, 3), room)
+    x4 = to_nhwc_pad(x, 4)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    y, ldy = _with_room(n, cout, hp, wp, room, x.device)
+    am = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=x.device)
+    with _OnDevice(x.device):
+        _lib.check(lib.nw_stem7x7s2_relu_maxpool_f16x2(_ptr(x4), _ptr(x4.nw_amax), _ptr(weight.split), _ptr(weight.scale), _ptr(_f32c(bias)),
+                                                       _ptr(y), _ptr(am), n, h, w, ldy if room > 0 else 0, _stream(x4)),
+                   "nw_stem7x7s2_relu_maxpool_f16x2")
+    y.nw_amax = am
+    return y
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Channels-last training path: BatchNorm + ReLU (csrc/bn_nhwc.hip) and the convolution's autograd node.
 def _nhwc_rows(x):

@@ -1003,3 +1003,33 @@ def test_cifar_resnet_inference_on_the_channels_last_kernels(dev, arch, batch):
             F.conv2d = orig
     assert getattr(dnet, "_nw_infer_plan", None) is not None and not calls
     assert (got.cpu() - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("n,h,w,room", [(3, 64, 64, 0), (2, 224, 224, 0), (2, 37, 53, 0), (1, 9, 7, 0), (5, 96, 80, 32), (1, 8, 201, 0)])
+def test_fused_stem_against_convolution_plus_pool(dev, n, h, w, room):
+    """nw_stem7x7s2_relu_maxpool_f16x2 (round 4; model/resnet.py:147, :200-203, model/densenet.py:114-120 with the BatchNorm folded in):
+    conv7x7/2 + bias + ReLU + maxpool3x3/2 in one kernel against the two kernels it replaces (same arithmetic: equal to fp32
+    rounding) and against fp64 torch; odd sizes, maps smaller than a tile, a result written into a wider slab, a NaN pixel."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(n + h + w)
+    x = (torch.randn(n, 3, h, w, generator=g) * 1.3 + 0.2).to(dev)
+    wt = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).to(dev)
+    b = (torch.randn(64, generator=g) * 0.3).to(dev)
+    sw = ops.SplitConvWeight(wt)
+    got = ops.stem_conv_relu_maxpool_nhwc(x, sw, b, room)
+    two = ops.maxpool3s2_nhwc(ops.conv2d_nhwc(x, sw, b, None, True, 2, 3), room)
+    ref = F.max_pool2d(F.relu(F.conv2d(x.double(), wt.double(), b.double(), 2, 3)), 3, 2, 1)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last) == two.is_contiguous(memory_format=torch.channels_last)
+    assert (got.double() - ref).abs().max().item() < TOL * ref.abs().max().item()
+    assert (got - two).abs().max().item() <= 1e-6 * float(two.abs().max())
+    assert float(got.nw_amax.max()) == float(got.abs().max())
+    if room:
+        assert got.nw_slab.shape[1] == 64 + room
+    x2 = x.clone()
+    x2[0, 1, h // 2, w // 2] = float("nan")
+    a, c = ops.stem_conv_relu_maxpool_nhwc(x2, sw, b), ops.maxpool3s2_nhwc(ops.conv2d_nhwc(x2, sw, b, None, True, 2, 3))
+    # the NaN reaches exactly the pooled pixels whose windows hold a convolution output that read the pixel (kx = 7 of the padded
+    # 8-pixel run does not exist: 0 x NaN there must not count; torch's own kernels spread a NaN further)
+    hit = F.conv2d(torch.isnan(x2).float(), torch.ones(1, 3, 7, 7, device=dev), None, 2, 3) > 0
+    want = (F.max_pool2d(hit.float(), 3, 2, 1) > 0).expand(-1, 64, -1, -1)
+    assert torch.equal(torch.isnan(a), want) and torch.equal(torch.isnan(c), want)
