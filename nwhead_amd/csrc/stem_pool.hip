@@ -13,9 +13,9 @@
 // kernel ROW is one 32-wide k chunk, and the eight k values a lane holds (4 kx + ci, kx = 2 g, 2 g + 1) are two neighbouring
 // input pixels: 16 bytes of the split patch in LDS, no gather.
 //
-// Persistent 512-thread workgroups: the 56 KB weight image (swizzled like conv_nhwc.hip's) is staged once; per tile the input
-// patch (23 x 56 pixels: requested one tile ahead, in registers) is split into an h and an l plane in LDS, eight waves multiply
-// two 16-pixel blocks x 64 channels each (7 k chunks), the results pass through bias + ReLU into a (225, 64) LDS map -- pixels
+// Persistent 512-thread workgroups: every wave keeps the weight fragments of ITS 32 channels in registers (112 of them, loaded
+// once); per tile the input patch (23 x 56 pixels: requested one tile ahead, in registers) is split into an h and an l plane in
+// LDS, eight waves multiply four 16-pixel blocks x 32 channels each (7 k chunks), the results pass through bias + ReLU into a (225, 64) LDS map -- pixels
 // outside the image as 0, which under a ReLU is the max pool's own padding -- and 48 x 16 float4 maxima go out, with the amax
 // record of what was written.
 #include "nw_internal.h"
@@ -29,10 +29,9 @@ constexpr int SP_TPH = 4, SP_TPW = 12;                 // pooled pixels per tile
 constexpr int SP_CH = 2 * SP_TPH + 1, SP_CW = 2 * SP_TPW + 1;   // convolution outputs under them: 9 x 25
 constexpr int SP_NPX = SP_CH * SP_CW;                  // 225 (16 blocks of 16: 256 slots)
 constexpr int SP_PR = 2 * SP_CH + 5, SP_PC = 2 * SP_CW + 6;     // input patch: 23 x 56 pixels of 4 channels
-constexpr int SP_WB = 7 * 64 * 128;                    // weight image bytes
 constexpr int SP_PB = SP_PR * SP_PC * 8;               // one plane (h or l) of the patch: 4 halves per pixel
 constexpr int SP_OS = 272;                             // bytes between two pixels of the result map (64 floats + 16: fewer bank conflicts)
-constexpr int SP_LDS = SP_WB + 2 * SP_PB + SP_NPX * SP_OS;
+constexpr int SP_LDS = 2 * SP_PB + SP_NPX * SP_OS;
 constexpr int SP_NLD = (SP_PR * SP_PC + 511) / 512;    // patch pixels per thread
 static_assert(SP_LDS <= 160 * 1024 - 256, "LDS");
 
@@ -45,8 +44,7 @@ struct StemP {
 
 __global__ __launch_bounds__(512, 1) void nw_stem_pool_kernel(const StemP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const wl = smem;
-    char* const ph = smem + SP_WB;
+    char* const ph = smem;
     char* const pl = ph + SP_PB;
     char* const om = pl + SP_PB;
     __shared__ float red[8];
@@ -60,18 +58,19 @@ __global__ __launch_bounds__(512, 1) void nw_stem_pool_kernel(const StemP p) {
     }
     const int ex = split_exponent(amx);
     const float up = __builtin_ldexpf(1.f, ex), inv_up = __builtin_ldexpf(1.f, -ex);
-    // the weight image: [k chunk][output channel][128 B], 16-byte slots swizzled with (row >> 1) & 7 (conv_nhwc.hip's reads)
-    for (int f0 = 0; f0 < 7 * 64 * 8; f0 += 512 * 7) {
-        float4 v[7];
+    // This wave's share: channel blocks 2 hc, 2 hc + 1 (32 channels) x pixel blocks 4 pq .. 4 pq + 3 (64 convolution outputs).  Its
+    // weight fragments -- 2 blocks x 7 kernel rows x (h, l): 112 registers -- are loaded ONCE and stay: no weight image in LDS, and
+    // the fragment traffic of a tile is the activations' alone (as a 56 KB LDS image read by all eight waves it was 2/3 of it)
+    const int hc = wave & 1, pq = wave >> 1;
+    half8 ah[2][7], al[2][7];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) v[r] = *reinterpret_cast<const float4*>(p.ws + (size_t)(f0 + r * 512 + tid) * 16);
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const int f = f0 + r * 512 + tid;                      // global: row co (7 x 128 B), chunk q, slot
-            const int co = f / 56, u = f - co * 56, q = u >> 3, slot = u & 7;
-            *reinterpret_cast<float4*>(wl + q * 8192 + co * 128 + ((slot ^ ((co >> 1) & 7)) << 4)) = v[r];
+        for (int ky = 0; ky < 7; ++ky) {
+            const char* src = p.ws + (size_t)(16 * (2 * hc + a) + i) * 896 + ky * 128 + g * 16;
+            ah[a][ky] = *reinterpret_cast<const half8*>(src);
+            al[a][ky] = *reinterpret_cast<const half8*>(src + 64);
         }
-    }
     const int per_img = p.tx * p.ty, ntiles = p.N * per_img;
     auto origin = [&](int t, int& n, int& py0, int& px0) {
         n = t / per_img;
@@ -93,17 +92,22 @@ __global__ __launch_bounds__(512, 1) void nw_stem_pool_kernel(const StemP p) {
             pre[j] = ok ? *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + iy) * p.W + ix) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    const int asw = (i >> 1) & 7;
-    const int aoff_h = i * 128 + ((g ^ asw) << 4), aoff_l = i * 128 + (((4 + g) ^ asw) << 4);
-    // this wave's two pixel blocks: convolution outputs p = 32 wave + 16 b + i of the tile (slots past 224: a dummy pixel 0)
-    int boff[2];
-    bool bok[2];
+    // this wave's four pixel blocks: convolution outputs px = 64 pq + 16 b + i of the tile (slots past 224: a dummy pixel 0)
+    int boff[4];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int px = 32 * wave + 16 * b + i;
-        bok[b] = px < SP_NPX;
-        const int q = bok[b] ? px : 0, cy = q / SP_CW, cx = q - cy * SP_CW;
+    for (int b = 0; b < 4; ++b) {
+        const int px = 64 * pq + 16 * b + i;
+        const int q = px < SP_NPX ? px : 0, cy = q / SP_CW, cx = q - cy * SP_CW;
         boff[b] = ((2 * cy) * SP_PC + 2 * cx + 2 * g) * 8;          // + ky SP_PC 8 per kernel row
+    }
+    // the lane's per-channel factors (channels 16 a + 4 g .. + 3), once: requested per tile they cost an L2 round trip each
+    float4 sc4[2], bi4[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int co = 16 * (2 * hc + a) + 4 * g;
+        const float4 s4 = *reinterpret_cast<const float4*>(p.wscale + co);
+        sc4[a] = make_float4(s4.x * inv_up, s4.y * inv_up, s4.z * inv_up, s4.w * inv_up);
+        bi4[a] = *reinterpret_cast<const float4*>(p.bias + co);
     }
     float mx = 0.f;
     int t = blockIdx.x;
@@ -130,56 +134,55 @@ __global__ __launch_bounds__(512, 1) void nw_stem_pool_kernel(const StemP p) {
         }
         __syncthreads();
         if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);  // the next tile's patch rides under this tile's arithmetic
-        f32x4 acc[4][2];
+        f32x4 acc[2][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        half8 bh[1][4], bl[1][4];
+        auto frags = [&](int set, int ky) {
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            half8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                ah[a] = *reinterpret_cast<const half8*>(wl + ky * 8192 + (16 * a) * 128 + aoff_h);
-                al[a] = *reinterpret_cast<const half8*>(wl + ky * 8192 + (16 * a) * 128 + aoff_l);
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                bh[b] = *reinterpret_cast<const half8*>(ph + boff[b] + ky * SP_PC * 8);
-                bl[b] = *reinterpret_cast<const half8*>(pl + boff[b] + ky * SP_PC * 8);
+            for (int b = 0; b < 4; ++b) {
+                bh[set][b] = *reinterpret_cast<const half8*>(ph + boff[b] + ky * SP_PC * 8);
+                bl[set][b] = *reinterpret_cast<const half8*>(pl + boff[b] + ky * SP_PC * 8);
                 if (g == 3) {          // kx = 7 does not exist: its weights are zeros, but 0 x NaN / inf of the pixel next door is not
 #pragma unroll
-                    for (int e = 4; e < 8; ++e) { bh[b][e] = (_Float16)0.f; bl[b][e] = (_Float16)0.f; }
+                    for (int e = 4; e < 8; ++e) { bh[set][b][e] = (_Float16)0.f; bl[set][b][e] = (_Float16)0.f; }
                 }
             }
+        };
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+        for (int ky = 0; ky < 7; ++ky) {
+            constexpr int s_ = 0;
+            frags(0, ky);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a][ky], bh[s_][b], acc[a][b], 0, 0, 0);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a][ky], bl[s_][b], acc[a][b], 0, 0, 0);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a][ky], bh[s_][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // bias + ReLU into the result map; a convolution output outside the image counts as 0 (<= every ReLU output: the pool's padding)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int px = 32 * wave + 16 * b + i;
+        for (int b = 0; b < 4; ++b) {
+            const int px = 64 * pq + 16 * b + i;
             if (px < SP_NPX) {
                 const int cy = px / SP_CW, cx = px - cy * SP_CW;
                 const int ay = 2 * py0 - 1 + cy, ax = 2 * px0 - 1 + cx;
                 const bool in = ay >= 0 && ay < p.Ho && ax >= 0 && ax < p.Wo;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const int co = 16 * a + 4 * g;
-                    const float4 s4 = *reinterpret_cast<const float4*>(p.wscale + co), b4 = *reinterpret_cast<const float4*>(p.bias + co);
+                for (int a = 0; a < 2; ++a) {
+                    const int co = 16 * (2 * hc + a) + 4 * g;
                     float4 v;
-                    v.x = __builtin_fmaf(acc[a][b][0], s4.x * inv_up, b4.x); v.y = __builtin_fmaf(acc[a][b][1], s4.y * inv_up, b4.y);
-                    v.z = __builtin_fmaf(acc[a][b][2], s4.z * inv_up, b4.z); v.w = __builtin_fmaf(acc[a][b][3], s4.w * inv_up, b4.w);
+                    v.x = __builtin_fmaf(acc[a][b][0], sc4[a].x, bi4[a].x); v.y = __builtin_fmaf(acc[a][b][1], sc4[a].y, bi4[a].y);
+                    v.z = __builtin_fmaf(acc[a][b][2], sc4[a].z, bi4[a].z); v.w = __builtin_fmaf(acc[a][b][3], sc4[a].w, bi4[a].w);
                     v.x = (in && !(v.x < 0.f)) ? v.x : 0.f; v.y = (in && !(v.y < 0.f)) ? v.y : 0.f;      // (!(v < 0): keeps a NaN, like torch's relu)
                     v.z = (in && !(v.z < 0.f)) ? v.z : 0.f; v.w = (in && !(v.w < 0.f)) ? v.w : 0.f;
                     *reinterpret_cast<float4*>(om + px * SP_OS + co * 4) = v;
