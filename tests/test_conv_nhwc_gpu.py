@@ -1033,3 +1033,22 @@ def test_fused_stem_against_convolution_plus_pool(dev, n, h, w, room):
     hit = F.conv2d(torch.isnan(x2).float(), torch.ones(1, 3, 7, 7, device=dev), None, 2, 3) > 0
     want = (F.max_pool2d(hit.float(), 3, 2, 1) > 0).expand(-1, 64, -1, -1)
     assert torch.equal(torch.isnan(a), want) and torch.equal(torch.isnan(c), want)
+
+
+def test_fused_stem_on_random_shapes(dev):
+    """The fused stem against convolution + pool on twenty random image sizes (7 .. 150 pixels a side, 1 .. 4 images): tiles cut
+    by the right and bottom edges, maps smaller than one tile, odd convolution and pool sizes."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(11)
+    wt = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).to(dev)
+    b = (torch.randn(64, generator=g) * 0.3).to(dev)
+    sw = ops.SplitConvWeight(wt)
+    for _ in range(20):
+        n = int(torch.randint(1, 5, (1,), generator=g))
+        h, w = (int(v) for v in torch.randint(7, 151, (2,), generator=g))
+        x = (torch.randn(n, 3, h, w, generator=g) * 2.0).to(dev)
+        got = ops.stem_conv_relu_maxpool_nhwc(x, sw, b)
+        two = ops.maxpool3s2_nhwc(ops.conv2d_nhwc(x, sw, b, None, True, 2, 3))
+        assert got.shape == two.shape, (n, h, w)
+        assert (got - two).abs().max().item() <= 1e-6 * max(float(two.abs().max()), 1e-30), (n, h, w)
+        assert float(got.nw_amax.max()) == float(got.abs().max())
