@@ -556,6 +556,11 @@ int nw_stem7x7s2_relu_maxpool_supported(int64_t n, int64_t H, int64_t W, int64_t
 int nw_stem7x7s2_relu_maxpool_f16x2(const float *x4, const float *amax_in, const float *w_split, const float *w_scale,
                                     const float *bias, float *y, float *amax_out, int64_t n, int64_t H, int64_t W, int64_t ldy,
                                     void *stream);
+/* An eval-mode DenseNet transition's BatchNorm + ReLU with its 2 x 2 average pool in front of the bias-free 1 x 1 convolution
+ * (model/densenet.py:83-91 runs norm -> relu -> conv -> pool; pool and convolution commute): y = avgpool2x2(relu((x - mean) a + beta)),
+ * tab = mean | a | beta (c floats apart), rows of x / y may be strided (ldx, ldy; 0: c); amax_out (nullable): the record of y. */
+int nw_bn_relu_avgpool2x2_nhwc_f32(const float *x, int64_t ldx, const float *tab, float *y, int64_t ldy, float *amax_out,
+                                   int64_t n, int64_t h, int64_t w, int64_t c, void *stream);
 /* The end of a residual block in training (model/resnet.py:60-66, :100-108: out = relu(bn(.) + identity)) over two tensors of
  * equal layout, `count` floats each (a multiple of 4), 16-byte aligned: nw_add_relu_f32 writes out = relu(a + b) (x < 0 ? 0 : x:
  * keeps a NaN) and out's amax record; nw_relu_bwd_f32 writes dx = g where out > 0, else 0 -- the gradient of BOTH summands --

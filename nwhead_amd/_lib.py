@@ -63,6 +63,7 @@ SIGNATURES = {
                                                            _i64, _p]),
     "nw_stem7x7s2_relu_maxpool_supported": (_int, [_i64] * 4),
     "nw_stem7x7s2_relu_maxpool_f16x2": (_int, [_p] * 7 + [_i64] * 4 + [_p]),
+    "nw_bn_relu_avgpool2x2_nhwc_f32": (_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "nw_add_relu_f32": (_int, [_p, _p, _p, _p, _i64, _p]),
     "nw_relu_bwd_f32": (_int, [_p, _p, _p, _p, _i64, _p]),
     "nw_bn_dgrad1x1_workspace_bytes": (_sz, [_i64, _i64]),

@@ -129,6 +129,42 @@ inline bool bad_dims(int64_t n, int64_t h, int64_t w, int64_t c) {
 }
 
 
+// y = avgpool2x2(relu((x - mean) a + beta)): an eval-mode DenseNet transition's BatchNorm + ReLU with the pool in FRONT of its
+// bias-free 1 x 1 convolution (the two commute: both linear, per pixel / per channel; model/densenet.py:83-91 runs conv -> pool):
+// the convolution then works on a quarter of the pixels.  tab: mean | a | beta (C floats apart).  amax record of y.
+__global__ __launch_bounds__(1024) void nw_bn_relu_avgpool2_nhwc_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ tab,
+                                                                       float* __restrict__ y, int64_t ldy, float* __restrict__ amax, int H,
+                                                                       int W, int Ho, int Wo, int C, int q4, int64_t total) {
+    __shared__ float red[16];
+    float mx = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = idx / q4;                    // output pixel (n, oy, ox)
+        const int c = (int)(idx - p * q4) * 4;
+        const int ox = (int)(p % Wo);
+        const int64_t t = p / Wo;
+        const int oy = (int)(t % Ho);
+        const int64_t n = t / Ho;
+        const float* r0 = x + ((n * H + 2 * oy) * W + 2 * ox) * ldx + c;
+        const float* r1 = r0 + (int64_t)W * ldx;
+        const float4 v[4] = {*reinterpret_cast<const float4*>(r0), *reinterpret_cast<const float4*>(r0 + ldx),
+                             *reinterpret_cast<const float4*>(r1), *reinterpret_cast<const float4*>(r1 + ldx)};
+        const float4 m = *reinterpret_cast<const float4*>(tab + c), a = *reinterpret_cast<const float4*>(tab + C + c),
+                     b = *reinterpret_cast<const float4*>(tab + 2 * C + c);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                  // (x < 0 ? 0 : x keeps a NaN, like torch's relu; torch's pool: the sum, then x 0.25)
+            const float e0 = __builtin_fmaf(v[k].x - m.x, a.x, b.x), e1 = __builtin_fmaf(v[k].y - m.y, a.y, b.y);
+            const float e2 = __builtin_fmaf(v[k].z - m.z, a.z, b.z), e3 = __builtin_fmaf(v[k].w - m.w, a.w, b.w);
+            s.x += e0 < 0.f ? 0.f : e0; s.y += e1 < 0.f ? 0.f : e1; s.z += e2 < 0.f ? 0.f : e2; s.w += e3 < 0.f ? 0.f : e3;
+        }
+        s.x *= 0.25f; s.y *= 0.25f; s.z *= 0.25f; s.w *= 0.25f;
+        mx = fmaxf(mx, fmaxf(fmaxf(s.x, s.y), fmaxf(s.z, s.w)));
+        *reinterpret_cast<float4*>(y + p * ldy + c) = s;
+    }
+    mx = nw::block_max(mx, red);
+    if (amax && threadIdx.x < 256 && (int)threadIdx.x % (int)gridDim.x == (int)blockIdx.x) amax[threadIdx.x] = threadIdx.x == blockIdx.x ? mx : 0.f;
+}
+
 // out = relu(a + b) at the end of a residual block (model/resnet.py:60-66, :100-108), x < 0 ? 0 : x (keeps a NaN, like torch's
 // relu), with the amax record of out: slots b, b + n, ... of the record belong to workgroup b of n
 __global__ __launch_bounds__(1024) void nw_add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
@@ -251,6 +287,22 @@ extern "C" int nw_relu_bwd_f32(const float* out, const float* g, float* dx, floa
     const int rc = ew_args(out, g, dx, amax_out, count);
     if (rc != NW_OK) return rc;
     hipLaunchKernelGGL(nw_relu_bwd_kernel, dim3(ew_grid(count / 4)), dim3(1024), 0, static_cast<hipStream_t>(stream), out, g, dx, amax_out, count / 4);
+    NW_CHECK_LAUNCH();
+    return NW_OK;
+}
+
+extern "C" int nw_bn_relu_avgpool2x2_nhwc_f32(const float* x, int64_t ldx, const float* tab, float* y, int64_t ldy, float* amax_out,
+                                              int64_t n, int64_t h, int64_t w, int64_t c, void* stream) {
+    if (bad_dims(n, h, w, c) || h < 2 || w < 2) return NW_ERR_INVALID_ARG;
+    if (ldx == 0) ldx = c;
+    if (ldy == 0) ldy = c;
+    if (ldx < c || ldx % 4 || ldy < c || ldy % 4) return NW_ERR_INVALID_ARG;
+    if (n == 0) return NW_OK;
+    if (!x || !y || !tab || misaligned(x) || misaligned(y) || misaligned(tab) || misaligned(amax_out)) return NW_ERR_INVALID_ARG;
+    const int Ho = (int)(h / 2), Wo = (int)(w / 2), q4 = (int)(c / 4);
+    const int64_t total = n * Ho * Wo * q4;
+    hipLaunchKernelGGL(nw_bn_relu_avgpool2_nhwc_kernel, dim3(ew_grid(total)), dim3(1024), 0, static_cast<hipStream_t>(stream), x, ldx, tab, y,
+                       ldy, amax_out, (int)h, (int)w, Ho, Wo, (int)c, q4, total);
     NW_CHECK_LAUNCH();
     return NW_OK;
 }

@@ -625,7 +625,12 @@ class DenseNet(nn.Module):
                 y = ops.dense_block_nhwc_infer(y, pl)
             else:
                 tab, wt = pl
-                y = ops.avgpool2_nhwc(ops.conv1x1_bnrelu_nhwc_infer(y, tab, wt), rooms[i + 1])
+                if TRANSITION_POOL_FIRST and y.shape[2] >= 2 and y.shape[3] >= 2:
+                    # BatchNorm + ReLU + the 2 x 2 average in one pass, then the (bias-free: it commutes with the pool) 1 x 1
+                    # convolution on a quarter of the pixels, written straight into the next block's slab
+                    y = ops.conv2d_nhwc(ops.bn_relu_avgpool2_nhwc(y, tab), wt, None, None, False, 1, 0, room=rooms[i + 1])
+                else:
+                    y = ops.avgpool2_nhwc(ops.conv1x1_bnrelu_nhwc_infer(y, tab, wt), rooms[i + 1])
         y = ops.bn_relu_nhwc_apply(y, *plan["norm5"])           # norm5 + the relu of DenseNet.forward (densenet.py:139, :160)
         return torch.flatten(F.adaptive_avg_pool2d(y, (1, 1)), 1)
 

@@ -1744,6 +1744,23 @@ def bn_relu_nhwc_apply(x, mean, invstd, gamma, beta, relu=True):
     return y
 
 
+@torch.no_grad()
+def bn_relu_avgpool2_nhwc(x, tab):
+    """avgpool2x2(relu((x - mean) a + beta)) over a channels-last fp32 activation (tab = bn_table(bn)): an eval-mode DenseNet
+    transition's norm -> relu with the pool pulled in front of the 1 x 1 convolution (nw_bn_relu_avgpool2x2_nhwc_f32)."""
+    _need_hip(x, tab)
+    lib = _lib.load()
+    xv, ldx = _nhwc_rows(x)
+    n, c, h, w = xv.shape
+    y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=xv.device, memory_format=torch.channels_last)
+    amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=xv.device)
+    with _OnDevice(xv.device):
+        _lib.check(lib.nw_bn_relu_avgpool2x2_nhwc_f32(_ptr(xv), ldx, _ptr(tab), _ptr(y), 0, _ptr(amax), n, h, w, c, _stream(xv)),
+                   "nw_bn_relu_avgpool2x2_nhwc_f32")
+    y.nw_amax = amax
+    return y
+
+
 def bn_table(bn):
     """mean | a | beta (3 c floats) of an eval-mode BatchNorm2d for nw_conv2d_nhwc_bnrelu_f16x2: y = (x - mean) a + beta."""
     a = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)

@@ -1052,3 +1052,23 @@ def test_fused_stem_on_random_shapes(dev):
         assert got.shape == two.shape, (n, h, w)
         assert (got - two).abs().max().item() <= 1e-6 * max(float(two.abs().max()), 1e-30), (n, h, w)
         assert float(got.nw_amax.max()) == float(got.abs().max())
+
+
+@pytest.mark.parametrize("n,c,h,w,wide", [(2, 64, 8, 8, 0), (3, 256, 28, 28, 0), (2, 96, 9, 7, 128), (1, 4, 2, 3, 0)])
+def test_bn_relu_avgpool2_nhwc_against_torch(dev, n, c, h, w, wide):
+    """ops.bn_relu_avgpool2_nhwc (nw_bn_relu_avgpool2x2_nhwc_f32: an eval-mode transition's norm -> relu with the 2 x 2 average pulled
+    in front of the 1 x 1 convolution, model/densenet.py:83-91) against torch, odd sizes (the last row / column dropped), a channel
+    prefix of a wider tensor, the amax record."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(c + h)
+    full = _cl((torch.randn(n, max(wide, c), h, w, generator=g) * 1.5 + 0.4).to(dev))
+    x = full[:, :c]
+    bn = torch.nn.BatchNorm2d(c).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5); bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(c, generator=g) * 0.5); bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        got = ops.bn_relu_avgpool2_nhwc(x, ops.bn_table(bn))
+        ref = F.avg_pool2d(F.relu(bn(x)), 2, 2)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got - ref).abs().max().item() < 2e-6 * float(ref.abs().max())
+    assert float(got.nw_amax.max()) == float(got.abs().max())
