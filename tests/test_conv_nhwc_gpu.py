@@ -527,7 +527,7 @@ def test_densenet_training_step_nhwc_against_fp64(dev):
     assert c1 > 0.9999 and (1 - c1) < 3 * (1 - c0) + 1e-7, (c0, c1)
 
 
-@pytest.mark.parametrize("arch,size,batch", [("resnet18", 96, 6), ("resnet50", 96, 6), ("CIFAR_ResNet18", 32, 16)])
+@pytest.mark.parametrize("arch,size,batch", [("resnet18", 96, 6), ("resnet50", 96, 6), ("CIFAR_ResNet18", 32, 16), ("CIFAR_DenseNet121", 32, 8)])
 def test_resnet_training_step_nhwc_against_fp64(dev, arch, size, batch):
     """The ResNets' (ImageNet-style and the CIFAR pre-activation one) training forward + backward on the channels-last path (round 4: own convolutions incl. the
     strided 3x3 / 2 and 1x1 / 2 data and weight gradients and the 7x7 / 2 stem, own NHWC BatchNorm, own max pool;
@@ -546,8 +546,8 @@ def test_resnet_training_step_nhwc_against_fp64(dev, arch, size, batch):
     t = torch.randn(batch, out_dim, device=dev)
 
     def run(model, xx, tt, nhwc):
-        old = BB.RESNET_NHWC_TRAINING
-        BB.RESNET_NHWC_TRAINING = nhwc
+        old = BB.RESNET_NHWC_TRAINING, BB.CIFAR_DENSENET_NHWC_TRAINING
+        BB.RESNET_NHWC_TRAINING = BB.CIFAR_DENSENET_NHWC_TRAINING = nhwc
         try:
             for m in model.modules():
                 if isinstance(m, torch.nn.BatchNorm2d):
@@ -556,7 +556,7 @@ def test_resnet_training_step_nhwc_against_fp64(dev, arch, size, batch):
             out = model(xx)
             (out * tt).sum().backward()
         finally:
-            BB.RESNET_NHWC_TRAINING = old
+            BB.RESNET_NHWC_TRAINING, BB.CIFAR_DENSENET_NHWC_TRAINING = old
         stats = torch.cat([b.detach().double().flatten() for k, b in model.named_buffers() if "running" in k])
         return out.detach().double(), torch.cat([p.grad.detach().double().flatten() for p in model.parameters()]), stats
 
