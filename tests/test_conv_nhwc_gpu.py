@@ -1072,3 +1072,77 @@ def test_bn_relu_avgpool2_nhwc_against_torch(dev, n, c, h, w, wide):
     assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert (got - ref).abs().max().item() < 2e-6 * float(ref.abs().max())
     assert float(got.nw_amax.max()) == float(got.abs().max())
+
+
+def test_strided_gradients_on_random_shapes(dev):
+    """ops.conv2d_nhwc_train with stride 2 on fifteen random shapes (3x3 / pad 1 and 1x1 / pad 0, 32 .. 160 channels, maps of 5 .. 40
+    pixels a side, odd sizes): data gradient (zero-dilated gy) and weight gradient (one 1x1 problem per tap) against fp64 autograd."""
+    from nwhead_amd import ops
+    g = torch.Generator().manual_seed(23)
+    for _ in range(15):
+        n = int(torch.randint(1, 4, (1,), generator=g))
+        cin, cout = (32 * int(v) for v in torch.randint(1, 6, (2,), generator=g))
+        h, w = (int(v) for v in torch.randint(5, 41, (2,), generator=g))
+        k = 3 if float(torch.rand(1, generator=g)) < 0.6 else 1
+        pad = k // 2
+        x0 = _cl(torch.randn(n, cin, h, w, generator=g).to(dev))
+        w0 = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
+        x64, w64 = x0.double().requires_grad_(True), w0.double().requires_grad_(True)
+        y64 = F.conv2d(x64, w64, None, 2, pad)
+        t = torch.randn(y64.shape, generator=g).to(dev)
+        (y64 * t.double()).sum().backward()
+        x, wp = x0.clone().requires_grad_(True), torch.nn.Parameter(w0.clone())
+        y = ops.conv2d_nhwc_train(x, wp, 2, pad)
+        (y * _cl(t)).sum().backward()
+        tag = (n, cin, cout, h, w, k)
+        assert (y.double() - y64).abs().max().item() < TOL * y64.abs().max().item(), tag
+        assert (x.grad.double() - x64.grad).abs().max().item() < 2e-5 * x64.grad.abs().max().item(), tag
+        assert (wp.grad.double() - w64.grad).abs().max().item() < 2e-5 * w64.grad.abs().max().item(), tag
+
+
+def test_fused_norm1_backward_on_random_shapes(dev):
+    """nw_bn_dgrad1x1_bwd_f16x2 on twelve random shapes (rows 1 .. 3000, c = 32 .. 800, k = 32 .. 128, slab wider than c) against the
+    two-step path (data-gradient convolution + nw_bn_relu_nhwc_train_bwd_f32)."""
+    from nwhead_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(29)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    for _ in range(12):
+        rows = int(torch.randint(2, 3001, (1,), generator=g))
+        c = 32 * int(torch.randint(1, 26, (1,), generator=g))
+        mid = 32 * int(torch.randint(1, 5, (1,), generator=g))
+        ctot = c + 32 * int(torch.randint(0, 3, (1,), generator=g))
+        slab = (torch.randn(rows, ctot, generator=g) * 1.2 + 0.3).to(dev)
+        gamma = ((torch.rand(c, generator=g) + 0.5) * torch.where(torch.rand(c, generator=g) < 0.2, -1.0, 1.0)).to(dev)
+        beta = (torch.randn(c, generator=g) * 0.5).to(dev)
+        wt = (torch.randn(mid, c, generator=g) / c ** 0.5).to(dev)
+        du = torch.randn(rows, mid, generator=g).to(dev)
+        G0 = torch.randn(rows, ctot, generator=g).to(dev)
+        x = slab[:, :c]
+        mean = x.mean(0).contiguous()
+        inv = (1.0 / torch.sqrt(x.var(0, unbiased=False) + 1e-5)).contiguous()
+        tab = torch.cat([mean, gamma * inv, beta]).contiguous()
+        d1 = ops.SplitConvWeight(wt.t().reshape(c, mid, 1, 1).contiguous())
+        am_du = ops.absmax(du)
+        G, am_g = G0.clone(), torch.empty(ops.AMAX_SLOTS, device=dev)
+        dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        fb = lib.nw_bn_dgrad1x1_workspace_bytes(rows, c)
+        ws = torch.empty(fb // 4, device=dev)
+        _lib.check(lib.nw_bn_dgrad1x1_bwd_f16x2(P(du), P(am_du), P(d1.split), P(d1.scale), P(slab), ctot, P(tab), c, P(inv), P(G), ctot,
+                                                P(am_g), P(dg), P(db), P(ws), fb, rows, c, mid, st), "nw_bn_dgrad1x1_bwd_f16x2")
+        dt1, am_t = torch.empty(rows, c, device=dev), torch.empty(ops.AMAX_SLOTS, device=dev)
+        _lib.check(lib.nw_conv2d_nhwc_f16x2(P(du), P(am_du), P(d1.split), P(d1.scale), None, None, 0, P(dt1), P(am_t), 1, rows, 1, mid, c, 1,
+                                            1, 1, 0, 0, 0, None, st), "nw_conv2d_nhwc_f16x2")
+        G2 = G0.clone()
+        dg2, db2, am2 = torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(ops.AMAX_SLOTS, device=dev)
+        bnb = lib.nw_bn_nhwc_workspace_bytes(rows, c)
+        ws2 = torch.empty(bnb // 4 + 4, device=dev)
+        _lib.check(lib.nw_bn_relu_nhwc_train_bwd_f32(P(slab), ctot, P(dt1), P(gamma), P(beta), P(mean), P(inv), P(G2), P(dg2), P(db2), P(G2),
+                                                     ctot, ctot, P(am2), P(ws2), bnb, rows, c, 1, st), "nw_bn_relu_nhwc_train_bwd_f32")
+        tag = (rows, c, mid, ctot)
+        sc = lambda t_: max(float(t_.abs().max()), 1e-12)
+        assert (G[:, :c] - G2[:, :c]).abs().max().item() < 3e-5 * sc(G2[:, :c]), tag
+        assert torch.equal(G[:, c:], G0[:, c:]), tag
+        assert (dg - dg2).abs().max().item() < 3e-5 * sc(dg2) and (db - db2).abs().max().item() < 3e-5 * sc(db2), tag
+        assert float(am_g.max()) == float(G[:, :c].abs().max()), tag
