@@ -7,6 +7,7 @@
 // ORIGINAL values (the pow(2).sum(-1) half of torch.cdist's matmul form).
 // One wave per row; HBM-bound streaming (8*d bytes per row).
 #include "nw_internal.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace nw {
@@ -155,23 +156,52 @@ __global__ __launch_bounds__(256) void nw_split_conv_weights_kernel(const int64_
         const int ky = k >> 5, j = k & 31, kx = j >> 2, ci = j & 3;
         return (kx < KW && ci < Cin) ? src[((int64_t)row * Cin + ci) * T + ky * KW + kx] : 0.f;
     };
-    float mx = 0.f;
-    for (int k = lane; k < cols; k += 64) mx = fmaxf(mx, fabsf(at(k)));
-    mx = wave_max(mx);
-    int e = 0;
-    if (mx > 0.f && mx < INFINITY) {
-        frexpf(mx, &e);
-        e = 14 - e;
-        if (e > 126) e = 126;
-    }
-    const float up = ldexpf(1.f, e);
-    if (lane == 0) scale_base[jb[2] + row] = ldexpf(1.f, -e);
+    // Rows of up to 64 x 72 elements (a 3 x 3 x 512 weight's) stay in registers between the maximum and the split: the gathers of
+    // the transposed (data-gradient) form are strided by Cin T floats -- every element its own cache line -- and were made twice
+    // (ResNet-18: 308 -> 123 us per step).  Three register tiers, so that a short row does not walk 72 guarded slots.
     _Float16* dst = reinterpret_cast<_Float16*>(split_base + jb[1] + (int64_t)row * cols);
-    for (int k = lane; k < cols; k += 64) {         // element k -> half (k % 32) of the 32-k chunk k / 32; l sits 32 halves on
-        const float v = at(k) * up;
+    auto finish = [&](float mx) {
+        mx = wave_max(mx);
+        int e = 0;
+        if (mx > 0.f && mx < INFINITY) {
+            frexpf(mx, &e);
+            e = 14 - e;
+            if (e > 126) e = 126;
+        }
+        if (lane == 0) scale_base[jb[2] + row] = ldexpf(1.f, -e);
+        return ldexpf(1.f, e);
+    };
+    auto put = [&](int k, float x, float up) {      // element k -> half (k % 32) of the 32-k chunk k / 32; l sits 32 halves on
+        const float v = x * up;
         const _Float16 h = (_Float16)v;
         dst[(k >> 5) * 64 + (k & 31)] = h;
         dst[(k >> 5) * 64 + 32 + (k & 31)] = (_Float16)(v - (float)h);
+    };
+    auto in_registers = [&](auto nrc) {
+        constexpr int NR = decltype(nrc)::value;
+        float keep[NR];
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int k = lane + 64 * j;
+            keep[j] = k < cols ? at(k) : 0.f;
+            mx = fmaxf(mx, fabsf(keep[j]));
+        }
+        const float up = finish(mx);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int k = lane + 64 * j;
+            if (k < cols) put(k, keep[j], up);
+        }
+    };
+    if (cols <= 64 * 8) in_registers(std::integral_constant<int, 8>{});
+    else if (cols <= 64 * 24) in_registers(std::integral_constant<int, 24>{});
+    else if (cols <= 64 * 72) in_registers(std::integral_constant<int, 72>{});
+    else {
+        float mx = 0.f;
+        for (int k = lane; k < cols; k += 64) mx = fmaxf(mx, fabsf(at(k)));
+        const float up = finish(mx);
+        for (int k = lane; k < cols; k += 64) put(k, at(k), up);
     }
 }
 
